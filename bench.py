@@ -1,0 +1,247 @@
+#!/usr/bin/env python
+"""bench.py -- MeMOTR per-frame hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload msda|train]
+
+Prints ONE JSON line on rank 0 (contract in the task description).  Workloads:
+
+  msda   (kernel path) one step = the MSDeformAttn work of one 800x1333 training frame:
+         6 encoder calls (Lq = S = 22323) + 6 decoder calls (Lq = 300 + n_track), forward and
+         backward, fp32, inputs resident in HBM.  value = frames/s of that path.
+  train  (added when the model path lands) one step = one clip train step of train_dancetrack.yaml.
+
+Every rank works on its own synthetic frame (clips shard by rank; no data-path collective), so
+scaling is "weak".  The JSON carries
+  roofline      for the dominant kernel (encoder-shape forward): algorithmic bytes
+                / average launch duration, measured with HIP events on the launch stream
+  cpu_baseline  the reference's pure-PyTorch fallback formulation (oracle.grid_sample_forward, a port
+                of models/ops/functions/ms_deform_attn_func.py:44-64) on the host cores, rank 0, N=1.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default=os.environ.get("MEMOTR_BENCH_WORKLOAD", "msda"))
+    ap.add_argument("--dist", default="encoder_like", choices=["encoder_like", "uniform"])
+    ap.add_argument("--n-track", type=int, default=20, help="track queries carried into the frame (Lq = 300 + n)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=20.0)
+    return ap.parse_args()
+
+
+def init_dist(n_gpus):
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if world != n_gpus:
+        raise SystemExit(f"--gpus {n_gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    return rank, local_rank, world
+
+
+def barrier(world):
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+class MsdaCall:
+    """Pre-allocated buffers + raw C-ABI launches (no allocation inside the timed region)."""
+
+    def __init__(self, x):
+        from memotr_amd import _lib
+        self.lib = _lib.lib
+        self._lib = _lib
+        self.x = x
+        v, loc = x["value"], x["loc"]
+        self.N, self.S, self.M, self.D = v.shape
+        self.Lq, self.L, self.P = loc.shape[1], loc.shape[3], loc.shape[4]
+        self.out = torch.empty(self.N, self.Lq, self.M * self.D, device=v.device)
+        self.gv = torch.zeros_like(v)
+        self.gl = torch.empty_like(loc)
+        self.ga = torch.empty_like(x["attn"])
+
+    def fwd(self):
+        x = self.x
+        rc = self.lib.msda_forward_f32(x["value"].data_ptr(), x["shapes"].data_ptr(), x["level_start"].data_ptr(),
+                                       x["loc"].data_ptr(), x["attn"].data_ptr(), self.N, self.S, self.M, self.D,
+                                       self.L, self.Lq, self.P, self.out.data_ptr(), None,
+                                       torch.cuda.current_stream().cuda_stream)
+        if rc:
+            raise RuntimeError(self._lib.last_error())
+
+    def bwd(self):
+        x = self.x
+        rc = self.lib.msda_backward_f32(x["value"].data_ptr(), x["shapes"].data_ptr(), x["level_start"].data_ptr(),
+                                        x["loc"].data_ptr(), x["attn"].data_ptr(), x["grad_out"].data_ptr(), self.N,
+                                        self.S, self.M, self.D, self.L, self.Lq, self.P, self.gv.data_ptr(),
+                                        self.gl.data_ptr(), self.ga.data_ptr(), 1, None,
+                                        torch.cuda.current_stream().cuda_stream)
+        if rc:
+            raise RuntimeError(self._lib.last_error())
+
+    def bytes(self, backward=False):
+        from memotr_amd.synth import algorithmic_bytes
+        return algorithmic_bytes(self.N, self.S, self.Lq, self.M, self.D, self.L, self.P, 4, backward)
+
+
+def time_kernel(fn, iters=50, warmup=5):
+    """Average launch duration (ms) from HIP events on the launch stream."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def read_traffic():
+    """HBM bytes per launch from the committed PMC pass (profiles/traffic.json), or None."""
+    p = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(p) as f:
+            return json.load(f).get("msda_fwd_encoder_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def cpu_baseline_msda(args, enc_shape_kwargs, dec_shape_kwargs):
+    """Reference CPU fallback formulation on the host cores; bounded sample, scaled to frames/s."""
+    from memotr_amd.synth import make_inputs
+    from oracle import msda_oracle as oracle
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+
+    def one(kw):
+        x = make_inputs(device="cpu", **kw)
+        v = x["value"].requires_grad_(True)
+        loc = x["loc"].requires_grad_(True)
+        attn = x["attn"].requires_grad_(True)
+        t0 = time.perf_counter()
+        out = oracle.grid_sample_forward(v, x["shapes_list"], loc, attn)
+        out.backward(x["grad_out"])
+        return time.perf_counter() - t0
+
+    one(dec_shape_kwargs)  # warm
+    t_enc, t_dec, reps = [], [], 0
+    t_start = time.perf_counter()
+    while reps < 5 and (time.perf_counter() - t_start) < args.cpu_budget_s:
+        t_enc.append(one(enc_shape_kwargs))
+        t_dec.append(one(dec_shape_kwargs))
+        reps += 1
+    per_frame = 6 * min(t_enc) + 6 * min(t_dec)
+    return {
+        "value": 1.0 / per_frame, "unit": "frames/s", "cores": cores, "kind": "port",
+        "sample": f"{reps} reps of one encoder-shape + one decoder-shape fwd+bwd "
+                  f"(torch-CPU grid_sample formulation, {cores} threads), best rep x6 calls each per frame",
+        "enc_fwd_bwd_s": min(t_enc), "dec_fwd_bwd_s": min(t_dec),
+    }
+
+
+def run_msda(args, rank, world):
+    from memotr_amd.synth import make_inputs
+    dev = torch.device("cuda", torch.cuda.current_device())
+    enc_kw = dict(dist=args.dist, seed=3 + rank)
+    dec_kw = dict(dist=args.dist, seed=103 + rank, n_queries=300 + args.n_track)
+    enc = MsdaCall(make_inputs(device=dev, **enc_kw))
+    dec = MsdaCall(make_inputs(device=dev, **dec_kw))
+
+    def step():
+        for _ in range(6):
+            enc.fwd()
+        for _ in range(6):
+            dec.fwd()
+        for _ in range(6):
+            dec.bwd()
+        for _ in range(6):
+            enc.bwd()
+
+    for _ in range(args.warmup):
+        step()
+    barrier(world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier(world)
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    result = None
+    if rank == 0:
+        ms_fwd = time_kernel(enc.fwd)
+        kernel = enc._lib.last_kernel()
+        ms_bwd = time_kernel(enc.bwd, iters=20)
+        kernel_bwd = enc._lib.last_kernel()
+        ms_dec = time_kernel(dec.fwd)
+        ach = enc.bytes() / (ms_fwd * 1e-3) / 1e9
+        result = {
+            "metric": "msda_path_frames_per_sec", "value": world * args.steps / dt, "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "msda: 6 enc (Lq=S=22323) + 6 dec (Lq=%d) MSDeformAttn fwd+bwd per frame, "
+                                   "800x1333 pyramid, M=8 D=32 L=4 P=4, bs=1/GPU" % (300 + args.n_track),
+                       "loc_dist": args.dist, "parallelism": f"dp{world}"},
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBPS, "traffic": read_traffic(), "kernel": kernel,
+                         "ms": ms_fwd, "algorithmic_bytes": enc.bytes()},
+            "kernels": {
+                "enc_fwd_ms": ms_fwd, "enc_bwd_ms": ms_bwd, "dec_fwd_ms": ms_dec, "enc_bwd_kernel": kernel_bwd,
+                "enc_bwd_GBps": enc.bytes(True) / (ms_bwd * 1e-3) / 1e9,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline_msda(args, dict(dist=args.dist, seed=3),
+                                                       dict(dist=args.dist, seed=103, n_queries=300 + args.n_track))
+    return result
+
+
+def main():
+    args = parse_args()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    rank, _, world = init_dist(args.gpus)
+    if args.workload == "msda":
+        result = run_msda(args, rank, world)
+    elif args.workload == "train":
+        from memotr_amd.train_bench import run_train  # lands with the model path
+        result = run_train(args, rank, world)
+    else:
+        raise SystemExit(f"unknown workload {args.workload}")
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

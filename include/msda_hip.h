@@ -1,0 +1,131 @@
+/*
+ * include/msda_hip.h -- C ABI of libmsda_hip.so (gfx950 / MI355X).
+ *
+ * Multi-scale deformable attention: sampling-point gather + bilinear
+ * interpolation + attention-weight reduction, forward and backward.  This is the
+ * drop-in boundary for the only native component of MeMOTR: the entry points
+ * below are what the reference's extension module `MultiScaleDeformableAttention`
+ * binds.  Paths cited are under the reference repository root.
+ *
+ *   msda_forward_*   replaces  ms_deform_attn_forward   (models/ops/src/ms_deform_attn.h:20-39,
+ *                    models/ops/src/cuda/ms_deform_attn_cuda.cu:20-80, exported by
+ *                    models/ops/src/vision.cpp:14)
+ *   msda_backward_*  replaces  ms_deform_attn_backward  (models/ops/src/ms_deform_attn.h:41-61,
+ *                    models/ops/src/cuda/ms_deform_attn_cuda.cu:83-153, vision.cpp:15)
+ *
+ * Conventions
+ *   - Plain pointers and sizes only; no torch / ATen types.  All data pointers are
+ *     DEVICE pointers to contiguous row-major arrays:
+ *         value        (N, S, M, D)         S = sum_l H_l*W_l
+ *         shapes_dev   (L, 2) int64         (H_l, W_l)             [.cu:67,138]
+ *         lstart_dev   (L,)   int64         first row of level l    [.cu:68,139]
+ *         loc          (N, Lq, M, L, P, 2)  (x, y) normalised to [0,1] incl. padding
+ *         attn         (N, Lq, M, L, P)
+ *         out          (N, Lq, M*D)
+ *         grad_out     (N, Lq, M*D)
+ *         grad_value / grad_loc / grad_attn  shaped like value / loc / attn
+ *   - `shapes_host` (L,2 int64, HOST memory) is optional (may be NULL).  When given
+ *     it must equal shapes_dev; it lets the library plan level-aware launches
+ *     without a device->host read.  Results never depend on it.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls are
+ *     asynchronous, allocate nothing, never synchronise, hold no global state
+ *     besides the tuning options below, and are thread-safe.
+ *   - Buffers are borrowed for the duration of the enqueued work.  `out`,
+ *     `grad_loc`, `grad_attn` are fully overwritten.  `grad_value` is accumulated
+ *     into with hardware float atomics: it must be zero on entry (the reference
+ *     allocates it with at::zeros_like, .cu:121) unless `zero_grad_value` != 0, in
+ *     which case the library enqueues the memset itself.
+ *   - Return value: MSDA_OK (0) on success; a negative MSDA_E* code for argument
+ *     errors; a positive hipError_t if the launch failed (the reference only
+ *     printf()s those, ms_deform_im2col_cuda.cuh:948-952 -- here they are
+ *     reported).  msda_last_error() returns a thread-local description.
+ *   - Floating point: f32 and f64 as in the reference (AT_DISPATCH_FLOATING_TYPES,
+ *     .cu:64,134).  The *_bf16 entry points are an extension with no reference
+ *     counterpart: value / out / grad_out / grad_value-in-fp32 policy documented in
+ *     DESIGN.md.
+ *   - Integer/index arithmetic (floor of loc*size-0.5, corner indices, the
+ *     (-1,H)x(-1,W) gate, zero padding per corner) is bit-identical to the
+ *     reference kernels (.cuh:33-84,285-288); msda_sample_indices_f32 exposes it
+ *     for parity tests.
+ */
+#ifndef MSDA_HIP_H_
+#define MSDA_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSDA_OK 0
+#define MSDA_EINVAL (-1)   /* null pointer / non-positive dimension               */
+#define MSDA_ERANGE (-2)   /* a tensor is too large for 32-bit index arithmetic   */
+#define MSDA_ENOTSUP (-3)  /* dtype/shape combination not supported (bf16: D%8)   */
+
+/* ABI version: bumped on any signature change. */
+int msda_abi_version(void);
+
+/* Thread-local, never NULL; empty string when the last call succeeded. */
+const char *msda_last_error(void);
+
+/* ---- forward: replaces ms_deform_attn_forward (ms_deform_attn.h:20-39) ---- */
+int msda_forward_f32(const float *value, const int64_t *shapes_dev, const int64_t *lstart_dev,
+                     const float *loc, const float *attn,
+                     int N, int S, int M, int D, int L, int Lq, int P,
+                     float *out, const int64_t *shapes_host, void *stream);
+
+int msda_forward_f64(const double *value, const int64_t *shapes_dev, const int64_t *lstart_dev,
+                     const double *loc, const double *attn,
+                     int N, int S, int M, int D, int L, int Lq, int P,
+                     double *out, const int64_t *shapes_host, void *stream);
+
+/* value/out are bf16 (uint16 storage), loc/attn fp32, accumulation fp32. */
+int msda_forward_bf16(const uint16_t *value, const int64_t *shapes_dev, const int64_t *lstart_dev,
+                      const float *loc, const float *attn,
+                      int N, int S, int M, int D, int L, int Lq, int P,
+                      uint16_t *out, const int64_t *shapes_host, void *stream);
+
+/* ---- backward: replaces ms_deform_attn_backward (ms_deform_attn.h:41-61) ---- */
+int msda_backward_f32(const float *value, const int64_t *shapes_dev, const int64_t *lstart_dev,
+                      const float *loc, const float *attn, const float *grad_out,
+                      int N, int S, int M, int D, int L, int Lq, int P,
+                      float *grad_value, float *grad_loc, float *grad_attn,
+                      int zero_grad_value, const int64_t *shapes_host, void *stream);
+
+int msda_backward_f64(const double *value, const int64_t *shapes_dev, const int64_t *lstart_dev,
+                      const double *loc, const double *attn, const double *grad_out,
+                      int N, int S, int M, int D, int L, int Lq, int P,
+                      double *grad_value, double *grad_loc, double *grad_attn,
+                      int zero_grad_value, const int64_t *shapes_host, void *stream);
+
+/* value/grad_out bf16; grad_value accumulated in fp32 (N,S,M,D floats); grad_loc/grad_attn fp32. */
+int msda_backward_bf16(const uint16_t *value, const int64_t *shapes_dev, const int64_t *lstart_dev,
+                       const float *loc, const float *attn, const uint16_t *grad_out,
+                       int N, int S, int M, int D, int L, int Lq, int P,
+                       float *grad_value, float *grad_loc, float *grad_attn,
+                       int zero_grad_value, const int64_t *shapes_host, void *stream);
+
+/* ---- parity hook: the integer side of the sampling arithmetic ----
+ * For every (n,q,m,l,p): h_low = floor(loc_y*H_l - 0.5), w_low = floor(loc_x*W_l - 0.5)
+ * and gate = (-1 < h < H_l && -1 < w < W_l) as computed by the device function the
+ * kernels use (.cuh:285-288, :38-39).  Outputs are (N,Lq,M,L,P) int32/int32/uint8. */
+int msda_sample_indices_f32(const int64_t *shapes_dev, const float *loc,
+                            int N, int M, int L, int Lq, int P,
+                            int32_t *h_low, int32_t *w_low, uint8_t *gate, void *stream);
+
+/* ---- tuning knobs (benchmarks / tests only; defaults pick the fastest correct path) ----
+ * key: "fwd_variant" | "bwd_variant" (0 = auto, 1 = generic one-thread-per-output
+ *       kernels, >=2 = specialised kernels), "fwd_block" | "bwd_block"
+ *       (threads per block, multiple of 64), "fwd_grid_mult" | "bwd_grid_mult" (blocks per CU).
+ * Returns MSDA_OK or MSDA_EINVAL for an unknown key / bad value. */
+int msda_set_option(const char *key, int value);
+int msda_get_option(const char *key, int *value);
+
+/* Name of the kernel the last forward/backward call on this thread dispatched to
+ * (for profiles and tests; never NULL). */
+const char *msda_last_kernel(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSDA_HIP_H_ */

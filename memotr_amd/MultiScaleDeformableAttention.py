@@ -1,0 +1,126 @@
+"""Drop-in for the reference's compiled extension module ``MultiScaleDeformableAttention``.
+
+Same two entry points, argument order and error behaviour as the pybind module built from
+``models/ops/src/vision.cpp:13-16`` (signatures ``models/ops/src/ms_deform_attn.h:20-61``,
+host logic ``models/ops/src/cuda/ms_deform_attn_cuda.cu:20-153``), backed by the gfx950 HIP
+kernels behind the C ABI of ``include/msda_hip.h``.
+
+Differences, all deliberate:
+  * launch failures raise ``RuntimeError`` (the reference only ``printf``s them,
+    ``ms_deform_im2col_cuda.cuh:948-952``);
+  * ``torch.bfloat16`` value/grad_output with fp32 locations/weights is accepted (extension);
+  * ``im2col_step`` only participates in the divisibility check -- the kernels take the whole
+    batch in one launch (the reference loops over ``batch / im2col_step`` chunks, same result).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+_SUFFIX = {torch.float32: "f32", torch.float64: "f64", torch.bfloat16: "bf16"}
+
+
+def _check_inputs(named):
+    for name, t in named:
+        if not t.is_contiguous():
+            raise RuntimeError(f"{name} tensor has to be contiguous")
+    for name, t in named:
+        if not t.is_cuda:
+            # ms_deform_attn.h:38,60 -- the reference has no CPU implementation either
+            raise RuntimeError("Not implemented on the CPU" if name == "value" else f"{name} must be a CUDA tensor")
+
+
+def _dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
+    if value.dim() != 4 or sampling_loc.dim() != 6 or attn_weight.dim() != 5:
+        raise RuntimeError("expected value (N,S,M,D), sampling_loc (N,Lq,M,L,P,2), attn_weight (N,Lq,M,L,P)")
+    N, S, M, D = value.shape
+    L = spatial_shapes.shape[0]
+    Lq, P = sampling_loc.shape[1], sampling_loc.shape[4]
+    if tuple(sampling_loc.shape) != (N, Lq, M, L, P, 2) or tuple(attn_weight.shape) != (N, Lq, M, L, P):
+        raise RuntimeError("sampling_loc / attn_weight shapes do not match value / spatial_shapes")
+    if tuple(spatial_shapes.shape) != (L, 2) or tuple(level_start_index.shape) != (L,):
+        raise RuntimeError("spatial_shapes must be (L,2) and level_start_index (L,)")
+    if spatial_shapes.dtype != torch.int64 or level_start_index.dtype != torch.int64:
+        raise RuntimeError("spatial_shapes and level_start_index must be int64 tensors")
+    step = min(N, int(im2col_step))
+    if N > 0 and (step <= 0 or N % step != 0):
+        raise RuntimeError(f"batch({N}) must divide im2col_step({step})")
+    return N, S, M, D, L, Lq, P
+
+
+def _suffix(value, sampling_loc, attn_weight):
+    suf = _SUFFIX.get(value.dtype)
+    if suf is None:
+        raise RuntimeError(f"ms_deform_attn: unsupported value dtype {value.dtype}")
+    want = torch.float32 if suf == "bf16" else value.dtype
+    if sampling_loc.dtype != want or attn_weight.dtype != want:
+        raise RuntimeError(f"ms_deform_attn: sampling_loc/attn_weight must be {want} for value dtype {value.dtype}")
+    return suf
+
+
+def _stream(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _raise(rc: int, what: str):
+    raise RuntimeError(f"{what} failed (code {rc}): {_lib.last_error()}")
+
+
+def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
+    """-> output (N, Lq, M*D); cf. ms_deform_attn_cuda_forward (ms_deform_attn_cuda.cu:20-80)."""
+    _check_inputs((("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
+                   ("sampling_loc", sampling_loc), ("attn_weight", attn_weight)))
+    N, S, M, D, L, Lq, P = _dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step)
+    suf = _suffix(value, sampling_loc, attn_weight)
+    with torch.cuda.device(value.device):
+        output = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
+        rc = getattr(_lib.lib, f"msda_forward_{suf}")(
+            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
+            attn_weight.data_ptr(), N, S, M, D, L, Lq, P, output.data_ptr(), None, _stream(value.device))
+    if rc != 0:
+        _raise(rc, "ms_deform_attn_forward")
+    return output
+
+
+def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output,
+                            im2col_step):
+    """-> [grad_value, grad_sampling_loc, grad_attn_weight]; cf. ms_deform_attn_cuda_backward (.cu:83-153)."""
+    _check_inputs((("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
+                   ("sampling_loc", sampling_loc), ("attn_weight", attn_weight), ("grad_output", grad_output)))
+    N, S, M, D, L, Lq, P = _dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step)
+    suf = _suffix(value, sampling_loc, attn_weight)
+    if grad_output.dtype != value.dtype or grad_output.numel() != N * Lq * M * D:
+        raise RuntimeError("grad_output must match the forward output (N, Lq, M*D) and value's dtype")
+    with torch.cuda.device(value.device):
+        # bf16: accumulate grad_value in fp32, round once at the end
+        acc_dtype = torch.float32 if suf == "bf16" else value.dtype
+        grad_value = torch.zeros(value.shape, dtype=acc_dtype, device=value.device)
+        grad_loc = torch.empty_like(sampling_loc)
+        grad_attn = torch.empty_like(attn_weight)
+        rc = getattr(_lib.lib, f"msda_backward_{suf}")(
+            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
+            attn_weight.data_ptr(), grad_output.data_ptr(), N, S, M, D, L, Lq, P, grad_value.data_ptr(),
+            grad_loc.data_ptr(), grad_attn.data_ptr(), 0, None, _stream(value.device))
+    if rc != 0:
+        _raise(rc, "ms_deform_attn_backward")
+    if grad_value.dtype != value.dtype:
+        grad_value = grad_value.to(value.dtype)
+    return [grad_value, grad_loc, grad_attn]
+
+
+def sample_indices(spatial_shapes, sampling_loc):
+    """Parity hook: (h_low, w_low, gate) of every sampling point, as the kernels compute them."""
+    if not (sampling_loc.is_cuda and sampling_loc.dtype == torch.float32 and sampling_loc.is_contiguous()):
+        raise RuntimeError("sample_indices expects a contiguous float32 CUDA sampling_loc")
+    N, Lq, M, L, P, _ = sampling_loc.shape
+    with torch.cuda.device(sampling_loc.device):
+        h = torch.empty((N, Lq, M, L, P), dtype=torch.int32, device=sampling_loc.device)
+        w = torch.empty_like(h)
+        g = torch.empty((N, Lq, M, L, P), dtype=torch.uint8, device=sampling_loc.device)
+        rc = _lib.lib.msda_sample_indices_f32(spatial_shapes.data_ptr(), sampling_loc.data_ptr(), N, M, L, Lq, P,
+                                              h.data_ptr(), w.data_ptr(), g.data_ptr(),
+                                              _stream(sampling_loc.device))
+    if rc != 0:
+        _raise(rc, "msda_sample_indices_f32")
+    return h, w, g

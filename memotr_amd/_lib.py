@@ -1,0 +1,78 @@
+"""ctypes binding of libmsda_hip.so (C ABI in include/msda_hip.h).
+
+No CPU fallback: if the library is missing or does not load, importing this module
+raises, and with it every operator of the package.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmsda_hip.so")
+
+ABI_VERSION = 1
+
+c_int = ctypes.c_int
+c_void_p = ctypes.c_void_p
+
+_FWD_ARGS = [c_void_p] * 5 + [c_int] * 7 + [c_void_p, c_void_p, c_void_p]
+_BWD_ARGS = [c_void_p] * 6 + [c_int] * 7 + [c_void_p] * 3 + [c_int, c_void_p, c_void_p]
+
+SYMBOLS = {
+    "msda_abi_version": ([], c_int),
+    "msda_last_error": ([], ctypes.c_char_p),
+    "msda_last_kernel": ([], ctypes.c_char_p),
+    "msda_forward_f32": (_FWD_ARGS, c_int),
+    "msda_forward_f64": (_FWD_ARGS, c_int),
+    "msda_forward_bf16": (_FWD_ARGS, c_int),
+    "msda_backward_f32": (_BWD_ARGS, c_int),
+    "msda_backward_f64": (_BWD_ARGS, c_int),
+    "msda_backward_bf16": (_BWD_ARGS, c_int),
+    "msda_sample_indices_f32": ([c_void_p, c_void_p] + [c_int] * 5 + [c_void_p] * 4, c_int),
+    "msda_set_option": ([ctypes.c_char_p, c_int], c_int),
+    "msda_get_option": ([ctypes.c_char_p, ctypes.POINTER(c_int)], c_int),
+}
+
+
+def _load() -> ctypes.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m memotr_amd.build` "
+            "(hipcc --offload-arch=gfx950). memotr_amd has no CPU fallback.")
+    # torch ships its own libamdhip64 (same SONAME); importing it first makes the HIP
+    # library bind to the runtime torch's streams/allocations live in.
+    import torch  # noqa: F401
+
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (argtypes, restype) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.argtypes = argtypes
+        fn.restype = restype
+    got = lib.msda_abi_version()
+    if got != ABI_VERSION:
+        raise ImportError(f"libmsda_hip.so ABI {got} != binding ABI {ABI_VERSION}; rebuild the library")
+    return lib
+
+
+lib = _load()
+
+
+def last_error() -> str:
+    return lib.msda_last_error().decode()
+
+
+def last_kernel() -> str:
+    return lib.msda_last_kernel().decode()
+
+
+def set_option(key: str, value: int) -> None:
+    if lib.msda_set_option(key.encode(), int(value)) != 0:
+        raise ValueError(f"msda_set_option({key!r}, {value}) rejected: {last_error()}")
+
+
+def get_option(key: str) -> int:
+    out = c_int(0)
+    if lib.msda_get_option(key.encode(), ctypes.byref(out)) != 0:
+        raise ValueError(f"unknown option {key!r}")
+    return out.value

@@ -1,0 +1,46 @@
+"""Build memotr_amd/lib/libmsda_hip.so with hipcc for gfx950 (cross-compiles without a GPU)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(_HERE, "csrc", "msda_hip.hip")
+HDR = os.path.join(os.path.dirname(_HERE), "include", "msda_hip.h")
+LIB_DIR = os.path.join(_HERE, "lib")
+LIB = os.path.join(LIB_DIR, "libmsda_hip.so")
+
+HIPCC_FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    "-munsafe-fp-atomics",      # float/double atomicAdd -> global_atomic_add_f32/_f64
+]
+
+
+def hipcc_path() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (ROCm toolchain required to build libmsda_hip.so)")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(p) > t for p in (SRC, HDR))
+
+
+def build_lib(force: bool = False, verbose: bool = False) -> str:
+    if not force and not needs_build():
+        return LIB
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [hipcc_path(), *HIPCC_FLAGS, SRC, "-o", LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_lib(force=True, verbose=True))

@@ -1,0 +1,34 @@
+"""Autograd binding of the gfx950 operator.
+
+Mirror of ``MSDeformAttnFunction`` in the reference
+(``models/ops/functions/ms_deform_attn_func.py:24-41``): six positional arguments,
+gradients for ``value``, ``sampling_locations`` and ``attention_weights`` only, no double
+backward.  There is deliberately no ``ms_deform_attn_core_pytorch`` here: the pure-PyTorch
+statement of the operator lives in ``oracle/`` as test infrastructure.
+"""
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from .. import MultiScaleDeformableAttention as MSDA
+
+
+class MSDeformAttnFunction(Function):
+    @staticmethod
+    def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights,
+                im2col_step):
+        ctx.im2col_step = im2col_step
+        output = MSDA.ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index,
+                                             sampling_locations, attention_weights, ctx.im2col_step)
+        ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                              attention_weights)
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights = ctx.saved_tensors
+        grad_value, grad_sampling_loc, grad_attn_weight = MSDA.ms_deform_attn_backward(
+            value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights,
+            grad_output.contiguous(), ctx.im2col_step)
+        return grad_value, None, None, grad_sampling_loc, grad_attn_weight, None

@@ -1,0 +1,74 @@
+#!/usr/bin/env python
+"""Condense rocprofv3 output dirs into profiles/<tag>_*.{md,json} (small, committed)."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def find(root, suffix):
+    hits = glob.glob(os.path.join(root, "**", f"*{suffix}"), recursive=True)
+    return hits[0] if hits else None
+
+
+def main():
+    root, tag = sys.argv[1], sys.argv[2]
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out_dir = os.path.join(os.environ.get("PROF_OUT", os.path.join(repo, "gpurun_out", "profiles")))
+    os.makedirs(out_dir, exist_ok=True)
+    lines = [f"# rocprofv3 summary ({tag})", "", "command: `python bench.py --steps 3 --warmup 1 --no-cpu-baseline`", ""]
+    stats = find(os.path.join(root, "stats"), "kernel_stats.csv")
+    summary = {}
+    if stats:
+        lines += ["## kernel stats (--kernel-trace --stats)", "", "| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
+        with open(stats) as f:
+            for r in csv.DictReader(f):
+                name = r.get("Name", "")[:90]
+                calls = int(r.get("Calls", 0))
+                tot = float(r.get("TotalDurationNs", 0)) / 1e6
+                avg = float(r.get("AverageNs", 0)) / 1e3
+                pct = r.get("Percentage", "")
+                lines.append(f"| `{name}` | {calls} | {tot:.3f} | {avg:.2f} | {pct} |")
+                summary[name] = dict(calls=calls, total_ms=tot, avg_us=avg)
+    traffic = {}
+    for key, sub, ctr in (("fetch", "pmc_fetch", "FETCH_SIZE"), ("write", "pmc_write", "WRITE_SIZE"),
+                          ("l2hit", "pmc_l2", "TCC_HIT_sum"), ("l2miss", "pmc_l2", "TCC_MISS_sum")):
+        p = find(os.path.join(root, sub), "counter_collection.csv")
+        if not p:
+            continue
+        agg = defaultdict(lambda: [0.0, 0])
+        with open(p) as f:
+            for r in csv.DictReader(f):
+                if r.get("Counter_Name") != ctr:
+                    continue
+                k = r.get("Kernel_Name", "")[:90]
+                agg[k][0] += float(r.get("Counter_Value", 0))
+                agg[k][1] += 1
+        traffic[key] = {k: dict(mean=v[0] / max(v[1], 1), n=v[1]) for k, v in agg.items()}
+    if traffic:
+        lines += ["", "## PMC (separate passes; mean per dispatch)", "",
+                  "FETCH_SIZE / WRITE_SIZE are in KiB as reported by rocprofv3; on gfx950 FETCH_SIZE under-counts "
+                  "wide coalesced reads by 2x (MI355X_MICROARCH.md, HBM) -- corrected value shown as fetch_x2.", "",
+                  "| kernel | FETCH_SIZE KiB | fetch_x2 MB | WRITE_SIZE KiB | L2 hit % |", "|---|---|---|---|---|"]
+        kernels = set()
+        for d in traffic.values():
+            kernels |= set(d)
+        for k in sorted(kernels):
+            fe = traffic.get("fetch", {}).get(k, {}).get("mean")
+            wr = traffic.get("write", {}).get(k, {}).get("mean")
+            hit = traffic.get("l2hit", {}).get(k, {}).get("mean")
+            miss = traffic.get("l2miss", {}).get(k, {}).get("mean")
+            hr = f"{100*hit/(hit+miss):.1f}" if hit is not None and miss is not None and hit + miss > 0 else ""
+            lines.append(f"| `{k}` | {fe if fe is None else round(fe,1)} | "
+                         f"{'' if fe is None else round(2*fe*1024/1e6,2)} | {wr if wr is None else round(wr,1)} | {hr} |")
+    with open(os.path.join(out_dir, f"{tag}_rocprof_summary.md"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    with open(os.path.join(out_dir, f"{tag}_rocprof_summary.json"), "w") as f:
+        json.dump(dict(stats=summary, pmc=traffic), f, indent=1)
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()
