@@ -43,6 +43,7 @@ def parse_args():
     ap.add_argument("--n-track", type=int, default=20, help="track queries carried into the frame (Lq = 300 + n)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores")
     return ap.parse_args()
 
 
@@ -81,12 +82,15 @@ class MsdaCall:
         self.gv = torch.zeros_like(v)
         self.gl = torch.empty_like(loc)
         self.ga = torch.empty_like(x["attn"])
+        import numpy as np
+        self.hshapes = np.ascontiguousarray(np.asarray(x["shapes_list"], dtype=np.int64))
+        self.hptr = self.hshapes.ctypes.data
 
     def fwd(self):
         x = self.x
         rc = self.lib.msda_forward_f32(x["value"].data_ptr(), x["shapes"].data_ptr(), x["level_start"].data_ptr(),
                                        x["loc"].data_ptr(), x["attn"].data_ptr(), self.N, self.S, self.M, self.D,
-                                       self.L, self.Lq, self.P, self.out.data_ptr(), None,
+                                       self.L, self.Lq, self.P, self.out.data_ptr(), self.hptr,
                                        torch.cuda.current_stream().cuda_stream)
         if rc:
             raise RuntimeError(self._lib.last_error())
@@ -96,7 +100,7 @@ class MsdaCall:
         rc = self.lib.msda_backward_f32(x["value"].data_ptr(), x["shapes"].data_ptr(), x["level_start"].data_ptr(),
                                         x["loc"].data_ptr(), x["attn"].data_ptr(), x["grad_out"].data_ptr(), self.N,
                                         self.S, self.M, self.D, self.L, self.Lq, self.P, self.gv.data_ptr(),
-                                        self.gl.data_ptr(), self.ga.data_ptr(), 1, None,
+                                        self.gl.data_ptr(), self.ga.data_ptr(), 1, self.hptr,
                                         torch.cuda.current_stream().cuda_stream)
         if rc:
             raise RuntimeError(self._lib.last_error())
@@ -136,6 +140,9 @@ def cpu_baseline_msda(args, enc_shape_kwargs, dec_shape_kwargs):
     from oracle import msda_oracle as oracle
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
+    if args.cpu_threads > 0:
+        cores = args.cpu_threads
+        torch.set_num_threads(cores)
 
     def one(kw):
         x = make_inputs(device="cpu", **kw)

@@ -59,6 +59,43 @@ def _suffix(value, sampling_loc, attn_weight):
     return suf
 
 
+_HOST_SHAPES = {}
+
+
+def host_shapes(spatial_shapes):
+    """HOST copy of ``spatial_shapes`` as a pinned-in-python numpy int64 array (or None).
+
+    The level-aware kernels plan their launch from it.  Callers that know the pyramid as python ints
+    attach it up front (``tag_host_shapes``) so no device->host read ever happens on the hot path;
+    otherwise the first call with a given shapes tensor pays one synchronising ``.cpu()`` and the
+    result is cached on (storage address, version).
+    """
+    arr = getattr(spatial_shapes, "_msda_host", None)
+    if arr is not None:
+        return arr
+    key = (spatial_shapes.data_ptr(), spatial_shapes._version, spatial_shapes.device.index)
+    arr = _HOST_SHAPES.get(key)
+    if arr is None:
+        import numpy as np
+        if len(_HOST_SHAPES) > 256:
+            _HOST_SHAPES.clear()
+        arr = np.ascontiguousarray(spatial_shapes.detach().cpu().numpy(), dtype=np.int64)
+        _HOST_SHAPES[key] = arr
+    return arr
+
+
+def tag_host_shapes(spatial_shapes, shapes_list):
+    """Attach the python-side pyramid [(H, W), ...] to a device ``spatial_shapes`` tensor."""
+    import numpy as np
+    spatial_shapes._msda_host = np.ascontiguousarray(np.asarray(shapes_list, dtype=np.int64).reshape(-1, 2))
+    return spatial_shapes
+
+
+def _host_ptr(spatial_shapes):
+    arr = host_shapes(spatial_shapes)
+    return arr, (arr.ctypes.data if arr is not None else None)
+
+
 def _stream(device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
@@ -75,9 +112,13 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     suf = _suffix(value, sampling_loc, attn_weight)
     with torch.cuda.device(value.device):
         output = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
+        if output.numel() == 0:  # a frame without queries: nothing to launch (empty tensors have no storage)
+            return output
+        keep, hptr = _host_ptr(spatial_shapes)
         rc = getattr(_lib.lib, f"msda_forward_{suf}")(
             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
-            attn_weight.data_ptr(), N, S, M, D, L, Lq, P, output.data_ptr(), None, _stream(value.device))
+            attn_weight.data_ptr(), N, S, M, D, L, Lq, P, output.data_ptr(), hptr, _stream(value.device))
+        del keep
     if rc != 0:
         _raise(rc, "ms_deform_attn_forward")
     return output
@@ -98,10 +139,14 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
         grad_value = torch.zeros(value.shape, dtype=acc_dtype, device=value.device)
         grad_loc = torch.empty_like(sampling_loc)
         grad_attn = torch.empty_like(attn_weight)
+        if grad_output.numel() == 0:
+            return [grad_value.to(value.dtype), grad_loc, grad_attn]
+        keep, hptr = _host_ptr(spatial_shapes)
         rc = getattr(_lib.lib, f"msda_backward_{suf}")(
             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
             attn_weight.data_ptr(), grad_output.data_ptr(), N, S, M, D, L, Lq, P, grad_value.data_ptr(),
-            grad_loc.data_ptr(), grad_attn.data_ptr(), 0, None, _stream(value.device))
+            grad_loc.data_ptr(), grad_attn.data_ptr(), 0, hptr, _stream(value.device))
+        del keep
     if rc != 0:
         _raise(rc, "ms_deform_attn_backward")
     if grad_value.dtype != value.dtype:

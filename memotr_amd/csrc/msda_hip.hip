@@ -531,6 +531,421 @@ __global__ __launch_bounds__(256) void msda_bwd_d32_gather(
 }
 
 // ----------------------------------------------------------------------------------------
+// Region-tiled kernels for self-attention over the pyramid (one query per pixel, Lq == S).
+//
+// A workgroup owns one (batch, region, head).  A region is the set of queries whose pixels fall
+// in one cell of the coarsest level's grid: side_l = 2^(L-1-l) pixels per side at level l
+// (8x8 + 4x4 + 2x2 + 1 = 85 queries for L = 4).  All of them sample the same neighbourhood of
+// every level, so the workgroup keeps one window of this head's rows per level in LDS
+// (128 B per pixel), centred on the mean sampling position it measures first:
+//   forward : windows hold `value`; corner reads are ds_read_b128 instead of L1/L2 requests
+//   backward: windows hold the grad_value partial sums; corner scatters are ds_add_f32 and the
+//             windows are flushed once with coalesced global atomics
+// Corners that fall outside a window take the global path (buffer load / buffer atomic), so
+// results do not depend on where the samples are -- only the speed does.
+// ----------------------------------------------------------------------------------------
+constexpr int kTileMaxL = 4;
+constexpr int kTileThreads = 256;
+constexpr unsigned kGlobalTag = 0x80000000u;
+
+struct TilePlan {
+    int N, S, M, L, P, Lq;
+    int RY, RX;
+    int rows;                      // queries per region
+    int H[kTileMaxL], W[kTileMaxL];
+    int qstart[kTileMaxL];         // first query of level l (cumulative H*W)
+    int shift[kTileMaxL];          // log2(side_l)
+    int row0[kTileMaxL + 1];       // first region-row of level l
+    int win[kTileMaxL];            // window side in pixels
+    int win_magic[kTileMaxL];      // (x * magic) >> 16 == x / win for x < win*win
+    int win_base[kTileMaxL + 1];   // first window pixel of level l (cumulative, pixels)
+    unsigned value_bytes;
+    int n_blocks;                  // real block count (grid is padded to a multiple of 8)
+};
+
+struct TileTables {  // LDS copy of the per-level tables (divergent lookups)
+    int H[kTileMaxL], W[kTileMaxL], qstart[kTileMaxL], shift[kTileMaxL], row0[kTileMaxL + 1];
+    int win[kTileMaxL], magic[kTileMaxL], base[kTileMaxL + 1], lstart[kTileMaxL];
+    int oy[kTileMaxL], ox[kTileMaxL];
+    float sum[kTileMaxL][3];
+};
+
+struct TileRow {
+    bool ok;
+    long pm;
+};
+
+__device__ __forceinline__ TileRow tile_row(const TileTables &tb, int L, int rows, int r, int b, int ry, int rx,
+                                            int m, int M, int Lq) {
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < kTileMaxL; ++i)
+        if (i < L && r >= tb.row0[i]) l = i;
+    const int local = r - tb.row0[l], sh = tb.shift[l];
+    const int py = (ry << sh) + (local >> sh), px = (rx << sh) + (local & ((1 << sh) - 1));
+    TileRow o;
+    o.ok = (r < rows) && (py < tb.H[l]) && (px < tb.W[l]);
+    const int q = o.ok ? tb.qstart[l] + py * tb.W[l] + px : 0;
+    o.pm = ((long)b * Lq + q) * M + m;
+    return o;
+}
+
+__device__ __forceinline__ void tile_block_coords(const TilePlan &pl, int &b, int &ry, int &rx, int &m, bool &live) {
+    // XCD-aware: block i runs on XCD i % 8; hand each XCD a contiguous run of (region, head) pairs
+    const int nb_pad = gridDim.x, chunk = nb_pad >> 3;
+    const int sw = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    live = sw < pl.n_blocks;
+    const int id = live ? sw : 0;
+    m = id % pl.M;
+    const int reg = (id / pl.M) % (pl.RY * pl.RX);
+    b = id / (pl.M * pl.RY * pl.RX);
+    ry = reg / pl.RX;
+    rx = reg - ry * pl.RX;
+}
+
+__device__ __forceinline__ void tile_load_tables(TileTables &tb, const TilePlan &pl,
+                                                 const int64_t *__restrict__ lstart) {
+    const int t = threadIdx.x;
+    if (t < kTileMaxL) {
+        tb.H[t] = pl.H[t];
+        tb.W[t] = pl.W[t];
+        tb.qstart[t] = pl.qstart[t];
+        tb.shift[t] = pl.shift[t];
+        tb.win[t] = pl.win[t];
+        tb.magic[t] = pl.win_magic[t];
+        tb.lstart[t] = t < pl.L ? (int)lstart[t] : 0;
+        tb.sum[t][0] = tb.sum[t][1] = tb.sum[t][2] = 0.f;
+    }
+    if (t <= kTileMaxL) {
+        tb.row0[t] = pl.row0[t];
+        tb.base[t] = pl.win_base[t];
+    }
+}
+
+// Measure the mean sampling position of every level over the region's gated points and place
+// the windows around it.  Ends with a __syncthreads(); tb.oy/ox are valid afterwards.
+__device__ __forceinline__ void tile_place_windows(TileTables &tb, const TilePlan &pl, const float *__restrict__ loc,
+                                                   int b, int ry, int rx, int m) {
+    const int LP = pl.L * pl.P;
+    const int lane = threadIdx.x & 63;
+    for (int l = 0; l < pl.L; ++l) {
+        float sx = 0.f, sy = 0.f, cnt = 0.f;
+        const int n = pl.rows * pl.P;
+        const int H = tb.H[l], W = tb.W[l];
+        for (int i = threadIdx.x; i < n; i += kTileThreads) {
+            const int r = i / pl.P, p = i - r * pl.P;
+            const TileRow row = tile_row(tb, pl.L, pl.rows, r, b, ry, rx, m, pl.M, pl.Lq);
+            if (row.ok) {
+                const f32x2 xy = *reinterpret_cast<const f32x2 *>(loc + (row.pm * LP + l * pl.P + p) * 2);
+                const Sample<float> s = sample_setup<float>(xy.x, xy.y, H, W);
+                if (s.gate) {
+                    sx += (float)s.w_low + s.lw;
+                    sy += (float)s.h_low + s.lh;
+                    cnt += 1.f;
+                }
+            }
+        }
+        sx = wave_sum(sx);
+        sy = wave_sum(sy);
+        cnt = wave_sum(cnt);
+        if (lane == 0) {
+            atomicAdd(&tb.sum[l][0], sx);
+            atomicAdd(&tb.sum[l][1], sy);
+            atomicAdd(&tb.sum[l][2], cnt);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < pl.L) {
+        const int l = threadIdx.x, win = tb.win[l], sh = tb.shift[l];
+        const float cnt = tb.sum[l][2];
+        // no gated point at this level: centre on the region itself
+        const float cx = cnt > 0.f ? tb.sum[l][0] / cnt : (float)((rx << sh) + (1 << sh) / 2);
+        const float cy = cnt > 0.f ? tb.sum[l][1] / cnt : (float)((ry << sh) + (1 << sh) / 2);
+        int ox = (int)floorf(cx - 0.5f * (float)(win - 1) + 0.5f);
+        int oy = (int)floorf(cy - 0.5f * (float)(win - 1) + 0.5f);
+        const int max_x = tb.W[l] - win, max_y = tb.H[l] - win;
+        ox = ox > max_x ? max_x : ox;
+        oy = oy > max_y ? max_y : oy;
+        tb.ox[l] = ox < 0 ? 0 : ox;
+        tb.oy[l] = oy < 0 ? 0 : oy;
+    }
+    __syncthreads();
+}
+
+// Byte offset of pixel (gy, gx) of level l, head m, batch b, relative to the tensor base.
+__device__ __forceinline__ unsigned tile_pixel_off(const TileTables &tb, const TilePlan &pl, int b, int l, int gy,
+                                                   int gx, int m) {
+    return (((unsigned)b * (unsigned)pl.S + (unsigned)(tb.lstart[l] + gy * tb.W[l] + gx)) * (unsigned)pl.M +
+            (unsigned)m) * 128u;
+}
+
+// LDS byte offset of a window cell, or a tagged global offset when the corner is outside the window;
+// `dead` when the corner is outside the level (or the point is gated off).
+__device__ __forceinline__ unsigned tile_corner_target(const TileTables &tb, const TilePlan &pl, int b, int l, int cy,
+                                                       int cx, int m, bool valid, unsigned dead) {
+    if (!valid) return dead;
+    const int wy = cy - tb.oy[l], wx = cx - tb.ox[l], win = tb.win[l];
+    if ((unsigned)wy < (unsigned)win && (unsigned)wx < (unsigned)win)
+        return (unsigned)(tb.base[l] + wy * win + wx) * 128u;
+    return kGlobalTag | tile_pixel_off(tb, pl, b, l, cy, cx, m);
+}
+
+// ---- forward -------------------------------------------------------------------------------
+__global__ __launch_bounds__(kTileThreads) void msda_fwd_d32_tile(
+    const float *__restrict__ value, const int64_t *__restrict__ lstart, const float *__restrict__ loc,
+    const float *__restrict__ attn, float *__restrict__ out, const TilePlan pl) {
+    constexpr int D = 32;
+    __shared__ TileTables tb;
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    int b, ry, rx, m;
+    bool live;
+    tile_block_coords(pl, b, ry, rx, m, live);
+    if (!live) return;
+    tile_load_tables(tb, pl, lstart);
+    __syncthreads();
+    tile_place_windows(tb, pl, loc, b, ry, rx, m);
+
+    const int LP = pl.L * pl.P;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane >> 3, sub = lane & 7;
+    const __amdgpu_buffer_rsrc_t vr = make_rsrc(value, pl.value_bytes);
+    f32x4 *win_f4 = reinterpret_cast<f32x4 *>(s_dyn);
+    const int win_px = tb.base[pl.L];
+    const unsigned zero_row = (unsigned)win_px * 128u;   // one all-zero pixel row after the windows
+    const int rec_stride = 2 * LP + 1;
+    u32x4 *rec = reinterpret_cast<u32x4 *>(s_dyn + (size_t)(win_px + 1) * 128) + (size_t)(wave * 8 + grp) * rec_stride;
+
+    // ---- fill the windows (coalesced 128-byte rows; out-of-level cells read as zero) ----
+    if (threadIdx.x < 8) win_f4[win_px * 8 + threadIdx.x] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int l = 0; l < pl.L; ++l) {
+        const int win = tb.win[l], magic = tb.magic[l], base = tb.base[l];
+        const int oy = tb.oy[l], ox = tb.ox[l], H = tb.H[l], W = tb.W[l];
+        const int n = win * win * 8;
+#pragma unroll 4
+        for (int i = threadIdx.x; i < n; i += kTileThreads) {
+            const int pix = i >> 3, s8 = i & 7;
+            const int wy = (pix * magic) >> 16, wx = pix - wy * win;
+            const int gy = oy + wy, gx = ox + wx;
+            const unsigned off = (gy < H && gx < W) ? tile_pixel_off(tb, pl, b, l, gy, gx, m) + (unsigned)s8 * 16u
+                                                    : kOobOffset;
+            win_f4[(base + pix) * 8 + s8] = buf_load_f4(vr, off);
+        }
+    }
+    __syncthreads();
+
+    // ---- passes of 32 rows (8 per wavefront) ----
+    const unsigned lane_off = (unsigned)sub * 16u;
+    const unsigned pix_stride = (unsigned)pl.M * 128u;
+    for (int r0 = 0; r0 < pl.rows; r0 += 32) {
+        const TileRow row = tile_row(tb, pl.L, pl.rows, r0 + wave * 8 + grp, b, ry, rx, m, pl.M, pl.Lq);
+        for (int t = sub; t < LP; t += 8) {
+            const int l = t / pl.P;
+            const f32x2 xy = *reinterpret_cast<const f32x2 *>(loc + (row.pm * LP + t) * 2);
+            const float a = attn[row.pm * LP + t];
+            const int H = tb.H[l], W = tb.W[l];
+            const Sample<float> s = sample_setup<float>(xy.x, xy.y, H, W);
+            const float hh = 1.f - s.lh, hw = 1.f - s.lw;
+            const int h0 = s.h_low, w0 = s.w_low, h1 = h0 + 1, w1 = w0 + 1;
+            const bool livep = s.gate && row.ok;
+            const bool okh0 = livep && h0 >= 0, okh1 = livep && h1 <= H - 1;
+            const bool okw0 = w0 >= 0, okw1 = w1 <= W - 1;
+            u32x4 off;
+            off.x = tile_corner_target(tb, pl, b, l, h0, w0, m, okh0 && okw0, zero_row);
+            off.y = tile_corner_target(tb, pl, b, l, h0, w1, m, okh0 && okw1, zero_row);
+            off.z = tile_corner_target(tb, pl, b, l, h1, w0, m, okh1 && okw0, zero_row);
+            off.w = tile_corner_target(tb, pl, b, l, h1, w1, m, okh1 && okw1, zero_row);
+            f32x4 w;
+            w.x = (hh * hw) * a;
+            w.y = (hh * s.lw) * a;
+            w.z = (s.lh * hw) * a;
+            w.w = (s.lh * s.lw) * a;
+            rec[2 * t] = off;
+            rec[2 * t + 1] = __builtin_bit_cast(u32x4, w);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+        for (int t = 0; t < LP; ++t) {
+            const u32x4 o = rec[2 * t];
+            const f32x4 w = __builtin_bit_cast(f32x4, rec[2 * t + 1]);
+            f32x4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned ok = o[k];
+                const bool g = (ok & kGlobalTag) != 0u;
+                v[k] = *reinterpret_cast<const f32x4 *>(s_dyn + ((g ? zero_row : ok) + lane_off));
+                if (g) v[k] = buf_load_f4(vr, (ok & ~kGlobalTag) + lane_off);
+            }
+            acc += w.x * v[0];
+            acc += w.y * v[1];
+            acc += w.z * v[2];
+            acc += w.w * v[3];
+        }
+        if (row.ok) *reinterpret_cast<f32x4 *>(out + row.pm * D + sub * 4) = acc;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    (void)pix_stride;
+}
+
+// ---- backward ------------------------------------------------------------------------------
+// Records: [0] global value offsets of the 4 corners (kOobOffset when dead), [1] scatter targets
+// (LDS window byte offset, or kGlobalTag|global offset, dead -> tagged out-of-range), [2] lh, lw, attn.
+__global__ __launch_bounds__(kTileThreads) void msda_bwd_d32_tile(
+    const float *__restrict__ value, const int64_t *__restrict__ lstart, const float *__restrict__ loc,
+    const float *__restrict__ attn, const float *__restrict__ grad_out, float *__restrict__ grad_value,
+    float *__restrict__ grad_loc, float *__restrict__ grad_attn, const TilePlan pl) {
+    constexpr int D = 32;
+    __shared__ TileTables tb;
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    int b, ry, rx, m;
+    bool live;
+    tile_block_coords(pl, b, ry, rx, m, live);
+    if (!live) return;
+    tile_load_tables(tb, pl, lstart);
+    __syncthreads();
+
+    const int LP = pl.L * pl.P;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane >> 3, sub = lane & 7;
+    const __amdgpu_buffer_rsrc_t vr = make_rsrc(value, pl.value_bytes);
+    const __amdgpu_buffer_rsrc_t gr = make_rsrc(grad_value, pl.value_bytes);
+    f32x4 *win_f4 = reinterpret_cast<f32x4 *>(s_dyn);
+    float *win_f = reinterpret_cast<float *>(s_dyn);
+    const int win_px = tb.base[pl.L];
+    const int rec_stride = 3 * LP + 1;
+    u32x4 *rec = reinterpret_cast<u32x4 *>(s_dyn + (size_t)win_px * 128) + (size_t)(wave * 8 + grp) * rec_stride;
+    float *res = reinterpret_cast<float *>(s_dyn + (size_t)win_px * 128 + (size_t)32 * rec_stride * 16) +
+                 (size_t)(wave * 8 + grp) * (3 * LP + 1);
+
+    // zero the accumulation windows while the placement pass runs
+    for (int i = threadIdx.x; i < win_px * 8; i += kTileThreads) win_f4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    tile_place_windows(tb, pl, loc, b, ry, rx, m);  // ends with __syncthreads()
+
+    const unsigned lane_off = (unsigned)sub * 16u;
+    const unsigned dead_target = kGlobalTag | 0x7fffff00u;  // tagged global, beyond value_bytes -> dropped
+    for (int r0 = 0; r0 < pl.rows; r0 += 32) {
+        const TileRow row = tile_row(tb, pl.L, pl.rows, r0 + wave * 8 + grp, b, ry, rx, m, pl.M, pl.Lq);
+        for (int t = sub; t < LP; t += 8) {
+            const int l = t / pl.P;
+            const f32x2 xy = *reinterpret_cast<const f32x2 *>(loc + (row.pm * LP + t) * 2);
+            const float a = row.ok ? attn[row.pm * LP + t] : 0.f;
+            const int H = tb.H[l], W = tb.W[l];
+            const Sample<float> s = sample_setup<float>(xy.x, xy.y, H, W);
+            const int h0 = s.h_low, w0 = s.w_low, h1 = h0 + 1, w1 = w0 + 1;
+            const bool livep = s.gate && row.ok;
+            const bool okh0 = livep && h0 >= 0, okh1 = livep && h1 <= H - 1;
+            const bool okw0 = w0 >= 0, okw1 = w1 <= W - 1;
+            const unsigned ps = (unsigned)pl.M * 128u;
+            const unsigned o00 = tile_pixel_off(tb, pl, b, l, h0, w0, m);
+            u32x4 go, to;
+            go.x = (okh0 && okw0) ? o00 : kOobOffset;
+            go.y = (okh0 && okw1) ? o00 + ps : kOobOffset;
+            go.z = (okh1 && okw0) ? o00 + (unsigned)W * ps : kOobOffset;
+            go.w = (okh1 && okw1) ? o00 + (unsigned)W * ps + ps : kOobOffset;
+            to.x = tile_corner_target(tb, pl, b, l, h0, w0, m, okh0 && okw0, dead_target);
+            to.y = tile_corner_target(tb, pl, b, l, h0, w1, m, okh0 && okw1, dead_target);
+            to.z = tile_corner_target(tb, pl, b, l, h1, w0, m, okh1 && okw0, dead_target);
+            to.w = tile_corner_target(tb, pl, b, l, h1, w1, m, okh1 && okw1, dead_target);
+            f32x4 w;
+            w.x = s.lh;
+            w.y = s.lw;
+            w.z = a;
+            w.w = 0.f;
+            rec[3 * t] = go;
+            rec[3 * t + 1] = to;
+            rec[3 * t + 2] = __builtin_bit_cast(u32x4, w);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const f32x4 g = row.ok ? *reinterpret_cast<const f32x4 *>(grad_out + row.pm * D + sub * 4)
+                               : f32x4{0.f, 0.f, 0.f, 0.f};
+        // LDS atomics: rotate the channel order by the row slot so that the 64 lanes of one
+        // ds_add_f32 cover all 32 banks twice (rows are 128-byte aligned: without the rotation
+        // eight rows would pile onto the same eight banks).
+        const int rot = grp & 3;
+        const f32x4 g_rot = rot == 0 ? g : rot == 1 ? f32x4{g.y, g.z, g.w, g.x}
+                                  : rot == 2 ? f32x4{g.z, g.w, g.x, g.y} : f32x4{g.w, g.x, g.y, g.z};
+        const unsigned c0 = (unsigned)((0 + rot) & 3) * 4u, c1 = (unsigned)((1 + rot) & 3) * 4u;
+        const unsigned c2 = (unsigned)((2 + rot) & 3) * 4u, c3 = (unsigned)((3 + rot) & 3) * 4u;
+        for (int t = 0; t < LP; ++t) {
+            const u32x4 go = rec[3 * t];
+            const u32x4 to = rec[3 * t + 1];
+            const f32x4 rw = __builtin_bit_cast(f32x4, rec[3 * t + 2]);
+            const float lh = rw.x, lw = rw.y, a = rw.z;
+            const float hh = 1.f - lh, hw = 1.f - lw;
+            const f32x4 v1 = buf_load_f4(vr, go.x + lane_off);
+            const f32x4 v2 = buf_load_f4(vr, go.y + lane_off);
+            const f32x4 v3 = buf_load_f4(vr, go.z + lane_off);
+            const f32x4 v4 = buf_load_f4(vr, go.w + lane_off);
+            const f32x4 tga = g * a;
+            const f32x4 tga_rot = g_rot * a;
+            const float wk[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned tk = to[k];
+                const f32x4 c = wk[k] * tga_rot;
+                if (tk & kGlobalTag) {
+                    const unsigned o = (tk & ~kGlobalTag) + lane_off;
+                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(c.x, gr, (int)(o + c0), 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(c.y, gr, (int)(o + c1), 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(c.z, gr, (int)(o + c2), 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(c.w, gr, (int)(o + c3), 0, 0);
+                } else {
+                    unsigned char *p = s_dyn + tk + lane_off;
+                    atomicAdd(reinterpret_cast<float *>(p + c0), c.x);
+                    atomicAdd(reinterpret_cast<float *>(p + c1), c.y);
+                    atomicAdd(reinterpret_cast<float *>(p + c2), c.z);
+                    atomicAdd(reinterpret_cast<float *>(p + c3), c.w);
+                }
+            }
+            const f32x4 val = wk[0] * v1 + wk[1] * v2 + wk[2] * v3 + wk[3] * v4;
+            const f32x4 gw = hh * (v2 - v1) + lh * (v4 - v3);
+            const f32x4 gh = hw * (v3 - v1) + lw * (v4 - v2);
+            float pa = g.x * val.x + g.y * val.y + g.z * val.z + g.w * val.w;
+            float pw = gw.x * tga.x + gw.y * tga.y + gw.z * tga.z + gw.w * tga.w;
+            float ph = gh.x * tga.x + gh.y * tga.y + gh.z * tga.z + gh.w * tga.w;
+            pa = sum8(pa);
+            pw = sum8(pw);
+            ph = sum8(ph);
+            if (sub == (t & 7)) {
+                const int l = t / pl.P;
+                res[2 * t] = pw * (float)tb.W[l];
+                res[2 * t + 1] = ph * (float)tb.H[l];
+                res[2 * LP + t] = pa;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (row.ok) {
+            for (int i = sub; i < 2 * LP; i += 8) grad_loc[row.pm * LP * 2 + i] = res[i];
+            for (int i = sub; i < LP; i += 8) grad_attn[row.pm * LP + i] = res[2 * LP + i];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    // ---- flush: one coalesced global atomic per touched window element ----
+    for (int l = 0; l < pl.L; ++l) {
+        const int win = tb.win[l], magic = tb.magic[l], base = tb.base[l];
+        const int oy = tb.oy[l], ox = tb.ox[l], H = tb.H[l], W = tb.W[l];
+        const int n = win * win * D;
+        for (int i = threadIdx.x; i < n; i += kTileThreads) {
+            const int pix = i >> 5, c = i & 31;
+            const float v = win_f[(base + pix) * D + c];
+            if (v != 0.f) {
+                const int wy = (pix * magic) >> 16, wx = pix - wy * win;
+                const int gy = oy + wy, gx = ox + wx;
+                if (gy < H && gx < W)
+                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(
+                        v, gr, (int)(tile_pixel_off(tb, pl, b, l, gy, gx, m) + (unsigned)c * 4u), 0, 0);
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------
 // host side
 // ----------------------------------------------------------------------------------------
 thread_local char g_err[256] = {0};
@@ -539,6 +954,7 @@ thread_local const char *g_kernel = "";
 std::atomic<int> opt_fwd_variant{0}, opt_bwd_variant{0};
 std::atomic<int> opt_fwd_block{256}, opt_bwd_block{256};
 std::atomic<int> opt_fwd_grid_mult{8}, opt_bwd_grid_mult{8};
+std::atomic<int> opt_fwd_tile_margin{3}, opt_bwd_tile_margin{2};
 
 int fail(int code, const char *msg) {
     snprintf(g_err, sizeof(g_err), "%s", msg);
@@ -575,9 +991,63 @@ int clamp_grid(long want, int mult) {
 
 bool d32_ok(int D, int L, long value_bytes) { return D == 32 && L <= kMaxLevels && value_bytes < 0x7fffff00L; }
 
+// Plan the region tiling from the HOST copy of the level shapes.  Returns false when the tiled
+// kernels do not apply (then the gather kernels run).
+bool make_tile_plan(TilePlan &pl, const int64_t *shapes_host, int N, int S, int M, int D, int L, int Lq, int P,
+                    long value_bytes, int margin, size_t extra_lds_per_pixel_row, size_t fixed_lds, size_t &lds) {
+    if (!shapes_host || D != 32 || L < 1 || L > kTileMaxL || Lq != S || value_bytes >= 0x7fffff00L) return false;
+    if (margin < 0) margin = 0;
+    memset(&pl, 0, sizeof(pl));
+    pl.N = N; pl.S = S; pl.M = M; pl.L = L; pl.P = P; pl.Lq = Lq;
+    pl.value_bytes = (unsigned)value_bytes;
+    long q = 0;
+    int rows = 0, px = 0, RY = 0, RX = 0;
+    for (int l = 0; l < kTileMaxL; ++l) {
+        if (l < L) {
+            const long H = shapes_host[2 * l], W = shapes_host[2 * l + 1];
+            if (H <= 0 || W <= 0 || H > 32767 || W > 32767) return false;
+            const int sh = L - 1 - l, side = 1 << sh;
+            int win = side + 2 * margin;
+            if (win > 32) win = 32;
+            pl.H[l] = (int)H; pl.W[l] = (int)W; pl.qstart[l] = (int)q; pl.shift[l] = sh; pl.row0[l] = rows;
+            pl.win[l] = win; pl.win_base[l] = px;
+            const int magic = 65536 / win + 1;
+            for (int x = 0; x < win * win; ++x)
+                if (((x * magic) >> 16) != x / win) return false;
+            pl.win_magic[l] = magic;
+            q += H * W; rows += side * side; px += win * win;
+            const int ry = (int)((H + side - 1) / side), rx = (int)((W + side - 1) / side);
+            RY = ry > RY ? ry : RY;
+            RX = rx > RX ? rx : RX;
+        } else {  // inert padding so that table loads stay in range
+            pl.H[l] = 1; pl.W[l] = 1; pl.qstart[l] = (int)q; pl.shift[l] = 0; pl.row0[l] = rows;
+            pl.win[l] = 1; pl.win_magic[l] = 65537; pl.win_base[l] = px;
+        }
+    }
+    if (q != S) return false;  // host shapes do not describe this value tensor
+    pl.row0[kTileMaxL] = rows; pl.win_base[kTileMaxL] = px;
+    for (int l = L; l <= kTileMaxL; ++l) { pl.row0[l] = rows; pl.win_base[l] = px; }
+    pl.rows = rows; pl.RY = RY; pl.RX = RX;
+    const long nb = (long)N * RY * RX * M;
+    if (nb > (1L << 30)) return false;
+    pl.n_blocks = (int)nb;
+    lds = (size_t)px * 128 + fixed_lds + extra_lds_per_pixel_row;
+    return lds <= 160 * 1024 - 512;
+}
+
+template <typename K>
+int allow_big_lds(K kernel, size_t lds) {
+    if (lds <= 64 * 1024) return MSDA_OK;
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+    return MSDA_OK;
+}
+
 template <typename TV, typename TC>
 int forward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart, const TC *loc, const TC *attn, int N,
-                 int S, int M, int D, int L, int Lq, int P, TV *out, hipStream_t stream, bool allow_d32) {
+                 int S, int M, int D, int L, int Lq, int P, TV *out, const int64_t *shapes_host, hipStream_t stream,
+                 bool allow_d32) {
     int rc = check_dims(value, shapes, lstart, loc, attn, out, N, S, M, D, L, Lq, P);
     if (rc) return rc;
     if ((long)N * Lq == 0) { g_err[0] = 0; return MSDA_OK; }
@@ -595,8 +1065,25 @@ int forward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart, 
         return check_launch("msda_fwd_generic");
     }
     if constexpr (sizeof(TV) == 4 && sizeof(TC) == 4) {
+        if (variant == 5) {
+            TilePlan pl;
+            size_t lds = 0;
+            const size_t rec_bytes = (size_t)32 * (2 * L * P + 1) * 16;
+            if (make_tile_plan(pl, shapes_host, N, S, M, D, L, Lq, P, value_bytes, opt_fwd_tile_margin.load(), 128,
+                               rec_bytes, lds)) {
+                rc = allow_big_lds(msda_fwd_d32_tile, lds);
+                if (rc) return rc;
+                const int grid = (pl.n_blocks + 7) & ~7;
+                g_kernel = "msda_fwd_d32_tile";
+                hipLaunchKernelGGL(msda_fwd_d32_tile, dim3(grid), dim3(kTileThreads), lds, stream,
+                                   (const float *)value, lstart, (const float *)loc, (const float *)attn,
+                                   (float *)out, pl);
+                return check_launch(g_kernel);
+            }
+            variant = 2;  // tiling does not apply to this call
+        }
         int block = opt_fwd_block.load();
-        if (block < 64 || block > 1024 || (block & 63)) block = 256;
+        if (block < 64 || block > 256 || (block & 63)) block = 256;  // kernels carry __launch_bounds__(256)
         const int wpb = block / 64;
         const long n_tasks = ((long)N * Lq * M + 7) / 8;
         // small problems: one wave per block so every task gets its own CU slot
@@ -629,7 +1116,7 @@ int forward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart, 
 template <typename TV, typename TC, typename TG>
 int backward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart, const TC *loc, const TC *attn,
                   const TV *grad_out, int N, int S, int M, int D, int L, int Lq, int P, TG *grad_value, TC *grad_loc,
-                  TC *grad_attn, int zero_grad_value, hipStream_t stream, bool allow_d32) {
+                  TC *grad_attn, int zero_grad_value, const int64_t *shapes_host, hipStream_t stream, bool allow_d32) {
     int rc = check_dims(value, shapes, lstart, loc, attn, grad_out, N, S, M, D, L, Lq, P);
     if (rc) return rc;
     if (!grad_value || !grad_loc || !grad_attn) return fail(MSDA_EINVAL, "null gradient pointer");
@@ -654,8 +1141,26 @@ int backward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart,
         return check_launch("msda_bwd_generic");
     }
     if constexpr (sizeof(TV) == 4 && sizeof(TC) == 4 && sizeof(TG) == 4) {
+        if (variant == 5) {
+            TilePlan pl;
+            size_t lds = 0;
+            const size_t rec_bytes = (size_t)32 * (3 * L * P + 1) * 16 + (size_t)32 * (3 * L * P + 1) * 4;
+            if (make_tile_plan(pl, shapes_host, N, S, M, D, L, Lq, P, value_bytes, opt_bwd_tile_margin.load(), 0,
+                               rec_bytes, lds)) {
+                rc = allow_big_lds(msda_bwd_d32_tile, lds);
+                if (rc) return rc;
+                const int grid = (pl.n_blocks + 7) & ~7;
+                g_kernel = "msda_bwd_d32_tile";
+                hipLaunchKernelGGL(msda_bwd_d32_tile, dim3(grid), dim3(kTileThreads), lds, stream,
+                                   (const float *)value, lstart, (const float *)loc, (const float *)attn,
+                                   (const float *)grad_out, (float *)grad_value, (float *)grad_loc,
+                                   (float *)grad_attn, pl);
+                return check_launch(g_kernel);
+            }
+            variant = 2;
+        }
         int block = opt_bwd_block.load();
-        if (block < 64 || block > 1024 || (block & 63)) block = 256;
+        if (block < 64 || block > 256 || (block & 63)) block = 256;  // kernels carry __launch_bounds__(256)
         const int wpb = block / 64;
         const long n_tasks = ((long)N * Lq * M + 7) / 8;
         int use_block = block;
@@ -696,44 +1201,39 @@ const char *msda_last_kernel(void) { return g_kernel; }
 int msda_forward_f32(const float *value, const int64_t *shapes_dev, const int64_t *lstart_dev, const float *loc,
                      const float *attn, int N, int S, int M, int D, int L, int Lq, int P, float *out,
                      const int64_t *shapes_host, void *stream) {
-    (void)shapes_host;
-    return forward_impl<float, float>(value, shapes_dev, lstart_dev, loc, attn, N, S, M, D, L, Lq, P, out,
+    return forward_impl<float, float>(value, shapes_dev, lstart_dev, loc, attn, N, S, M, D, L, Lq, P, out, shapes_host,
                                       (hipStream_t)stream, true);
 }
 
 int msda_forward_f64(const double *value, const int64_t *shapes_dev, const int64_t *lstart_dev, const double *loc,
                      const double *attn, int N, int S, int M, int D, int L, int Lq, int P, double *out,
                      const int64_t *shapes_host, void *stream) {
-    (void)shapes_host;
     return forward_impl<double, double>(value, shapes_dev, lstart_dev, loc, attn, N, S, M, D, L, Lq, P, out,
-                                        (hipStream_t)stream, false);
+                                        shapes_host, (hipStream_t)stream, false);
 }
 
 int msda_forward_bf16(const uint16_t *value, const int64_t *shapes_dev, const int64_t *lstart_dev, const float *loc,
                       const float *attn, int N, int S, int M, int D, int L, int Lq, int P, uint16_t *out,
                       const int64_t *shapes_host, void *stream) {
-    (void)shapes_host;
     return forward_impl<bf16_t, float>((const bf16_t *)value, shapes_dev, lstart_dev, loc, attn, N, S, M, D, L, Lq, P,
-                                       (bf16_t *)out, (hipStream_t)stream, false);
+                                       (bf16_t *)out, shapes_host, (hipStream_t)stream, false);
 }
 
 int msda_backward_f32(const float *value, const int64_t *shapes_dev, const int64_t *lstart_dev, const float *loc,
                       const float *attn, const float *grad_out, int N, int S, int M, int D, int L, int Lq, int P,
                       float *grad_value, float *grad_loc, float *grad_attn, int zero_grad_value,
                       const int64_t *shapes_host, void *stream) {
-    (void)shapes_host;
     return backward_impl<float, float, float>(value, shapes_dev, lstart_dev, loc, attn, grad_out, N, S, M, D, L, Lq, P,
-                                              grad_value, grad_loc, grad_attn, zero_grad_value, (hipStream_t)stream,
-                                              true);
+                                              grad_value, grad_loc, grad_attn, zero_grad_value, shapes_host,
+                                              (hipStream_t)stream, true);
 }
 
 int msda_backward_f64(const double *value, const int64_t *shapes_dev, const int64_t *lstart_dev, const double *loc,
                       const double *attn, const double *grad_out, int N, int S, int M, int D, int L, int Lq, int P,
                       double *grad_value, double *grad_loc, double *grad_attn, int zero_grad_value,
                       const int64_t *shapes_host, void *stream) {
-    (void)shapes_host;
     return backward_impl<double, double, double>(value, shapes_dev, lstart_dev, loc, attn, grad_out, N, S, M, D, L, Lq,
-                                                 P, grad_value, grad_loc, grad_attn, zero_grad_value,
+                                                 P, grad_value, grad_loc, grad_attn, zero_grad_value, shapes_host,
                                                  (hipStream_t)stream, false);
 }
 
@@ -741,10 +1241,9 @@ int msda_backward_bf16(const uint16_t *value, const int64_t *shapes_dev, const i
                        const float *attn, const uint16_t *grad_out, int N, int S, int M, int D, int L, int Lq, int P,
                        float *grad_value, float *grad_loc, float *grad_attn, int zero_grad_value,
                        const int64_t *shapes_host, void *stream) {
-    (void)shapes_host;
     return backward_impl<bf16_t, float, float>((const bf16_t *)value, shapes_dev, lstart_dev, loc, attn,
                                                (const bf16_t *)grad_out, N, S, M, D, L, Lq, P, grad_value, grad_loc,
-                                               grad_attn, zero_grad_value, (hipStream_t)stream, false);
+                                               grad_attn, zero_grad_value, shapes_host, (hipStream_t)stream, false);
 }
 
 int msda_sample_indices_f32(const int64_t *shapes_dev, const float *loc, int N, int M, int L, int Lq, int P,
@@ -767,6 +1266,8 @@ static std::atomic<int> *find_opt(const char *key) {
     if (!strcmp(key, "bwd_block")) return &opt_bwd_block;
     if (!strcmp(key, "fwd_grid_mult")) return &opt_fwd_grid_mult;
     if (!strcmp(key, "bwd_grid_mult")) return &opt_bwd_grid_mult;
+    if (!strcmp(key, "fwd_tile_margin")) return &opt_fwd_tile_margin;
+    if (!strcmp(key, "bwd_tile_margin")) return &opt_bwd_tile_margin;
     return nullptr;
 }
 

@@ -1,0 +1,109 @@
+"""Multi-scale deformable attention module on the gfx950 operator.
+
+Same constructor, parameter names (``sampling_offsets``, ``attention_weights``, ``value_proj``,
+``output_proj`` -- state-dict compatible), initialisation and forward contract as the reference
+module (``models/ops/modules/ms_deform_attn.py:36-130``).  What differs is how the work is issued:
+the offset and attention-logit projections share one GEMM over the query (their weight rows are
+stacked: 256 -> 3*M*L*P outputs), and the gather/interpolate/reduce runs in the hand-written HIP
+kernels behind ``MSDeformAttnFunction``.
+"""
+from __future__ import annotations
+
+import math
+import warnings
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+from torch.nn.init import constant_, xavier_uniform_
+
+from ..functions import MSDeformAttnFunction
+
+
+def _is_power_of_2(n) -> bool:
+    if (not isinstance(n, int)) or (n < 0):
+        raise ValueError("invalid input for _is_power_of_2: {} (type: {})".format(n, type(n)))
+    return (n & (n - 1) == 0) and n != 0
+
+
+class MSDeformAttn(nn.Module):
+    def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4, sigmoid_attn=False, visualize=False):
+        super().__init__()
+        if d_model % n_heads != 0:
+            raise ValueError("d_model must be divisible by n_heads, but got {} and {}".format(d_model, n_heads))
+        if not _is_power_of_2(d_model // n_heads):
+            warnings.warn("MSDeformAttn: a power-of-2 head dimension (32 for MeMOTR) takes the specialised "
+                          "gfx950 kernels; other sizes run the generic ones.")
+        self.im2col_step = 64
+        self.sigmoid_attn = sigmoid_attn
+        self.d_model = d_model
+        self.n_levels = n_levels
+        self.n_heads = n_heads
+        self.n_points = n_points
+        self.visualize = visualize  # accepted for config compatibility; tensor dumps are not implemented
+
+        self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
+        self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
+        self.value_proj = nn.Linear(d_model, d_model)
+        self.output_proj = nn.Linear(d_model, d_model)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        """Zero offset weights, bias = 8-direction star scaled by the point index (reference :72-86)."""
+        constant_(self.sampling_offsets.weight.data, 0.0)
+        thetas = torch.arange(self.n_heads, dtype=torch.float32) * (2.0 * math.pi / self.n_heads)
+        grid = torch.stack([thetas.cos(), thetas.sin()], -1)
+        grid = grid / grid.abs().max(-1, keepdim=True)[0]
+        grid = grid.view(self.n_heads, 1, 1, 2).repeat(1, self.n_levels, self.n_points, 1)
+        grid = grid * torch.arange(1, self.n_points + 1, dtype=torch.float32).view(1, 1, self.n_points, 1)
+        with torch.no_grad():
+            self.sampling_offsets.bias = nn.Parameter(grid.reshape(-1))
+        constant_(self.attention_weights.weight.data, 0.0)
+        constant_(self.attention_weights.bias.data, 0.0)
+        xavier_uniform_(self.value_proj.weight.data)
+        constant_(self.value_proj.bias.data, 0.0)
+        xavier_uniform_(self.output_proj.weight.data)
+        constant_(self.output_proj.bias.data, 0.0)
+
+    def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
+                input_padding_mask=None):
+        """
+        query (N, Lq, C); reference_points (N, Lq, L, 2|4) in [0,1] incl. padding; input_flatten (N, S, C);
+        input_spatial_shapes (L, 2) int64 (H, W); input_level_start_index (L,); input_padding_mask (N, S) bool.
+        Returns (N, Lq, C).
+        """
+        N, Lq, _ = query.shape
+        S = input_flatten.shape[1]
+        M, L, P = self.n_heads, self.n_levels, self.n_points
+
+        value = self.value_proj(input_flatten)
+        if input_padding_mask is not None:
+            value = value.masked_fill(input_padding_mask[..., None], 0.0)
+        value = value.view(N, S, M, self.d_model // M)
+
+        # one GEMM for both query projections
+        n_off = M * L * P * 2
+        w = torch.cat((self.sampling_offsets.weight, self.attention_weights.weight), 0)
+        b = torch.cat((self.sampling_offsets.bias, self.attention_weights.bias), 0)
+        proj = F.linear(query, w, b)
+        offsets = proj[..., :n_off].reshape(N, Lq, M, L, P, 2)
+        logits = proj[..., n_off:].reshape(N, Lq, M, L * P)
+        if self.sigmoid_attn:
+            attn = logits.sigmoid()
+        else:
+            attn = F.softmax(logits, -1)
+        attn = attn.view(N, Lq, M, L, P)
+
+        if reference_points.shape[-1] == 2:
+            wh = input_spatial_shapes.flip(-1).to(offsets.dtype)  # (L, 2) as (W, H)
+            loc = reference_points[:, :, None, :, None, :] + offsets / wh[None, None, None, :, None, :]
+        elif reference_points.shape[-1] == 4:
+            loc = reference_points[:, :, None, :, None, :2] \
+                + offsets / P * reference_points[:, :, None, :, None, 2:] * 0.5
+        else:
+            raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead.".format(
+                reference_points.shape[-1]))
+
+        out = MSDeformAttnFunction.apply(value.contiguous(), input_spatial_shapes, input_level_start_index,
+                                         loc.contiguous(), attn.contiguous(), self.im2col_step)
+        return self.output_proj(out)

@@ -1,0 +1,113 @@
+"""Per-clip track state handed between frames (contract of structures/track_instances.py:7-129).
+
+A bag of per-track tensors.  The quirks of the reference container that callers can observe are kept:
+``to`` / ``__getitem__`` / ``cat_tracked_instances`` rebuild the object with *default* meta
+(``use_dab=False``; ``cat`` also resets ``hidden_dim``/``num_classes``) and then overwrite every
+attribute, so only tensor fields are reliable after the first query update.
+"""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+
+_TENSOR_FIELDS = (
+    "ref_pts", "query_embed", "ids", "boxes", "labels", "logits", "matched_idx", "output_embed",
+    "disappear_time", "scores", "area", "iou", "last_output", "long_memory", "last_appear_boxes",
+)
+
+
+class TrackInstances:
+    def __init__(self, frame_height: float = 1.0, frame_width: float = 1.0, hidden_dim: int = 256,
+                 num_classes: int = 1, use_dab: bool = False):
+        self.use_dab = use_dab
+        self.frame_height = frame_height
+        self.frame_width = frame_width
+        self.hidden_dim = hidden_dim
+        self.num_classes = num_classes
+        self.ref_pts = torch.zeros((0, 4))
+        self.query_embed = torch.zeros((0, hidden_dim if use_dab else 2 * hidden_dim))
+        self.ids = torch.zeros((0,), dtype=torch.long)
+        self.boxes = torch.zeros((0, 4))
+        self.labels = torch.zeros((0,), dtype=torch.long)
+        self.logits = torch.zeros((0, num_classes))
+        self.matched_idx = torch.zeros((0,), dtype=torch.long)
+        self.output_embed = torch.zeros((0, hidden_dim))
+        self.disappear_time = torch.zeros((0,), dtype=torch.long)
+        self.scores = torch.zeros((0,), dtype=torch.float)
+        self.area = torch.zeros((0,), dtype=torch.float)
+        self.iou = torch.zeros((0,), dtype=torch.float)
+        self.last_output = torch.zeros((0, hidden_dim), dtype=torch.float)
+        self.long_memory = torch.zeros((0, hidden_dim), dtype=torch.float)
+        self.last_appear_boxes = torch.zeros((0, 4))
+
+    def _blank_like(self) -> "TrackInstances":
+        return TrackInstances(frame_height=self.frame_height, frame_width=self.frame_width,
+                              hidden_dim=self.hidden_dim, num_classes=self.num_classes)
+
+    def to(self, device) -> "TrackInstances":
+        res = self._blank_like()
+        for k, v in vars(self).items():
+            setattr(res, k, v.to(device) if hasattr(v, "to") else v)
+        return res
+
+    def __len__(self) -> int:
+        assert self.ref_pts.shape[0] == self.query_embed.shape[0]
+        return max(self.query_embed.shape[0], self.labels.shape[0])
+
+    def __getitem__(self, item) -> "TrackInstances":
+        if type(item) == int:
+            n = len(self)
+            if item >= n or item < -n:
+                raise IndexError("TrackInstances index out of range!")
+            item = slice(item, None, n)
+        res = self._blank_like()
+        for k, v in vars(self).items():
+            if hasattr(v, "__getitem__") and v.shape[0] != 0:
+                setattr(res, k, v[item])
+            else:
+                setattr(res, k, v)
+        return res
+
+    @staticmethod
+    def init_tracks(batch: dict, hidden_dim: int, num_classes: int, device="cpu", use_dab: bool = False):
+        """One empty TrackInstances per clip of the batch (``batch["imgs"][b][t]`` is a (3,H,W) frame)."""
+        first_frames = [clip[0] for clip in batch["imgs"]]
+        h_max = max(f.shape[-2] for f in first_frames)
+        w_max = max(f.shape[-1] for f in first_frames)
+        return [
+            TrackInstances(frame_height=float(f.shape[-2] / h_max), frame_width=float(f.shape[-1] / w_max),
+                           hidden_dim=hidden_dim, num_classes=num_classes, use_dab=use_dab).to(device)
+            for f in first_frames
+        ]
+
+    @staticmethod
+    def cat_tracked_instances(tracked1: "TrackInstances", tracked2: "TrackInstances") -> "TrackInstances":
+        res = TrackInstances(frame_height=tracked1.frame_height, frame_width=tracked1.frame_width)
+        for k, v in vars(tracked1).items():
+            if type(v) is torch.Tensor:
+                setattr(res, k, torch.cat((v, getattr(tracked2, k))))
+        return res
+
+    @staticmethod
+    def tracks_to_meta_tensors(tracks: List["TrackInstances"]):
+        keys = [k for k in vars(tracks[0]) if type(getattr(tracks[0], k)) is torch.Tensor]
+        meta = {"frame_height": [], "frame_width": [], "hidden_dim": [], "num_classes": [], "keys": keys}
+        tensors = []
+        for t in tracks:
+            for name in ("frame_height", "frame_width", "hidden_dim", "num_classes"):
+                meta[name].append(getattr(t, name))
+            tensors.extend(getattr(t, k) for k in keys)
+        return meta, tensors
+
+    @staticmethod
+    def meta_tensors_to_tracks(meta: dict, tensors: List[torch.Tensor]):
+        n_keys = len(meta["keys"])
+        tracks = []
+        for b in range(len(meta["frame_height"])):
+            t = TrackInstances(frame_height=meta["frame_height"][b], frame_width=meta["frame_width"][b],
+                               hidden_dim=meta["hidden_dim"][b], num_classes=meta["num_classes"][b])
+            for i, k in enumerate(meta["keys"]):
+                setattr(t, k, tensors[b * n_keys + i])
+            tracks.append(t)
+        return tracks

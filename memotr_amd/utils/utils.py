@@ -1,0 +1,48 @@
+"""Small helpers of the reference's utils/utils.py that the per-frame path touches."""
+from __future__ import annotations
+
+import os
+import random
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import yaml
+
+
+def is_distributed() -> bool:
+    return dist.is_available() and dist.is_initialized()
+
+
+def distributed_rank() -> int:
+    return dist.get_rank() if is_distributed() else 0
+
+
+def distributed_world_size() -> int:
+    return dist.get_world_size() if is_distributed() else 1
+
+
+def is_main_process() -> bool:
+    return distributed_rank() == 0
+
+
+def set_seed(seed: int) -> None:
+    """seed + rank, as utils/utils.py:37-38."""
+    seed = seed + distributed_rank()
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    random.seed(seed)
+    os.environ["PYTHONHASHSEED"] = str(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+
+
+def yaml_to_dict(path: str) -> dict:
+    with open(path) as f:
+        return yaml.load(f.read(), yaml.FullLoader)
+
+
+def inverse_sigmoid(x: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """logit with both odds clamped at eps (utils/utils.py:61-74)."""
+    x = x.clamp(min=0, max=1)
+    return torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))

@@ -178,6 +178,72 @@ def test_index_arithmetic_is_bit_exact(msda):
     assert live.mean() > 0.8
 
 
+# ----------------------------------------------------------------------------- region-tiled kernels
+def pyramid_case(seed, shapes, N, M, P, mode, dtype=np.float32):
+    """Self-attention layout (one query per pyramid pixel, Lq == S) -- what the tiled kernels target."""
+    rng = np.random.default_rng(seed)
+    shapes = np.asarray(shapes, dtype=np.int64)
+    L = len(shapes)
+    S = int((shapes[:, 0] * shapes[:, 1]).sum())
+    g = seeded_case(seed, N, M, 32, S, L, P, shapes, dtype)
+    if mode == "local":     # pixel-centre reference points + a few pixels of offset (encoder-like)
+        ref = []
+        for (H, W) in shapes:
+            ys, xs = np.meshgrid((np.arange(H) + 0.5) / H, (np.arange(W) + 0.5) / W, indexing="ij")
+            ref.append(np.stack([xs.reshape(-1), ys.reshape(-1)], -1))
+        ref = np.concatenate(ref, 0)                                     # (S, 2)
+        wh = shapes[:, ::-1].astype(np.float64)                          # (L, 2) as (W, H)
+        off = rng.normal(0, 2.0, (N, S, M, L, P, 2))
+        g["loc"] = (ref[None, :, None, None, None, :] + off / wh[None, None, None, :, None, :]).astype(dtype)
+    return g
+
+
+TILE_CASES = [
+    (41, [(20, 28), (10, 14), (5, 7), (3, 4)], 2, 8, 4, "local"),
+    (42, [(20, 28), (10, 14), (5, 7), (3, 4)], 1, 8, 4, "uniform"),     # almost everything takes the global path
+    (43, [(13, 9), (7, 5), (4, 3)], 2, 3, 2, "local"),                  # L=3, M=3, odd sizes, partial regions
+    (44, [(6, 8), (3, 4)], 1, 8, 4, "local"),                           # L=2
+    (45, [(5, 5)], 1, 8, 4, "local"),                                   # L=1: one query per region
+    (46, [(17, 23), (9, 12), (5, 6), (3, 3)], 1, 8, 3, "local"),        # LP=12, non-halving pyramid
+]
+
+
+@pytest.mark.parametrize("case", TILE_CASES, ids=lambda c: f"seed{c[0]}")
+@pytest.mark.parametrize("margin", [0, 2, 4])
+def test_region_tiled_kernels_match_oracle(msda, hip_lib, case, margin):
+    from oracle import msda_oracle as oracle
+    seed, shapes, N, M, P, mode = case
+    g = pyramid_case(seed, shapes, N, M, P, mode)
+    ref_out = oracle.forward(g["value"], g["shapes"], g["level_start"], g["loc"], g["attn"])
+    rgv, rgl, rga = oracle.backward(g["value"], g["shapes"], g["level_start"], g["loc"], g["attn"], g["grad_out"])
+    hip_lib.set_option("fwd_variant", 5)
+    hip_lib.set_option("bwd_variant", 5)
+    hip_lib.set_option("fwd_tile_margin", margin)
+    hip_lib.set_option("bwd_tile_margin", margin)
+    try:
+        out = run_fwd(msda, g)
+        assert hip_lib.last_kernel() == "msda_fwd_d32_tile"
+        gv, gl, ga = run_bwd(msda, g)
+        assert hip_lib.last_kernel() == "msda_bwd_d32_tile"
+    finally:
+        hip_lib.set_option("fwd_tile_margin", 3)
+        hip_lib.set_option("bwd_tile_margin", 2)
+    np.testing.assert_allclose(out, ref_out, **tol(np.float32, 2))
+    np.testing.assert_allclose(gv, rgv, **tol(np.float32, 8))
+    np.testing.assert_allclose(gl, rgl, **tol(np.float32, 100))
+    np.testing.assert_allclose(ga, rga, **tol(np.float32, 40))
+
+
+def test_tiled_variant_falls_back_when_queries_are_not_the_pyramid(msda, hip_lib):
+    g = seeded_case(47, 1, 8, 32, 300, 4, 4, [(25, 42), (13, 21), (7, 11), (4, 6)], np.float32)
+    hip_lib.set_option("fwd_variant", 5)
+    out = run_fwd(msda, g)
+    assert "gather" in hip_lib.last_kernel()
+    from oracle import msda_oracle as oracle
+    np.testing.assert_allclose(out, oracle.forward(g["value"], g["shapes"], g["level_start"], g["loc"], g["attn"]),
+                               **tol(np.float32, 2))
+
+
 # ----------------------------------------------------------------------------- full size (BASELINE shapes)
 @pytest.fixture(scope="module")
 def full_inputs():
@@ -191,16 +257,18 @@ def test_full_size_specialised_equals_generic(msda, hip_lib, full_inputs):
     args = (x["value"], x["shapes"], x["level_start"], x["loc"], x["attn"])
     hip_lib.set_option("fwd_variant", 1)
     ref = msda.ms_deform_attn_forward(*args, 64)
-    for v in (2, 3, 4):
+    for v in (2, 3, 4, 5):
         hip_lib.set_option("fwd_variant", v)
         out = msda.ms_deform_attn_forward(*args, 64)
         assert "d32" in hip_lib.last_kernel()
+        assert (v == 5) == ("tile" in hip_lib.last_kernel())
         torch.testing.assert_close(out, ref, rtol=1e-4, atol=2e-5)
     hip_lib.set_option("bwd_variant", 1)
     ref_g = msda.ms_deform_attn_backward(*args, x["grad_out"], 64)
-    for v in (2, 3):
+    for v in (2, 3, 5):
         hip_lib.set_option("bwd_variant", v)
         got = msda.ms_deform_attn_backward(*args, x["grad_out"], 64)
+        assert (v == 5) == ("tile" in hip_lib.last_kernel())
         torch.testing.assert_close(got[0], ref_g[0], rtol=1e-3, atol=2e-4)   # atomics: order-dependent sums
         torch.testing.assert_close(got[1], ref_g[1], rtol=1e-3, atol=5e-3)
         torch.testing.assert_close(got[2], ref_g[2], rtol=1e-3, atol=5e-4)

@@ -26,17 +26,19 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--out", default="gpurun_out/kbench.json")
-    ap.add_argument("--fwd-variants", default="1,2,3,4")
-    ap.add_argument("--bwd-variants", default="1,2,3,90")
-    ap.add_argument("--blocks", default="64,128,256,512")
-    ap.add_argument("--grid-mults", default="4,8,16,32")
+    ap.add_argument("--fwd-variants", default="1,2,3,4,5")
+    ap.add_argument("--bwd-variants", default="1,2,3,90,5")
+    ap.add_argument("--blocks", default="64,256")
+    ap.add_argument("--margins", default="1,2,3,4,5")
+    ap.add_argument("--grid-mults", default="8,16,32")
     args = ap.parse_args()
     fv = [int(x) for x in args.fwd_variants.split(",")]
     bv = [int(x) for x in args.bwd_variants.split(",")]
     blocks = [int(x) for x in args.blocks.split(",")]
     gms = [int(x) for x in args.grid_mults.split(",")]
+    margins = [int(x) for x in args.margins.split(",")]
     if args.quick:
-        blocks, gms = [256], [8]
+        blocks, gms, margins = [256], [16], [2, 3]
     rows = []
     shapes = [("enc", None), ("dec320", 320)] if args.quick else [("enc", None), ("dec300", 300), ("dec400", 400)]
     for dist in ("encoder_like", "uniform"):
@@ -50,9 +52,13 @@ def main():
             ref = (call.out.clone(), call.gv.clone(), call.gl.clone(), call.ga.clone())
             for v in fv:
                 combos = [(256, 8)] if v == 1 else itertools.product(blocks, gms)
+                if v == 5:
+                    if nq is not None:
+                        continue
+                    combos = [(256, mg) for mg in margins]
                 for blk, gm in combos:
                     _lib.set_option("fwd_variant", v); _lib.set_option("fwd_block", blk)
-                    _lib.set_option("fwd_grid_mult", gm)
+                    _lib.set_option("fwd_tile_margin" if v == 5 else "fwd_grid_mult", gm)
                     call.out.zero_(); call.fwd(); torch.cuda.synchronize()
                     err = float((call.out - ref[0]).abs().max())
                     ms = time_kernel(call.fwd, iters=30 if nq is None else 100)
@@ -63,9 +69,13 @@ def main():
                           f"({gbps/80:5.1f}%)  err {err:.1e}  {_lib.last_kernel()}", flush=True)
             for v in bv:
                 combos = [(256, 8)] if v == 1 else itertools.product(blocks, gms)
+                if v == 5:
+                    if nq is not None:
+                        continue
+                    combos = [(256, mg) for mg in margins]
                 for blk, gm in combos:
                     _lib.set_option("bwd_variant", v); _lib.set_option("bwd_block", blk)
-                    _lib.set_option("bwd_grid_mult", gm)
+                    _lib.set_option("bwd_tile_margin" if v == 5 else "bwd_grid_mult", gm)
                     call.bwd(); torch.cuda.synchronize()
                     errs = [float((a - b).abs().max()) for a, b in zip((call.gv, call.gl, call.ga), ref[1:])]
                     ms = time_kernel(call.bwd, iters=10 if nq is None else 50)
