@@ -59,41 +59,39 @@ def _suffix(value, sampling_loc, attn_weight):
     return suf
 
 
-_HOST_SHAPES = {}
-
-
 def host_shapes(spatial_shapes):
-    """HOST copy of ``spatial_shapes`` as a pinned-in-python numpy int64 array (or None).
+    """HOST copy of ``spatial_shapes`` as a numpy int64 array kept on the tensor object itself.
 
     The level-aware kernels plan their launch from it.  Callers that know the pyramid as python ints
     attach it up front (``tag_host_shapes``) so no device->host read ever happens on the hot path;
-    otherwise the first call with a given shapes tensor pays one synchronising ``.cpu()`` and the
-    result is cached on (storage address, version).
+    otherwise the first call with a given tensor *object* pays one synchronising ``.cpu()`` (the copy is
+    stored as an attribute of that object together with its version counter, so it can never go stale
+    or be confused with another tensor that reuses the same device address).
     """
-    arr = getattr(spatial_shapes, "_msda_host", None)
-    if arr is not None:
-        return arr
-    key = (spatial_shapes.data_ptr(), spatial_shapes._version, spatial_shapes.device.index)
-    arr = _HOST_SHAPES.get(key)
-    if arr is None:
-        import numpy as np
-        if len(_HOST_SHAPES) > 256:
-            _HOST_SHAPES.clear()
-        arr = np.ascontiguousarray(spatial_shapes.detach().cpu().numpy(), dtype=np.int64)
-        _HOST_SHAPES[key] = arr
+    tagged = getattr(spatial_shapes, "_msda_host", None)
+    if tagged is not None and tagged[1] == spatial_shapes._version:
+        return tagged[0]
+    import numpy as np
+    arr = np.ascontiguousarray(spatial_shapes.detach().cpu().numpy(), dtype=np.int64)
+    spatial_shapes._msda_host = (arr, spatial_shapes._version)
     return arr
 
 
 def tag_host_shapes(spatial_shapes, shapes_list):
     """Attach the python-side pyramid [(H, W), ...] to a device ``spatial_shapes`` tensor."""
     import numpy as np
-    spatial_shapes._msda_host = np.ascontiguousarray(np.asarray(shapes_list, dtype=np.int64).reshape(-1, 2))
+    arr = np.ascontiguousarray(np.asarray(shapes_list, dtype=np.int64).reshape(-1, 2))
+    spatial_shapes._msda_host = (arr, spatial_shapes._version)
     return spatial_shapes
 
 
-def _host_ptr(spatial_shapes):
+def _host_ptr(spatial_shapes, eligible: bool):
+    """(keep-alive, pointer) of the host shapes -- only fetched for calls the level-aware kernels can take
+    (fp32, D = 32, one query per pyramid pixel); every other call passes NULL and never synchronises."""
+    if not eligible:
+        return None, None
     arr = host_shapes(spatial_shapes)
-    return arr, (arr.ctypes.data if arr is not None else None)
+    return arr, arr.ctypes.data
 
 
 def _stream(device) -> int:
@@ -114,7 +112,7 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
         output = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
         if output.numel() == 0:  # a frame without queries: nothing to launch (empty tensors have no storage)
             return output
-        keep, hptr = _host_ptr(spatial_shapes)
+        keep, hptr = _host_ptr(spatial_shapes, suf == "f32" and D == 32 and Lq == S and L <= 4)
         rc = getattr(_lib.lib, f"msda_forward_{suf}")(
             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
             attn_weight.data_ptr(), N, S, M, D, L, Lq, P, output.data_ptr(), hptr, _stream(value.device))
@@ -141,7 +139,7 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
         grad_attn = torch.empty_like(attn_weight)
         if grad_output.numel() == 0:
             return [grad_value.to(value.dtype), grad_loc, grad_attn]
-        keep, hptr = _host_ptr(spatial_shapes)
+        keep, hptr = _host_ptr(spatial_shapes, suf == "f32" and D == 32 and Lq == S and L <= 4)
         rc = getattr(_lib.lib, f"msda_backward_{suf}")(
             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
             attn_weight.data_ptr(), grad_output.data_ptr(), N, S, M, D, L, Lq, P, grad_value.data_ptr(),

@@ -953,7 +953,7 @@ thread_local const char *g_kernel = "";
 
 std::atomic<int> opt_fwd_variant{0}, opt_bwd_variant{0};
 std::atomic<int> opt_fwd_block{256}, opt_bwd_block{256};
-std::atomic<int> opt_fwd_grid_mult{8}, opt_bwd_grid_mult{8};
+std::atomic<int> opt_fwd_grid_mult{32}, opt_bwd_grid_mult{16};
 std::atomic<int> opt_fwd_tile_margin{3}, opt_bwd_tile_margin{2};
 
 int fail(int code, const char *msg) {
@@ -1054,7 +1054,7 @@ int forward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart, 
     int variant = opt_fwd_variant.load();
     const long value_bytes = (long)N * S * M * D * (long)sizeof(TV);
     const bool can32 = allow_d32 && d32_ok(D, L, value_bytes);
-    if (variant == 0) variant = can32 ? 2 : 1;
+    if (variant == 0) variant = can32 ? 3 : 1;  // 4 points (16 rows) in flight: best of the sweep in profiles/
     if (variant >= 2 && !can32) variant = 1;
     if (variant == 1) {
         const long total = (long)N * Lq * M * D;
@@ -1128,7 +1128,10 @@ int backward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart,
     int variant = opt_bwd_variant.load();
     const long value_bytes = (long)N * S * M * D * (long)sizeof(TV);
     const bool can32 = allow_d32 && d32_ok(D, L, value_bytes);
-    if (variant == 0) variant = can32 ? 2 : 1;
+    // Measured on MI355X (profiles/): the backward is bound by L2 float-atomic throughput, and the
+    // row-per-block kernel's 32-consecutive-lane atomics run 4x faster than the 8-lane-strided
+    // pattern of the gather kernel, so it is the default until the tiled backward pre-reduces in LDS.
+    if (variant == 0) variant = 1;
     if (variant >= 2 && !can32) variant = 1;
     if (variant == 1) {
         int block = ((D + 63) / 64) * 64;
