@@ -9,9 +9,9 @@ OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 CMD="python bench.py --steps 3 --warmup 1 --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o stats -- $CMD > "$OUT/stats.log" 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o fetch -- $CMD > "$OUT/pmc_fetch.log" 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_write" -o write -- $CMD > "$OUT/pmc_write.log" 2>&1
-rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d "$OUT/pmc_l2" -o l2 -- $CMD > "$OUT/pmc_l2.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- $CMD > "$OUT/stats.log" 2>&1
+rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o fetch -- $CMD > "$OUT/pmc_fetch.log" 2>&1
+rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d "$OUT/pmc_write" -o write -- $CMD > "$OUT/pmc_write.log" 2>&1
+rocprofv3 --kernel-trace --output-format csv --pmc TCC_HIT_sum TCC_MISS_sum -d "$OUT/pmc_l2" -o l2 -- $CMD > "$OUT/pmc_l2.log" 2>&1
 find "$OUT" -name '*.csv' | head -50
 python tools/prof_summary.py "$OUT" "$TAG"

@@ -41,22 +41,23 @@ __global__ __launch_bounds__(256) void k_lds_add(float* out, int iters, int mode
     if (tid == 0) out[blockIdx.x] = lds[5];
 }
 
-// mode 0: ds_read_b128 row gather (8 lanes x 16 B per 128-B row), random rows per 8-lane group
+// ds_read_b128 row gather (8 lanes x 16 B per 128-B row), random rows per 8-lane group
 __global__ __launch_bounds__(256) void k_lds_read(float* out, int iters) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, sub = lane & 7;
     for (int i = tid; i < 4096; i += 256) lds[i] = (float)i;
     __syncthreads();
+    const f4* lds4 = reinterpret_cast<const f4*>(lds);
     unsigned idx[8];
     unsigned x = (tid >> 3) * 2654435761u + blockIdx.x * 977u;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { x = x * 1664525u + 1013904223u; idx[j] = ((x >> 8) & 127) * 32 + sub * 4; }
+    for (int j = 0; j < 8; ++j) { x = x * 1664525u + 1013904223u; idx[j] = ((x >> 8) & 127) * 8 + sub; }
     f4 acc = {0, 0, 0, 0};
     for (int it = 0; it < iters; it += 8) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            acc += *reinterpret_cast<f4*>(&lds[idx[j]]);
-            idx[j] = (idx[j] + 32 * 37) & 4095;      // new row next time (keeps the loads in the loop)
+            acc += lds4[idx[j]];
+            idx[j] = (idx[j] + 8 * 37) & 1023;      // new row next time (keeps the loads in the loop)
         }
     }
     if (acc.x + acc.y + acc.z + acc.w == 12345.f) out[0] = 1;
