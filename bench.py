@@ -231,6 +231,29 @@ def run_msda(args, rank, world):
     return result
 
 
+def run_msda_kernels_only(args):
+    """Roofline numbers for the dominant kernel + a thunk for the CPU baseline (used by the train workload)."""
+    from memotr_amd.synth import make_inputs
+    dev = torch.device("cuda", torch.cuda.current_device())
+    enc = MsdaCall(make_inputs(device=dev, dist=args.dist, seed=3))
+    dec = MsdaCall(make_inputs(device=dev, dist=args.dist, seed=103, n_queries=300 + args.n_track))
+    ms_fwd = time_kernel(enc.fwd)
+    kernel = enc._lib.last_kernel()
+    ms_bwd = time_kernel(enc.bwd, iters=20)
+    kernel_bwd = enc._lib.last_kernel()
+    ms_dec = time_kernel(dec.fwd)
+    ach = enc.bytes() / (ms_fwd * 1e-3) / 1e9
+    return {
+        "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": ach / HBM_PEAK_GBPS, "traffic": read_traffic(), "kernel": kernel, "ms": ms_fwd,
+                     "algorithmic_bytes": enc.bytes()},
+        "kernels": {"enc_fwd_ms": ms_fwd, "enc_bwd_ms": ms_bwd, "dec_fwd_ms": ms_dec, "enc_bwd_kernel": kernel_bwd,
+                    "enc_bwd_GBps": enc.bytes(True) / (ms_bwd * 1e-3) / 1e9},
+        "cpu_baseline_fn": lambda: cpu_baseline_msda(args, dict(dist=args.dist, seed=3),
+                                                     dict(dist=args.dist, seed=103, n_queries=300 + args.n_track)),
+    }
+
+
 def main():
     args = parse_args()
     if not torch.cuda.is_available():
@@ -239,8 +262,16 @@ def main():
     if args.workload == "msda":
         result = run_msda(args, rank, world)
     elif args.workload == "train":
-        from memotr_amd.train_bench import run_train  # lands with the model path
+        from memotr_amd.train_bench import run_train
         result = run_train(args, rank, world)
+        if rank == 0:   # the kernel roofline and the CPU fallback baseline ride along on rank 0
+            k = run_msda_kernels_only(args)
+            result["roofline"] = k["roofline"]
+            result["kernels"] = k["kernels"]
+            if world == 1 and not args.no_cpu_baseline:
+                result["cpu_baseline"] = k["cpu_baseline_fn"]()
+                result["cpu_baseline"]["sample"] += ("; covers the MSDeformAttn calls of a frame only -- the "
+                                                     "reference has no CPU path for the rest of the model")
     else:
         raise SystemExit(f"unknown workload {args.workload}")
     if rank == 0:

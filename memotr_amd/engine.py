@@ -1,0 +1,96 @@
+"""The clip train step of the reference's train_engine.py:183-246, as a reusable function.
+
+``clip_forward_backward`` is the body of ``train_one_epoch`` for one batch: empty tracks -> T sequential
+``model(frame, tracks)`` calls with the criterion and the query updater between frames -> one backward.
+``get_param_groups`` reproduces the four AdamW groups of train_engine.py:291-336.  Synthetic clips
+(BASELINE.json: random frames, persistent ground-truth identities with a small per-frame drift) stand in
+for the data pipeline, which is out of scope.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Tuple
+
+import torch
+import torch.nn as nn
+
+from .models.utils import get_model
+from .structures.track_instances import TrackInstances
+from .utils.nested_tensor import tensor_list_to_nested_tensor
+
+
+def get_param_groups(config: dict, model: nn.Module) -> Tuple[List[Dict], List[str]]:
+    def has(name, keys):
+        return any(k in name for k in keys)
+
+    backbone, points, updater = ["backbone.backbone"], ["reference_points", "sampling_offsets"], ["query_updater"]
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    groups = [
+        {"params": [p for n, p in named if has(n, backbone)], "lr": config["LR_BACKBONE"]},
+        {"params": [p for n, p in named if has(n, points)], "lr": config["LR_POINTS"]},
+        {"params": [p for n, p in named if has(n, updater)], "lr": config["LR"]},
+        {"params": [p for n, p in named if not has(n, backbone) and not has(n, points) and not has(n, updater)],
+         "lr": config["LR"]},
+    ]
+    return groups, ["lr_backbone", "lr_points", "lr_query_updater", "lr"]
+
+
+def build_optimizer(config: dict, model: nn.Module) -> torch.optim.Optimizer:
+    groups, _ = get_param_groups(config, model)
+    return torch.optim.AdamW(params=groups, lr=config["LR"], weight_decay=config["WEIGHT_DECAY"])
+
+
+def make_synthetic_clip(clip_len: int, height: int, width: int, n_gts: int, seed: int, batch_size: int = 1,
+                        num_classes: int = 1) -> dict:
+    """{"imgs": [B][T] (3,H,W) tensors, "infos": [B][T] {"ids","labels","boxes"}} -- the collate format of the
+    reference (data/utils.py:7-12); boxes are normalised cxcywh, identities persist over the clip."""
+    g = torch.Generator().manual_seed(seed)
+    imgs, infos = [], []
+    for _ in range(batch_size):
+        centre = torch.rand(n_gts, 2, generator=g) * 0.6 + 0.2
+        size = torch.rand(n_gts, 2, generator=g) * 0.15 + 0.05
+        labels = torch.randint(0, num_classes, (n_gts,), generator=g)
+        clip_imgs, clip_infos = [], []
+        for _t in range(clip_len):
+            clip_imgs.append(torch.randn(3, height, width, generator=g))
+            centre = (centre + torch.randn(n_gts, 2, generator=g) * 0.01).clamp(0.1, 0.9)
+            clip_infos.append({"ids": torch.arange(n_gts), "labels": labels.clone(),
+                               "boxes": torch.cat((centre, size), -1)})
+        imgs.append(clip_imgs)
+        infos.append(clip_infos)
+    return {"imgs": imgs, "infos": infos}
+
+
+def clip_to_device(batch: dict, device) -> dict:
+    """Pre-stage a clip in HBM (the bench measures with inputs resident)."""
+    return {"imgs": [[f.to(device) for f in clip] for clip in batch["imgs"]],
+            "infos": [[{k: v.to(device) for k, v in info.items()} for info in clip] for clip in batch["infos"]]}
+
+
+def clip_forward_backward(model: nn.Module, criterion, batch: dict, device, use_dab: bool = True,
+                          accumulation_steps: int = 1, backward: bool = True):
+    """One clip through model + criterion (+ backward).  Returns (loss tensor, loss_dict)."""
+    core = get_model(model)
+    tracks = TrackInstances.init_tracks(batch=batch, hidden_dim=core.hidden_dim, num_classes=core.num_classes,
+                                        device=device, use_dab=use_dab)
+    criterion.init_a_clip(batch=batch, hidden_dim=core.hidden_dim, num_classes=core.num_classes, device=device)
+    clip_len = len(batch["imgs"][0])
+    for frame_idx in range(clip_len):
+        frame = tensor_list_to_nested_tensor([clip[frame_idx] for clip in batch["imgs"]]).to(device)
+        res = model(frame=frame, tracks=tracks)
+        previous, new, unmatched = criterion.process_single_frame(model_outputs=res, tracked_instances=tracks,
+                                                                  frame_idx=frame_idx)
+        if frame_idx < clip_len - 1:
+            tracks = core.postprocess_single_frame(previous, new, unmatched)
+    loss_dict, _ = criterion.get_mean_by_n_gts()
+    loss = criterion.get_sum_loss_dict(loss_dict=loss_dict)
+    if backward:
+        (loss / accumulation_steps).backward()
+    return loss, loss_dict
+
+
+def optimizer_step(model: nn.Module, optimizer: torch.optim.Optimizer, max_norm: float):
+    """clip_grad_norm_ with the reference's hard-coded 0.1 whenever clipping is on (train_engine.py:241-246)."""
+    if max_norm > 0:
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 0.1)
+    optimizer.step()
+    optimizer.zero_grad()

@@ -1,0 +1,149 @@
+"""Deformable decoder with DAB anchors, iterative box refinement and the detect/track split of the
+first layers (reference models/deformable_decoder.py:22-319)."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+from torch.utils.checkpoint import checkpoint
+
+from ..modules import MSDeformAttn
+from ..utils.utils import inverse_sigmoid
+from .mlp import MLP
+from .utils import get_activation_layer, get_clones, pos_to_pos_embed
+
+
+class DeformableDecoder(nn.Module):
+    def __init__(self, decoder_layer, num_layers, return_intermediate=False, merge_det_track_layer: int = 0,
+                 n_det_queries: int = 300, d_model: int = 256, use_checkpoint: bool = False, use_dab: bool = False,
+                 visualize: bool = False):
+        super().__init__()
+        self.layers = get_clones(module=decoder_layer, n=num_layers)
+        self.num_layers = num_layers
+        self.return_intermediate = return_intermediate
+        self.merge_det_track_layer = merge_det_track_layer
+        self.n_det_queries = n_det_queries
+        self.d_model = d_model
+        self.bbox_embed = None      # set by MeMOTR (shared with its box heads)
+        self.class_embed = None
+        self.use_checkpoint = use_checkpoint
+        self.use_dab = use_dab
+        self.visualize = visualize
+        if self.use_dab:
+            self.query_scale = MLP(d_model, d_model, d_model, 2)
+            self.ref_point_head = MLP(d_model * 2, d_model, d_model, 2)
+
+    def forward(self, tgt, reference_points, src, src_spatial_shapes, src_level_start_index, src_valid_ratios,
+                query_pos, query_mask, src_padding_mask):
+        """tgt (B,Nq,C); reference_points (B,Nq,4) in [0,1]; src (B,S,C).
+        Returns stacks over layers: outputs (n,B,Nq,C), refined references (n,B,Nq,4), layer inputs (n,B,Nq,C)."""
+        if not self.return_intermediate:
+            raise NotImplementedError("Not Support for no Inter Outputs.")
+        nd = self.n_det_queries
+        output = tgt
+        outs, refs, layer_inputs = [], [], []
+        ref_backup = None
+        for lid, layer in enumerate(self.layers):
+            if lid == 0 and not self.use_dab:        # Deformable-DETR variant: 2-d references
+                ref_backup = reference_points.clone()
+                reference_points = reference_points[:, :, :2]
+            if reference_points.shape[-1] == 4:
+                ref_in = reference_points[:, :, None] * torch.cat([src_valid_ratios, src_valid_ratios], -1)[:, None]
+            else:
+                assert reference_points.shape[-1] == 2
+                ref_in = reference_points[:, :, None] * src_valid_ratios[:, None]
+            if self.use_dab:
+                anchor = pos_to_pos_embed(ref_in[:, :, 0, :], num_pos_feats=self.d_model // 2)
+                raw_pos = self.ref_point_head(anchor)
+                query_pos = raw_pos if lid == 0 else self.query_scale(output) * raw_pos
+            layer_inputs.append(output)
+            merge = lid >= self.merge_det_track_layer
+            if self.use_checkpoint:
+                output = checkpoint(layer, output, query_pos, ref_in, src, src_spatial_shapes, src_level_start_index,
+                                    query_mask, src_padding_mask, merge, use_reentrant=False)
+            else:
+                output = layer(output, query_pos, ref_in, src, src_spatial_shapes, src_level_start_index, query_mask,
+                               src_padding_mask, merge)
+            if self.bbox_embed is not None:
+                delta = self.bbox_embed[lid](output)
+                if reference_points.shape[-1] == 4:
+                    new_ref = (delta + inverse_sigmoid(reference_points)).sigmoid()
+                else:
+                    xy = delta[..., :2] + inverse_sigmoid(reference_points)
+                    new_ref = torch.cat((xy, delta[..., 2:]), -1).sigmoid()
+                if not merge:   # track queries did not go through the layer: keep their anchors
+                    keep = reference_points if self.use_dab else ref_backup
+                    reference_points = torch.cat((new_ref[:, :nd].detach(), keep[:, nd:]), dim=1)
+                else:
+                    reference_points = new_ref.detach()
+            outs.append(output)
+            refs.append(reference_points)
+        return torch.stack(outs), torch.stack(refs), torch.stack(layer_inputs)
+
+
+class DeformableDecoderLayer(nn.Module):
+    def __init__(self, d_model=256, d_ffn=1024, dropout=0.1, activation="ReLU", n_levels=4, n_heads=8, n_points=4,
+                 sigmoid_attn=False, extra_track_attn=False, n_det_queries=300, visualize: bool = False):
+        super().__init__()
+        self.visualize = visualize
+        self.n_det_queries = n_det_queries
+        self.n_heads = n_heads
+        self.self_attn = nn.MultiheadAttention(embed_dim=d_model, num_heads=n_heads, dropout=dropout,
+                                               batch_first=True)
+        self.dropout2 = nn.Dropout(dropout)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.cross_attn = MSDeformAttn(d_model=d_model, n_levels=n_levels, n_heads=n_heads, n_points=n_points,
+                                       sigmoid_attn=sigmoid_attn, visualize=visualize)
+        self.dropout1 = nn.Dropout(dropout)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.activation = get_activation_layer(activation=activation)
+        self.dropout3 = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.dropout4 = nn.Dropout(dropout)
+        self.norm3 = nn.LayerNorm(d_model)
+        self.extra_track_attn = extra_track_attn
+        if extra_track_attn:
+            self.track_attn = nn.MultiheadAttention(embed_dim=d_model, num_heads=n_heads, dropout=dropout,
+                                                    batch_first=True)
+            self.dropout5 = nn.Dropout(dropout)
+            self.norm4 = nn.LayerNorm(d_model)
+
+    @staticmethod
+    def with_pos_embed(tensor, pos):
+        return tensor if pos is None else tensor + pos
+
+    def forward_self_attn(self, tgt, query_pos, query_mask):
+        qk = self.with_pos_embed(tgt, query_pos)
+        attn, _ = self.self_attn(qk, qk, tgt, key_padding_mask=query_mask, need_weights=False)
+        return self.norm2(tgt + self.dropout2(attn))
+
+    def forward_track_attn(self, tgt, query_pos, query_mask):
+        nd = self.n_det_queries
+        if tgt.shape[1] <= nd:
+            return tgt
+        qk = self.with_pos_embed(tgt, query_pos)[:, nd:]
+        attn, _ = self.track_attn(qk, qk, tgt[:, nd:], key_padding_mask=query_mask[:, nd:], need_weights=False)
+        return torch.cat([tgt[:, :nd], self.norm4(tgt[:, nd:] + self.dropout5(attn))], dim=1)
+
+    def forward_ffn(self, tgt):
+        hidden = self.dropout3(self.activation(self.linear1(tgt)))
+        return self.norm3(tgt + self.dropout4(self.linear2(hidden)))
+
+    def forward(self, tgt, query_pos, reference_points, src, src_spatial_shapes, level_start_index, query_mask,
+                src_padding_mask=None, merge_det_track=False):
+        nd = self.n_det_queries
+        track_tgt = None
+        if not merge_det_track:   # early layers see the detect queries only
+            track_tgt = tgt[:, nd:, :]
+            tgt, query_pos = tgt[:, :nd, :], query_pos[:, :nd, :]
+            reference_points, query_mask = reference_points[:, :nd], query_mask[:, :nd]
+        if self.extra_track_attn:
+            tgt = self.forward_track_attn(tgt, query_pos, query_mask)
+        tgt = self.forward_self_attn(tgt, query_pos, query_mask)
+        cross = self.cross_attn(self.with_pos_embed(tgt, query_pos), reference_points, src, src_spatial_shapes,
+                                level_start_index, src_padding_mask)
+        tgt = self.norm1(tgt + self.dropout1(cross))
+        tgt = self.forward_ffn(tgt)
+        if track_tgt is not None:
+            tgt = torch.cat((tgt, track_tgt), dim=1)
+        return tgt

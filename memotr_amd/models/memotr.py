@@ -1,0 +1,208 @@
+"""MeMOTR per-frame model (API of the reference's models/memotr.py:28-321).
+
+``forward(frame: NestedTensor, tracks: list[TrackInstances]) -> dict`` and
+``postprocess_single_frame(previous, new, unmatched, no_augment=False)`` are what train_engine.py /
+submit_engine.py call; parameter names are state-dict compatible with the reference.
+Query / reference / mask assembly happens on the device the tracks already live on (the reference builds
+them on the CPU and copies, models/memotr.py:222-278 -- a device->host->device round trip per frame).
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.utils.checkpoint import checkpoint
+
+from ..structures.track_instances import TrackInstances
+from ..utils.nested_tensor import NestedTensor
+from ..utils.utils import inverse_sigmoid
+from .backbone import BackboneWithPE
+from .backbone import build as build_backbone_with_pe
+from .deformable_transformer import DeformableTransformer
+from .deformable_transformer import build as build_deformable_transformer
+from .mlp import MLP
+from .query_updater import build as build_query_updater
+from .utils import get_clones
+
+
+class MeMOTR(nn.Module):
+    def __init__(self, backbone: BackboneWithPE, transformer: DeformableTransformer, query_updater: nn.Module,
+                 num_classes: int, n_det_queries: int, n_feature_levels: int, hidden_dim: int, ffn_dim: int,
+                 dropout: float, aux_loss: bool = True, with_box_refine: bool = True, use_checkpoint: bool = False,
+                 checkpoint_level: int = 2, use_dab: bool = False, visualize: bool = False):
+        super().__init__()
+        self.num_classes = num_classes
+        self.n_det_queries = n_det_queries
+        self.n_feature_levels = n_feature_levels
+        self.hidden_dim = hidden_dim
+        self.ffn_dim = ffn_dim
+        self.dropout = dropout
+        self.aux_loss = aux_loss
+        self.with_box_refine = with_box_refine
+        self.use_checkpoint = use_checkpoint
+        self.checkpoint_level = checkpoint_level
+        self.use_dab = use_dab
+        self.visualize = visualize
+
+        self.backbone = backbone
+        self.transformer = transformer
+        self.query_updater = query_updater
+        self.class_embed = nn.Linear(hidden_dim, num_classes)
+        self.bbox_embed = MLP(hidden_dim, hidden_dim, 4, 3)
+        if use_dab:
+            self.det_anchor = nn.Parameter(torch.randn(n_det_queries, 4))
+            self.det_query_embed = nn.Parameter(torch.randn(n_det_queries, hidden_dim))
+        else:
+            self.det_query_embed = nn.Parameter(torch.randn(n_det_queries, hidden_dim * 2))
+        assert n_feature_levels > 1
+        channels = backbone.n_inter_channels()
+        projs = [nn.Sequential(nn.Conv2d(c, hidden_dim, kernel_size=1), nn.GroupNorm(32, hidden_dim))
+                 for c in channels]
+        projs += [nn.Sequential(nn.Conv2d(channels[-1], hidden_dim, kernel_size=3, stride=2, padding=1),
+                                nn.GroupNorm(32, hidden_dim))
+                  for _ in range(n_feature_levels - backbone.n_inter_layers())]
+        self.feature_projs = nn.ModuleList(projs)
+
+        prior_prob = 0.01
+        self.class_embed.bias.data = torch.ones(num_classes) * (-math.log((1 - prior_prob) / prior_prob))
+        nn.init.constant_(self.bbox_embed.layers[-1].weight.data, 0)
+        nn.init.constant_(self.bbox_embed.layers[-1].bias.data, 0)
+        for proj in self.feature_projs:
+            nn.init.xavier_uniform_(proj[0].weight, gain=1)
+            nn.init.constant_(proj[0].bias, 0)
+        n_dec = transformer.get_n_dec_layers()
+        if with_box_refine:
+            self.class_embed = get_clones(self.class_embed, n_dec)
+            self.bbox_embed = get_clones(self.bbox_embed, n_dec)
+            nn.init.constant_(self.bbox_embed[0].layers[-1].bias.data[2:], -2.0)
+            self.transformer.set_refine_bbox_embed(self.bbox_embed)   # aliased: both names in the state dict
+        else:
+            nn.init.constant_(self.bbox_embed.layers[-1].bias.data[2:], -2.0)
+            self.class_embed = nn.ModuleList([self.class_embed for _ in range(n_dec)])
+            self.bbox_embed = nn.ModuleList([self.bbox_embed for _ in range(n_dec)])
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, frame: NestedTensor, tracks: List[TrackInstances]):
+        if self.use_checkpoint and self.checkpoint_level != 3:
+            features, pos = checkpoint(self.backbone, frame, use_reentrant=False)
+        else:
+            features, pos = self.backbone(frame)
+        pos = list(pos)
+        srcs, masks = [], []
+        for lvl, feat in enumerate(features):
+            src, mask = feat.decompose()
+            srcs.append(self.feature_projs[lvl](src))
+            masks.append(mask)
+        for lvl in range(len(srcs), self.n_feature_levels):   # extra levels: stride-2 conv on the raw last map
+            src = self.feature_projs[lvl](features[-1].tensors if lvl == len(features) else srcs[-1])
+            mask = F.interpolate(frame.masks[None].float(), size=src.shape[-2:])[0].to(torch.bool)
+            pos.append(self.backbone.position_embedding(NestedTensor(src, mask)).to(src.device))
+            srcs.append(src)
+            masks.append(mask)
+
+        device = srcs[0].device
+        reference_points = self.get_reference_points(tracks).to(device)     # (B, Nd+Nt, 4) logit space
+        query_embed = self.get_query_embed(tracks).to(device)               # (B, Nd+Nt, C | 2C)
+        query_mask = self.get_query_mask(tracks).to(device)                 # (B, Nd+Nt) bool
+
+        outputs, init_reference, inter_references, inter_queries = self.transformer(
+            srcs=srcs, masks=masks, pos_embeds=pos, query_embed=query_embed, ref_pts=reference_points,
+            query_mask=query_mask)
+        assert outputs.ndim == 4, \
+            f"Deformable Transformer's outputs should have shape (n_dec_layers, B, Nd+Nq, C, but get n_dim={outputs.ndim}"
+        classes, boxes = [], []
+        for lvl in range(outputs.shape[0]):
+            reference = inverse_sigmoid(init_reference if lvl == 0 else inter_references[lvl - 1])
+            box = self.bbox_embed[lvl](outputs[lvl])
+            if reference.shape[-1] == 4:
+                box = box + reference
+            else:
+                assert reference.shape[-1] == 2, f"Reference should have only 2 coord, but get {reference.shape[-1]}."
+                box = torch.cat((box[..., :2] + reference, box[..., 2:]), -1)
+            classes.append(self.class_embed[lvl](outputs[lvl]))
+            boxes.append(box.sigmoid())
+        classes = torch.stack(classes, dim=0)
+        boxes = torch.stack(boxes, dim=0)
+        res = {
+            "pred_logits": classes[-1],
+            "pred_bboxes": boxes[-1],
+            "last_ref_pts": inverse_sigmoid(inter_references[-2, :, :, :]),
+            "query_mask": query_mask,
+            "det_query_embed": query_embed[0][:self.n_det_queries],
+            "init_ref_pts": inverse_sigmoid(init_reference),
+        }
+        if self.aux_loss:
+            res["aux_outputs"] = self.set_aux_loss(classes, boxes, query_mask, inter_queries)
+        res["outputs"] = outputs[-1]
+        return res
+
+    @torch.jit.unused
+    def set_aux_loss(self, output_classes, output_bboxes, query_mask, queries):
+        return [{"pred_logits": a, "pred_bboxes": b, "query_mask": query_mask, "queries": c}
+                for a, b, c in zip(output_classes[:-1], output_bboxes[:-1], queries[1:])]
+
+    # ------------------------------------------------------------------ query assembly
+    def get_det_reference_points(self) -> torch.Tensor:
+        if self.use_dab:
+            return self.det_anchor
+        return self.transformer.reference_points(self.det_query_embed[:, :self.hidden_dim])
+
+    def _pad_stack(self, parts: List[torch.Tensor], width: int) -> torch.Tensor:
+        """(B, max_len, width) zero-padded stack of per-clip (n_i, width) tensors, on the model's device."""
+        device = self.det_query_embed.device
+        max_len = max(p.shape[0] for p in parts)
+        out = torch.zeros((len(parts), max_len, width), device=device)
+        for i, p in enumerate(parts):
+            if p.shape[0]:
+                out[i, :p.shape[0]] = p.to(device)
+        return out
+
+    def get_track_reference_points(self, tracks: List[TrackInstances]):
+        return self._pad_stack([t.ref_pts for t in tracks], 4)
+
+    def get_track_query_embed(self, tracks: List[TrackInstances]):
+        return self._pad_stack([t.query_embed for t in tracks],
+                               self.hidden_dim if self.use_dab else self.hidden_dim * 2)
+
+    def get_reference_points(self, tracks: List[TrackInstances]):
+        det = self.get_det_reference_points().repeat(len(tracks), 1, 1)
+        if det.shape[-1] == 2:
+            det = torch.cat((det, torch.zeros_like(det)), dim=-1)
+        return torch.cat((det, self.get_track_reference_points(tracks).to(det.device)), dim=1)
+
+    def get_query_embed(self, tracks: List[TrackInstances]):
+        det = self.det_query_embed.repeat(len(tracks), 1, 1)
+        return torch.cat((det, self.get_track_query_embed(tracks).to(det.device)), dim=1)
+
+    def get_query_mask(self, tracks: List[TrackInstances]):
+        """True on padded track slots; a clip with no track at all keeps its padding unmasked (reference :271-274)."""
+        lens = [len(t.query_embed) for t in tracks]
+        max_len = max(lens)
+        device = self.det_query_embed.device
+        mask = torch.zeros((len(tracks), self.n_det_queries + max_len), dtype=torch.bool, device=device)
+        for i, n in enumerate(lens):
+            if n > 0:
+                mask[i, self.n_det_queries + n:] = True
+        return mask
+
+    def postprocess_single_frame(self, previous_tracks: List[TrackInstances], new_tracks: List[TrackInstances],
+                                 unmatched_dets: Optional[List[TrackInstances]], no_augment: bool = False):
+        """Query updating between frames."""
+        return self.query_updater(previous_tracks, new_tracks, unmatched_dets, no_augment)
+
+
+DATASET_NUM_CLASSES = {"DanceTrack": 1, "SportsMOT": 1, "MOT17": 1, "MOT17_SPLIT": 1, "BDD100K": 8}
+
+
+def build(config: dict) -> MeMOTR:
+    assert config["DATASET"] in DATASET_NUM_CLASSES, f"Do not know the class num of {config['DATASET']} dataset."
+    return MeMOTR(
+        backbone=build_backbone_with_pe(config), transformer=build_deformable_transformer(config),
+        query_updater=build_query_updater(config), num_classes=DATASET_NUM_CLASSES[config["DATASET"]],
+        n_det_queries=config["NUM_DET_QUERIES"], n_feature_levels=config["NUM_FEATURE_LEVELS"],
+        hidden_dim=config["HIDDEN_DIM"], ffn_dim=config["FFN_DIM"], dropout=config["DROPOUT"], aux_loss=True,
+        with_box_refine=True, use_checkpoint=config["USE_CHECKPOINT"], checkpoint_level=config["CHECKPOINT_LEVEL"],
+        use_dab=config["USE_DAB"], visualize=config["VISUALIZE"])

@@ -1,0 +1,167 @@
+"""Long-term-memory query updater (reference models/query_updater.py:18-271).
+
+Between frames: pick the tracks that stay alive, then rewrite their query embeddings from the
+short-term memory (last output), the long-term memory (EMA of outputs) and one memory-attention layer.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from ..structures.track_instances import TrackInstances
+from ..utils.box_ops import box_cxcywh_to_xyxy, box_iou_union
+from ..utils.utils import inverse_sigmoid
+from .ffn import FFN
+from .mlp import MLP
+from .utils import logits_to_scores, pos_to_pos_embed
+
+
+class QueryUpdater(nn.Module):
+    def __init__(self, hidden_dim: int, ffn_dim: int, tp_drop_ratio: float, fp_insert_ratio: float, dropout: float,
+                 use_checkpoint: bool, use_dab: bool, update_threshold: float, long_memory_lambda: float,
+                 visualize: bool = False):
+        super().__init__()
+        self.hidden_dim = hidden_dim
+        self.ffn_dim = ffn_dim
+        self.tp_drop_ratio = tp_drop_ratio
+        self.fp_insert_ratio = fp_insert_ratio
+        self.dropout = dropout
+        self.use_checkpoint = use_checkpoint
+        self.use_dab = use_dab
+        self.visualize = visualize
+        self.update_threshold = update_threshold
+        self.long_memory_lambda = long_memory_lambda
+
+        self.confidence_weight_net = nn.Sequential(MLP(hidden_dim, hidden_dim, hidden_dim, 2), nn.Sigmoid())
+        self.short_memory_fusion = MLP(2 * hidden_dim, 2 * hidden_dim, hidden_dim, 2)
+        self.memory_attn = nn.MultiheadAttention(embed_dim=hidden_dim, num_heads=8, batch_first=True)
+        self.memory_dropout = nn.Dropout(dropout)
+        self.memory_norm = nn.LayerNorm(hidden_dim)
+        self.memory_ffn = FFN(d_model=hidden_dim, d_ffn=ffn_dim, dropout=dropout)
+        self.query_feat_dropout = nn.Dropout(dropout)
+        self.query_feat_norm = nn.LayerNorm(hidden_dim)
+        self.query_feat_ffn = FFN(d_model=hidden_dim, d_ffn=ffn_dim, dropout=dropout)
+        self.query_pos_head = MLP(hidden_dim * 2, hidden_dim, hidden_dim, 2)
+        if not self.use_dab:     # Deformable-DETR variant also refreshes the positional half
+            self.linear_pos1 = nn.Linear(256, 256)
+            self.linear_pos2 = nn.Linear(256, 256)
+            self.norm_pos = nn.LayerNorm(256)
+            self.activation = nn.ReLU(inplace=True)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def forward(self, previous_tracks: List[TrackInstances], new_tracks: List[TrackInstances],
+                unmatched_dets: Optional[List[TrackInstances]], no_augment: bool = False):
+        tracks = self.select_active_tracks(previous_tracks, new_tracks, unmatched_dets, no_augment=no_augment)
+        return self.update_tracks_embedding(tracks)
+
+    # ------------------------------------------------------------------ embedding update
+    def update_tracks_embedding(self, tracks: List[TrackInstances]):
+        C = self.hidden_dim
+        lam = self.long_memory_lambda
+        for t in tracks:
+            scores = torch.max(logits_to_scores(t.logits), dim=1).values
+            is_pos = scores > self.update_threshold
+            pos_col = is_pos.reshape(-1, 1)
+            t.ref_pts[is_pos] = inverse_sigmoid(t[is_pos].boxes.detach().clone())
+
+            query_pos = self.query_pos_head(pos_to_pos_embed(t.ref_pts.sigmoid(), num_pos_feats=C // 2))
+            out_embed = t.output_embed
+            long_memory = t.long_memory.detach()
+
+            confidence = self.confidence_weight_net(out_embed)
+            short_memory = self.short_memory_fusion(torch.cat((confidence * out_embed, t.last_output), dim=-1))
+
+            q = (short_memory + query_pos)[None]
+            k = (long_memory + query_pos)[None]
+            attn = self.memory_attn(q, k, out_embed[None], need_weights=False)[0][0]
+            tgt = self.memory_ffn(self.memory_norm(out_embed + self.memory_dropout(attn)))
+            query_feat = self.query_feat_ffn(self.query_feat_norm(long_memory + self.query_feat_dropout(tgt)))
+
+            new_long = (1 - lam) * long_memory + lam * out_embed
+            t.long_memory = t.long_memory * ~pos_col + new_long * pos_col
+            t.last_output = t.last_output * ~pos_col + out_embed * pos_col
+
+            if self.use_dab:
+                t.query_embed[is_pos] = query_feat[is_pos]
+            else:
+                t.query_embed[:, C:][is_pos] = query_feat[is_pos]
+                refreshed = self.norm_pos(t.query_embed[:, :C]
+                                          + self.linear_pos2(self.activation(self.linear_pos1(out_embed))))
+                t.query_embed[:, :C][is_pos] = refreshed[is_pos]
+        return tracks
+
+    # ------------------------------------------------------------------ track selection
+    def _seed_memories(self, t: TrackInstances):
+        t.last_output = t.output_embed
+        t.long_memory = t.query_embed if self.use_dab else t.query_embed[:, self.hidden_dim:]
+
+    def _fake_track(self, n_logits: int) -> TrackInstances:
+        """One random track with id -2: keeps every parameter of this module in the autograd graph when a
+        clip has no active track (DDP runs with find_unused_parameters=False)."""
+        device = next(self.query_feat_ffn.parameters()).device
+        C = self.hidden_dim
+        f = TrackInstances(frame_height=1.0, frame_width=1.0, hidden_dim=C).to(device=device)
+        rn = lambda *s: torch.randn(s, dtype=torch.float, device=device)  # noqa: E731
+        f.query_embed = rn(1, C if self.use_dab else 2 * C)
+        f.output_embed = rn(1, C)
+        f.ref_pts = rn(1, 4)
+        f.ids = torch.as_tensor([-2], dtype=torch.long, device=device)
+        f.matched_idx = torch.as_tensor([-2], dtype=torch.long, device=device)
+        f.boxes = rn(1, 4)
+        f.logits = rn(1, n_logits)
+        f.iou = torch.zeros((1,), dtype=torch.float, device=device)
+        f.last_output = rn(1, C)
+        f.long_memory = rn(1, C)
+        return f
+
+    def select_active_tracks(self, previous_tracks, new_tracks, unmatched_dets, no_augment: bool = False):
+        cat = TrackInstances.cat_tracked_instances
+        if not self.training:
+            assert len(previous_tracks) == 1 and len(new_tracks) == 1     # eval runs one sequence at a time
+            self._seed_memories(new_tracks[0])
+            active = cat(previous_tracks[0], new_tracks[0])
+            return [active[active.ids >= 0]]
+        tracks = []
+        for b in range(len(new_tracks)):
+            self._seed_memories(new_tracks[b])
+            self._seed_memories(unmatched_dets[b])
+            if self.tp_drop_ratio == 0.0 and self.fp_insert_ratio == 0.0:
+                active = cat(cat(previous_tracks[b], new_tracks[b]), unmatched_dets[b])
+                scores = torch.max(logits_to_scores(active.logits), dim=1).values
+                active = active[(scores > self.update_threshold) | (active.ids >= 0)]
+                active.ids[active.iou < 0.5] = -1
+            else:
+                active = cat(previous_tracks[b], new_tracks[b])
+                active = active[(active.iou > 0.5) & (active.ids >= 0)]
+                if self.tp_drop_ratio > 0.0 and not no_augment and len(active) > 0:
+                    active = active[torch.rand((len(active),)) > self.tp_drop_ratio]
+                if self.fp_insert_ratio > 0.0 and not no_augment:
+                    picked = active[torch.bernoulli(torch.ones((len(active),)) * self.fp_insert_ratio).bool()]
+                    if len(unmatched_dets[b]) > 0 and len(picked) > 0:
+                        if len(picked) >= len(unmatched_dets[b]):
+                            fp = unmatched_dets[b]
+                        else:       # the unmatched detection overlapping each picked track the most
+                            iou, _ = box_iou_union(box_cxcywh_to_xyxy(unmatched_dets[b].boxes),
+                                                   box_cxcywh_to_xyxy(picked.boxes))
+                            fp = unmatched_dets[b][torch.unique(torch.max(iou, dim=0).indices)]
+                        active = cat(active, fp)
+            if len(active) == 0:
+                active = self._fake_track(active.logits.shape[1])
+            tracks.append(active)
+        return tracks
+
+
+def build(config: dict) -> QueryUpdater:
+    return QueryUpdater(
+        hidden_dim=config["HIDDEN_DIM"], ffn_dim=config["FFN_DIM"], dropout=config["DROPOUT"],
+        tp_drop_ratio=config.get("TP_DROP_RATE", 0.0), fp_insert_ratio=config.get("FP_INSERT_RATE", 0.0),
+        use_checkpoint=config["USE_CHECKPOINT"], use_dab=config["USE_DAB"],
+        update_threshold=config["UPDATE_THRESH"], long_memory_lambda=config["LONG_MEMORY_LAMBDA"],
+        visualize=config["VISUALIZE"])

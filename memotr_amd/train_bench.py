@@ -1,0 +1,75 @@
+"""bench.py --workload train: one clip train step of train_dancetrack.yaml per "step".
+
+Step = the body of the reference's train loop (train_engine.py:183-246) on a synthetic clip resident in
+HBM: T sequential frames through ResNet-50 -> deformable encoder/decoder (HIP MSDeformAttn) -> criterion
+-> query updater, one backward, RCCL gradient all-reduce (DDP), clip-grad, AdamW.  Random-init weights,
+random 800x1333 frames, persistent ground-truth identities.  value = frames/s over all ranks.
+"""
+from __future__ import annotations
+
+import os
+import time
+
+import torch
+
+
+def run_train(args, rank: int, world: int, clip_len: int = None, height: int = 800, width: int = 1333,
+              n_gts: int = 10, config: dict = None):
+    from .configs import dancetrack_config
+    from .engine import build_optimizer, clip_forward_backward, clip_to_device, make_synthetic_clip, optimizer_step
+    from .models import build_model
+    from .models.criterion import build as build_criterion
+    from .utils.utils import set_seed
+
+    clip_len = clip_len or int(os.environ.get("MEMOTR_BENCH_CLIP_LEN", "5"))
+    cfg = config or dancetrack_config()
+    torch.backends.cuda.matmul.allow_tf32 = False     # main.py:96-97 of the reference: strict fp32
+    torch.backends.cudnn.allow_tf32 = False
+    dev = torch.device("cuda", torch.cuda.current_device())
+    set_seed(cfg["SEED"])
+    cfg = dict(cfg, DEVICE="cuda", AVAILABLE_GPUS="0")
+    model = build_model(cfg).to(dev)
+    model.train()
+    criterion = build_criterion(cfg)
+    optimizer = build_optimizer(cfg, model)
+    if world > 1:
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        model = DDP(model, device_ids=[dev.index], find_unused_parameters=False)
+    batch = clip_to_device(make_synthetic_clip(clip_len, height, width, n_gts, seed=cfg["SEED"] + rank), dev)
+
+    def step():
+        loss, _ = clip_forward_backward(model, criterion, batch, dev, use_dab=cfg["USE_DAB"])
+        optimizer_step(model, optimizer, cfg["CLIP_MAX_NORM"])
+        return loss
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    dt = float(t.item())
+    if rank != 0:
+        return None
+    n_params = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    return {
+        "metric": "train_frames_per_sec", "value": world * clip_len * args.steps / dt, "unit": "frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"train_dancetrack.yaml clip step: R50 + 6-enc/6-dec deformable transformer + query "
+                               f"updater, clip length {clip_len}, {height}x{width} frames, bs=1/GPU, {n_gts} GT "
+                               f"tracks, AdamW, grad-clip 0.1, random-init weights",
+                   "parallelism": f"dp{world}", "trainable_params": n_params,
+                   "frames_per_gpu_per_sec": clip_len * args.steps / dt, "final_loss": float(loss)},
+        "max_memory_MB": torch.cuda.max_memory_allocated() // (1024 ** 2),
+    }

@@ -1,0 +1,104 @@
+"""CPU: the from-definition ResNet-50 / frozen-BN backbone and the full-size model assembly.
+
+The ResNet-50 arithmetic is torchvision's in the reference (third-party, absent here): parity is UNPINNED for
+the convolution stack; what is pinned is the topology (output shapes/strides, parameter names and
+counts of torchvision's resnet50) and the frozen-BN formula of models/backbone.py:42-52.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from model_helpers import small_config
+
+
+def test_frozen_bn_formula_and_conv_folding():
+    from memotr_amd.models.backbone import FrozenBatchNorm2d
+    torch.manual_seed(0)
+    bn = FrozenBatchNorm2d(6)
+    bn.weight.copy_(torch.rand(6) + 0.5)
+    bn.bias.copy_(torch.randn(6))
+    bn.running_mean.copy_(torch.randn(6))
+    bn.running_var.copy_(torch.rand(6) + 0.1)
+    x = torch.randn(2, 6, 5, 7)
+    want = (x - bn.running_mean.view(1, -1, 1, 1)) / torch.sqrt(bn.running_var.view(1, -1, 1, 1) + 1e-5) \
+        * bn.weight.view(1, -1, 1, 1) + bn.bias.view(1, -1, 1, 1)
+    np.testing.assert_allclose(bn(x).numpy(), want.numpy(), rtol=1e-5, atol=1e-6)
+    conv = torch.nn.Conv2d(3, 6, 3, padding=1, bias=False)
+    inp = torch.randn(2, 3, 5, 7)
+    w, b = bn.fold_into_conv(conv.weight)
+    np.testing.assert_allclose(F.conv2d(inp, w, b, padding=1).detach().numpy(), bn(conv(inp)).detach().numpy(),
+                               rtol=1e-4, atol=1e-5)
+    assert "num_batches_tracked" not in bn.state_dict()
+    sd = bn.state_dict()
+    sd["num_batches_tracked"] = torch.tensor(3)
+    bn.load_state_dict(sd)          # torchvision checkpoints carry the key; it is dropped on load
+
+
+def test_resnet50_topology_matches_torchvision_layout():
+    from memotr_amd.models.backbone import Backbone
+    from memotr_amd.utils.nested_tensor import tensor_list_to_nested_tensor
+    bb = Backbone("resnet50", train_backbone=True, return_interm_layers=True)
+    n_conv = sum(p.numel() for n, p in bb.named_parameters())
+    assert n_conv == 23_454_912                                       # resnet50 convs (no fc, BN are buffers)
+    trainable = sum(p.numel() for p in bb.parameters() if p.requires_grad)
+    assert trainable == 23_454_912 - 9_408 - 212_992                  # conv1 + layer1 frozen (backbone.py:72-74)
+    names = set(bb.state_dict())
+    for k in ("backbone.conv1.weight", "backbone.bn1.running_var", "backbone.layer1.0.downsample.0.weight",
+              "backbone.layer1.0.downsample.1.bias", "backbone.layer2.3.conv3.weight", "backbone.layer3.5.bn2.weight",
+              "backbone.layer4.2.conv2.weight"):
+        assert k in names, k
+    assert bb.backbone.layer2[0].conv2.stride == (2, 2) and bb.backbone.layer2[0].conv1.stride == (1, 1)  # v1.5
+    nt = tensor_list_to_nested_tensor([torch.randn(3, 70, 100)])      # padded to 96 x 128
+    with torch.no_grad():
+        out = bb(nt)
+    assert [tuple(out[k].tensors.shape) for k in ("0", "1", "2")] == [(1, 512, 12, 16), (1, 1024, 6, 8),
+                                                                      (1, 2048, 3, 4)]
+    assert out["0"].masks.shape == (1, 12, 16) and out["0"].masks[0, :8, :12].sum() == 0 and out["0"].masks[0, 9:].all()
+
+
+def test_full_size_model_names_and_counts():
+    """26.902 M non-backbone parameters, aliased box heads, DanceTrack config."""
+    from memotr_amd.models import build_model
+    cfg = small_config()
+    cfg.update(HIDDEN_DIM=256, FFN_DIM=2048, NUM_ENC_LAYERS=6, NUM_DEC_LAYERS=6, NUM_DET_QUERIES=300)
+    model = build_model(cfg)
+    non_backbone = sum(p.numel() for n, p in model.named_parameters() if not n.startswith("backbone."))
+    assert non_backbone == 26_902_025 or abs(non_backbone - 26_902_000) < 1_000, non_backbone
+    sd = model.state_dict()
+    for k, shape in {
+        "det_anchor": (300, 4), "det_query_embed": (300, 256), "transformer.level_embed": (4, 256),
+        "transformer.encoder.layers.5.self_attn.sampling_offsets.weight": (256, 256),
+        "transformer.decoder.layers.0.self_attn.in_proj_weight": (768, 256),
+        "transformer.decoder.layers.3.cross_attn.attention_weights.bias": (128,),
+        "transformer.decoder.query_scale.layers.1.weight": (256, 256),
+        "transformer.decoder.ref_point_head.layers.0.weight": (256, 512),
+        "transformer.decoder.bbox_embed.5.layers.2.weight": (4, 256),
+        "query_updater.short_memory_fusion.layers.0.weight": (512, 512),
+        "query_updater.memory_attn.in_proj_weight": (768, 256),
+        "query_updater.query_feat_ffn.linear1.weight": (2048, 256),
+        "class_embed.5.weight": (1, 256), "bbox_embed.0.layers.2.bias": (4,),
+        "feature_projs.3.0.weight": (256, 2048, 3, 3), "feature_projs.0.1.weight": (256,),
+        "backbone.backbone.backbone.layer4.2.conv3.weight": (2048, 512, 1, 1),
+    }.items():
+        assert tuple(sd[k].shape) == shape, k
+    assert sd["bbox_embed.2.layers.0.weight"].data_ptr() == sd["transformer.decoder.bbox_embed.2.layers.0.weight"].data_ptr()
+    assert float(sd["class_embed.0.bias"][0]) == pytest.approx(-4.59512, abs=1e-4)     # -log(99)
+    assert torch.equal(sd["bbox_embed.0.layers.2.bias"], torch.tensor([0.0, 0.0, -2.0, -2.0]))
+    assert model.hidden_dim == 256 and model.num_classes == 1
+
+
+def test_pretrained_key_remap():
+    from memotr_amd.models.utils import remap_pretrained_state_dict
+    model_state = {"det_query_embed": torch.zeros(300, 256), "det_anchor": torch.zeros(300, 4),
+                   "class_embed.0.weight": torch.zeros(1, 256), "feature_projs.0.0.weight": torch.zeros(2),
+                   "backbone.backbone.backbone.conv1.weight": torch.zeros(3), "fresh": torch.ones(1)}
+    pre = {"tgt_embed.weight": torch.ones(300, 256), "refpoint_embed.weight": torch.ones(300, 4),
+           "class_embed.0.weight": torch.arange(91 * 256.).view(91, 256), "input_proj.0.0.weight": torch.ones(2),
+           "backbone.0.body.conv1.weight": torch.ones(3)}
+    out = remap_pretrained_state_dict(pre, model_state)
+    assert torch.equal(out["det_query_embed"], torch.ones(300, 256)) and torch.equal(out["det_anchor"], torch.ones(300, 4))
+    assert torch.equal(out["class_embed.0.weight"], pre["class_embed.0.weight"][1:2])
+    assert torch.equal(out["feature_projs.0.0.weight"], torch.ones(2))
+    assert torch.equal(out["backbone.backbone.backbone.conv1.weight"], torch.ones(3))
+    assert "tgt_embed.weight" not in out and torch.equal(out["fresh"], torch.ones(1))

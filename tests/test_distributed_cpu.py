@@ -1,0 +1,79 @@
+"""CPU, world_size 2, gloo: the data-parallel path of the clip train step.
+
+Clips shard by rank (no data-path collective); the only exchanges are DDP's gradient all-reduce and the
+criterion's ground-truth-count all-reduce (reference criterion.py:122-124).  Checked here: both ranks end a
+step with identical parameters, the normalisation uses the world-average count, and T forwards per backward
+work under DistributedDataParallel(find_unused_parameters=False) like the reference's train_engine.py:90.
+"""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    import memotr_amd.modules.ms_deform_attn as mod
+    from model_helpers import OracleMSDeformAttnFunction, TinyBackbone, small_config
+    from memotr_amd.engine import build_optimizer, clip_forward_backward, make_synthetic_clip, optimizer_step
+    from memotr_amd.models.backbone import BackboneWithPE
+    from memotr_amd.models.criterion import build as build_criterion
+    from memotr_amd.models.deformable_transformer import build as build_tr
+    from memotr_amd.models.memotr import MeMOTR
+    from memotr_amd.models.position_embedding import build as build_pe
+    from memotr_amd.models.query_updater import build as build_qu
+    mod.MSDeformAttnFunction = OracleMSDeformAttnFunction       # CPU stand-in for the HIP operator (tests only)
+    cfg = small_config()
+    cfg.update(MATCH_COST_CLASS=2, MATCH_COST_BBOX=5, MATCH_COST_GIOU=2, LOSS_WEIGHT_FOCAL=2, LOSS_WEIGHT_L1=5,
+               LOSS_WEIGHT_GIOU=2, AUX_LOSS_WEIGHT=[1.0], SAMPLE_LENGTHS=[2, 3], LR=2e-4, LR_BACKBONE=2e-5,
+               LR_POINTS=1e-5, WEIGHT_DECAY=5e-4, CLIP_MAX_NORM=0.1)
+    torch.manual_seed(100 + rank)           # different init per rank: DDP must broadcast rank 0's weights
+    model = MeMOTR(backbone=BackboneWithPE(TinyBackbone(), build_pe(cfg)), transformer=build_tr(cfg),
+                   query_updater=build_qu(cfg), num_classes=1, n_det_queries=20, n_feature_levels=4, hidden_dim=64,
+                   ffn_dim=128, dropout=0.0, use_dab=True).train()
+    with torch.no_grad():
+        for ce in model.class_embed:
+            ce.bias.zero_()
+    ddp = torch.nn.parallel.DistributedDataParallel(model, find_unused_parameters=False)
+    criterion = build_criterion(cfg)
+    opt = build_optimizer(cfg, ddp)
+    n_gts = 4 + 2 * rank                     # ranks see different ground-truth counts
+    batch = make_synthetic_clip(clip_len=2, height=96, width=128, n_gts=n_gts, seed=7 + rank)
+    loss, loss_dict = clip_forward_backward(ddp, criterion, batch, torch.device("cpu"))
+    grads_ok = all(p.grad is not None for p in ddp.parameters() if p.requires_grad)
+    optimizer_step(ddp, opt, cfg["CLIP_MAX_NORM"])
+    flat = torch.cat([p.detach().reshape(-1) for p in ddp.parameters()])
+    torch.save({"flat": flat, "loss": float(loss), "grads_ok": grads_ok, "n_gts": criterion.n_gts,
+                "l1_sum": float(criterion.loss["box_l1_loss"]), "l1_mean": float(loss_dict["box_l1_loss"])},
+               f"{out_path}.{rank}")
+    dist.destroy_process_group()
+
+
+def test_two_rank_clip_step_keeps_replicas_in_sync(tmp_path):
+    world, port = 2, _free_port()
+    out = str(tmp_path / "rank")
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    assert r0["grads_ok"] and r1["grads_ok"]
+    assert torch.equal(r0["flat"], r1["flat"]), "replicas diverged after one step"
+    assert r0["n_gts"] == [4, 4] and r1["n_gts"] == [6, 6]
+    # normaliser = world-average ground-truth count: (8 + 12) / 2 = 10 on both ranks
+    assert r0["l1_mean"] == pytest.approx(r0["l1_sum"] / 10.0, rel=1e-5)
+    assert r1["l1_mean"] == pytest.approx(r1["l1_sum"] / 10.0, rel=1e-5)
+    assert r0["loss"] != r1["loss"]            # different clips per rank
