@@ -70,6 +70,6 @@ def run_train(args, rank: int, world: int, clip_len: int = None, height: int = 8
                                f"updater, clip length {clip_len}, {height}x{width} frames, bs=1/GPU, {n_gts} GT "
                                f"tracks, AdamW, grad-clip 0.1, random-init weights",
                    "parallelism": f"dp{world}", "trainable_params": n_params,
-                   "frames_per_gpu_per_sec": clip_len * args.steps / dt, "final_loss": float(loss)},
+                   "frames_per_gpu_per_sec": clip_len * args.steps / dt, "final_loss": float(loss.detach())},
         "max_memory_MB": torch.cuda.max_memory_allocated() // (1024 ** 2),
     }

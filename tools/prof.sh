@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 passes for the bench workload (run on the GPU box, from the repo root).
-#   tools/prof.sh <tag>     -> gpurun_out/prof_<tag>/{stats,pmc_fetch,pmc_write}/...
+#   tools/prof.sh <tag> [train|msda]  -> gpurun_out/prof_<tag>/{stats,pmc_fetch,pmc_write}/...
 # Kernel-trace/stats and the two PMC passes are separate runs (FETCH_SIZE and WRITE_SIZE do not fit
 # one pass; never combined with sys/hip/hsa tracing).
 set -u
@@ -8,10 +8,11 @@ TAG=${1:-r01}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-CMD="python bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+WORKLOAD=${2:-train}
+CMD="python bench.py --workload $WORKLOAD --steps 3 --warmup 2 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- $CMD > "$OUT/stats.log" 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o fetch -- $CMD > "$OUT/pmc_fetch.log" 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d "$OUT/pmc_write" -o write -- $CMD > "$OUT/pmc_write.log" 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc TCC_HIT_sum TCC_MISS_sum -d "$OUT/pmc_l2" -o l2 -- $CMD > "$OUT/pmc_l2.log" 2>&1
 find "$OUT" -name '*.csv' | head -50
-python tools/prof_summary.py "$OUT" "$TAG"
+python tools/prof_summary.py "$OUT" "$TAG" "$CMD"

@@ -15,10 +15,11 @@ def find(root, suffix):
 
 def main():
     root, tag = sys.argv[1], sys.argv[2]
+    cmd = sys.argv[3] if len(sys.argv) > 3 else "python bench.py"
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out_dir = os.path.join(os.environ.get("PROF_OUT", os.path.join(repo, "gpurun_out", "profiles")))
     os.makedirs(out_dir, exist_ok=True)
-    lines = [f"# rocprofv3 summary ({tag})", "", "command: `python bench.py --steps 3 --warmup 1 --no-cpu-baseline`", ""]
+    lines = [f"# rocprofv3 summary ({tag})", "", f"command: `{cmd}`", ""]
     stats = find(os.path.join(root, "stats"), "kernel_stats.csv")
     summary = {}
     if stats:
@@ -32,6 +33,27 @@ def main():
                 pct = r.get("Percentage", "")
                 lines.append(f"| `{name}` | {calls} | {tot:.3f} | {avg:.2f} | {pct} |")
                 summary[name] = dict(calls=calls, total_ms=tot, avg_us=avg)
+    # MSDeformAttn launches split by grid size (encoder-shape vs decoder-shape calls share a kernel name)
+    trace = find(os.path.join(root, "stats"), "kernel_trace.csv")
+    if trace:
+        groups = defaultdict(list)
+        total_ns = 0.0
+        with open(trace) as f:
+            for r in csv.DictReader(f):
+                dur = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+                total_ns += dur
+                if "msda" in r["Kernel_Name"]:
+                    short = r["Kernel_Name"].split("::")[-1].split("(")[0]
+                    groups[(short, int(r["Grid_Size_X"]), int(r["Workgroup_Size_X"]), int(r["VGPR_Count"]),
+                            int(r["LDS_Block_Size"]))].append(dur)
+        lines += ["", "## MSDeformAttn launches by launch shape", "",
+                  "| kernel | grid (threads) | block | VGPR | LDS B | calls | avg us | min us | total ms |",
+                  "|---|---|---|---|---|---|---|---|---|"]
+        for (k, grid, blk, vg, lds), ds in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
+            lines.append(f"| `{k}` | {grid} | {blk} | {vg} | {lds} | {len(ds)} | {sum(ds)/len(ds)/1e3:.2f} | "
+                         f"{min(ds)/1e3:.2f} | {sum(ds)/1e6:.3f} |")
+            summary[f"{k}@grid{grid}"] = dict(calls=len(ds), avg_us=sum(ds) / len(ds) / 1e3, min_us=min(ds) / 1e3)
+        lines += ["", f"total GPU kernel time in the trace: {total_ns/1e6:.2f} ms"]
     traffic = {}
     for key, sub, ctr in (("fetch", "pmc_fetch", "FETCH_SIZE"), ("write", "pmc_write", "WRITE_SIZE"),
                           ("l2hit", "pmc_l2", "TCC_HIT_sum"), ("l2miss", "pmc_l2", "TCC_MISS_sum")):
