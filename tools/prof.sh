@@ -16,3 +16,6 @@ rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d "$OUT/pmc_write
 rocprofv3 --kernel-trace --output-format csv --pmc TCC_HIT_sum TCC_MISS_sum -d "$OUT/pmc_l2" -o l2 -- $CMD > "$OUT/pmc_l2.log" 2>&1
 find "$OUT" -name '*.csv' | head -50
 python tools/prof_summary.py "$OUT" "$TAG" "$CMD"
+# keep the stats table, drop the per-dispatch traces (tens of MB)
+mkdir -p gpurun_out/profiles && cp "$OUT"/stats/*kernel_stats.csv gpurun_out/profiles/${TAG}_kernel_stats.csv 2>/dev/null
+rm -rf "$OUT"
