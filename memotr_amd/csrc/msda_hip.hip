@@ -945,6 +945,216 @@ __global__ __launch_bounds__(kTileThreads) void msda_bwd_d32_tile(
     }
 }
 
+// ---- backward, fixed-point window accumulation ---------------------------------------------------
+// Same tiling as msda_bwd_d32_tile, but the LDS windows accumulate grad_value as 32-bit fixed point:
+// on gfx950 ds_add_f32 retires ~0.33 lanes/clk/CU while ds_add_u32 retires 5-13 (profiles/r01_ubench_*).
+// Per workgroup: B = max|grad_out| * max|attn| over the region bounds every contribution
+// (|w_corner| <= 1); a window cell receives at most rows*P contributions (one per point of its
+// level), so with scale = 2^e, e = 30 - ceil(log2(rows*P)) - ceil(log2(B)), sums cannot overflow and
+// the quantisation step is B * 2^-(30 - log2(rows*P)) (~2^-21 B for L = P = 4).  The flush converts
+// back (exact power-of-two scaling) and adds into grad_value with float atomics like every other
+// path.  Integer adds commute, so the in-window part of the result is order-independent.
+template <int PTS>
+__global__ __launch_bounds__(kTileThreads) void msda_bwd_d32_tile_q(
+    const float *__restrict__ value, const int64_t *__restrict__ lstart, const float *__restrict__ loc,
+    const float *__restrict__ attn, const float *__restrict__ grad_out, float *__restrict__ grad_value,
+    float *__restrict__ grad_loc, float *__restrict__ grad_attn, const TilePlan pl) {
+    constexpr int D = 32;
+    __shared__ TileTables tb;
+    __shared__ int s_bound[2];   // float bits of max|grad_out|, max|attn|
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    int b, ry, rx, m;
+    bool live;
+    tile_block_coords(pl, b, ry, rx, m, live);
+    if (!live) return;
+    tile_load_tables(tb, pl, lstart);
+    if (threadIdx.x < 2) s_bound[threadIdx.x] = 0;
+    __syncthreads();
+
+    const int LP = pl.L * pl.P;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane >> 3, sub = lane & 7;
+    const __amdgpu_buffer_rsrc_t vr = make_rsrc(value, pl.value_bytes);
+    const __amdgpu_buffer_rsrc_t gr = make_rsrc(grad_value, pl.value_bytes);
+    u32x4 *win_u4 = reinterpret_cast<u32x4 *>(s_dyn);
+    int *win_i = reinterpret_cast<int *>(s_dyn);
+    const int win_px = tb.base[pl.L];
+    const int rec_stride = 3 * LP + 1;
+    u32x4 *rec = reinterpret_cast<u32x4 *>(s_dyn + (size_t)win_px * 128) + (size_t)(wave * 8 + grp) * rec_stride;
+    float *res = reinterpret_cast<float *>(s_dyn + (size_t)win_px * 128 + (size_t)32 * rec_stride * 16) +
+                 (size_t)(wave * 8 + grp) * (3 * LP + 1);
+
+    for (int i = threadIdx.x; i < win_px * 8; i += kTileThreads) win_u4[i] = u32x4{0u, 0u, 0u, 0u};
+    // contribution bound of this region: max|grad_out| and max|attn| over its rows
+    {
+        float gmax = 0.f, amax = 0.f;
+        for (int i = threadIdx.x; i < pl.rows * 8; i += kTileThreads) {
+            const TileRow row = tile_row(tb, pl.L, pl.rows, i >> 3, b, ry, rx, m, pl.M, pl.Lq);
+            if (row.ok) {
+                const f32x4 g4 = *reinterpret_cast<const f32x4 *>(grad_out + row.pm * D + (i & 7) * 4);
+                gmax = fmaxf(gmax, fmaxf(fmaxf(fabsf(g4.x), fabsf(g4.y)), fmaxf(fabsf(g4.z), fabsf(g4.w))));
+            }
+        }
+        for (int i = threadIdx.x; i < pl.rows * LP; i += kTileThreads) {
+            const int r = i / LP;
+            const TileRow row = tile_row(tb, pl.L, pl.rows, r, b, ry, rx, m, pl.M, pl.Lq);
+            if (row.ok) amax = fmaxf(amax, fabsf(attn[row.pm * LP + (i - r * LP)]));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            gmax = fmaxf(gmax, __shfl_xor(gmax, o, kWave));
+            amax = fmaxf(amax, __shfl_xor(amax, o, kWave));
+        }
+        if (lane == 0) {   // non-negative floats order like their bit patterns
+            atomicMax(&s_bound[0], __float_as_int(gmax));
+            atomicMax(&s_bound[1], __float_as_int(amax));
+        }
+    }
+    tile_place_windows(tb, pl, loc, b, ry, rx, m);  // ends with __syncthreads()
+
+    float bound = __int_as_float(s_bound[0]) * __int_as_float(s_bound[1]);
+    if (!(bound < 3.0e38f)) bound = 3.0e38f;         // inf / nan inputs: results are garbage either way
+    int cnt_log2 = 0;
+    while ((1 << cnt_log2) < pl.rows * pl.P) ++cnt_log2;
+    int bexp = 0;
+    (void)frexpf(bound, &bexp);                       // bound <= 2^bexp
+    const int e = 30 - cnt_log2 - bexp;
+    const float scale = bound > 0.f ? ldexpf(1.0f, e) : 0.f;
+    const float inv_scale = bound > 0.f ? ldexpf(1.0f, -e) : 0.f;
+
+    const unsigned lane_off = (unsigned)sub * 16u;
+    const unsigned dead_target = kGlobalTag | 0x7fffff00u;
+    for (int r0 = 0; r0 < pl.rows; r0 += 32) {
+        const TileRow row = tile_row(tb, pl.L, pl.rows, r0 + wave * 8 + grp, b, ry, rx, m, pl.M, pl.Lq);
+        for (int t = sub; t < LP; t += 8) {
+            const int l = t / pl.P;
+            const f32x2 xy = *reinterpret_cast<const f32x2 *>(loc + (row.pm * LP + t) * 2);
+            const float a = row.ok ? attn[row.pm * LP + t] : 0.f;
+            const int H = tb.H[l], W = tb.W[l];
+            const Sample<float> s = sample_setup<float>(xy.x, xy.y, H, W);
+            const int h0 = s.h_low, w0 = s.w_low, h1 = h0 + 1, w1 = w0 + 1;
+            const bool livep = s.gate && row.ok;
+            const bool okh0 = livep && h0 >= 0, okh1 = livep && h1 <= H - 1;
+            const bool okw0 = w0 >= 0, okw1 = w1 <= W - 1;
+            const unsigned ps = (unsigned)pl.M * 128u;
+            const unsigned o00 = tile_pixel_off(tb, pl, b, l, h0, w0, m);
+            u32x4 go, to;
+            go.x = (okh0 && okw0) ? o00 : kOobOffset;
+            go.y = (okh0 && okw1) ? o00 + ps : kOobOffset;
+            go.z = (okh1 && okw0) ? o00 + (unsigned)W * ps : kOobOffset;
+            go.w = (okh1 && okw1) ? o00 + (unsigned)W * ps + ps : kOobOffset;
+            to.x = tile_corner_target(tb, pl, b, l, h0, w0, m, okh0 && okw0, dead_target);
+            to.y = tile_corner_target(tb, pl, b, l, h0, w1, m, okh0 && okw1, dead_target);
+            to.z = tile_corner_target(tb, pl, b, l, h1, w0, m, okh1 && okw0, dead_target);
+            to.w = tile_corner_target(tb, pl, b, l, h1, w1, m, okh1 && okw1, dead_target);
+            f32x4 w;
+            w.x = s.lh;
+            w.y = s.lw;
+            w.z = a;
+            w.w = 0.f;
+            rec[3 * t] = go;
+            rec[3 * t + 1] = to;
+            rec[3 * t + 2] = __builtin_bit_cast(u32x4, w);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const f32x4 g = row.ok ? *reinterpret_cast<const f32x4 *>(grad_out + row.pm * D + sub * 4)
+                               : f32x4{0.f, 0.f, 0.f, 0.f};
+        const int rot = grp & 3;   // spread the 64 lanes of one ds_add over all banks (rows are 128-B aligned)
+        const f32x4 g_rot = rot == 0 ? g : rot == 1 ? f32x4{g.y, g.z, g.w, g.x}
+                                  : rot == 2 ? f32x4{g.z, g.w, g.x, g.y} : f32x4{g.w, g.x, g.y, g.z};
+        const unsigned c0 = (unsigned)((0 + rot) & 3) * 4u, c1 = (unsigned)((1 + rot) & 3) * 4u;
+        const unsigned c2 = (unsigned)((2 + rot) & 3) * 4u, c3 = (unsigned)((3 + rot) & 3) * 4u;
+        for (int t0 = 0; t0 < LP; t0 += PTS) {
+            u32x4 go[PTS], to[PTS];
+            f32x4 rw[PTS], v[PTS][4];
+#pragma unroll
+            for (int i = 0; i < PTS; ++i) {
+                const int t = (t0 + i < LP) ? t0 + i : LP - 1;
+                go[i] = rec[3 * t];
+                to[i] = rec[3 * t + 1];
+                rw[i] = __builtin_bit_cast(f32x4, rec[3 * t + 2]);
+            }
+#pragma unroll
+            for (int i = 0; i < PTS; ++i) {
+                v[i][0] = buf_load_f4(vr, go[i].x + lane_off);
+                v[i][1] = buf_load_f4(vr, go[i].y + lane_off);
+                v[i][2] = buf_load_f4(vr, go[i].z + lane_off);
+                v[i][3] = buf_load_f4(vr, go[i].w + lane_off);
+            }
+#pragma unroll
+            for (int i = 0; i < PTS; ++i) {
+                const int t = t0 + i;
+                if (t < LP) {
+                    const float lh = rw[i].x, lw = rw[i].y, a = rw[i].z;
+                    const float hh = 1.f - lh, hw = 1.f - lw;
+                    const f32x4 tga = g * a;
+                    const f32x4 tga_rot = g_rot * a;
+                    const float wk[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const unsigned tk = to[i][k];
+                        const f32x4 c = wk[k] * tga_rot;
+                        if (tk & kGlobalTag) {
+                            const unsigned o = (tk & ~kGlobalTag) + lane_off;
+                            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(c.x, gr, (int)(o + c0), 0, 0);
+                            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(c.y, gr, (int)(o + c1), 0, 0);
+                            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(c.z, gr, (int)(o + c2), 0, 0);
+                            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(c.w, gr, (int)(o + c3), 0, 0);
+                        } else {
+                            unsigned char *p = s_dyn + tk + lane_off;
+                            atomicAdd(reinterpret_cast<int *>(p + c0), __float2int_rn(c.x * scale));
+                            atomicAdd(reinterpret_cast<int *>(p + c1), __float2int_rn(c.y * scale));
+                            atomicAdd(reinterpret_cast<int *>(p + c2), __float2int_rn(c.z * scale));
+                            atomicAdd(reinterpret_cast<int *>(p + c3), __float2int_rn(c.w * scale));
+                        }
+                    }
+                    const f32x4 val = wk[0] * v[i][0] + wk[1] * v[i][1] + wk[2] * v[i][2] + wk[3] * v[i][3];
+                    const f32x4 gw = hh * (v[i][1] - v[i][0]) + lh * (v[i][3] - v[i][2]);
+                    const f32x4 gh = hw * (v[i][2] - v[i][0]) + lw * (v[i][3] - v[i][1]);
+                    float pa = g.x * val.x + g.y * val.y + g.z * val.z + g.w * val.w;
+                    float pw = gw.x * tga.x + gw.y * tga.y + gw.z * tga.z + gw.w * tga.w;
+                    float ph = gh.x * tga.x + gh.y * tga.y + gh.z * tga.z + gh.w * tga.w;
+                    pa = sum8(pa);
+                    pw = sum8(pw);
+                    ph = sum8(ph);
+                    if (sub == (t & 7)) {
+                        const int l = t / pl.P;
+                        res[2 * t] = pw * (float)tb.W[l];
+                        res[2 * t + 1] = ph * (float)tb.H[l];
+                        res[2 * LP + t] = pa;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (row.ok) {
+            for (int i = sub; i < 2 * LP; i += 8) grad_loc[row.pm * LP * 2 + i] = res[i];
+            for (int i = sub; i < LP; i += 8) grad_attn[row.pm * LP + i] = res[2 * LP + i];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    for (int l = 0; l < pl.L; ++l) {
+        const int win = tb.win[l], magic = tb.magic[l], base = tb.base[l];
+        const int oy = tb.oy[l], ox = tb.ox[l], H = tb.H[l], W = tb.W[l];
+        const int n = win * win * D;
+        for (int i = threadIdx.x; i < n; i += kTileThreads) {
+            const int pix = i >> 5, c = i & 31;
+            const int q = win_i[(base + pix) * D + c];
+            if (q != 0) {
+                const int wy = (pix * magic) >> 16, wx = pix - wy * win;
+                const int gy = oy + wy, gx = ox + wx;
+                if (gy < H && gx < W)
+                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(
+                        (float)q * inv_scale, gr, (int)(tile_pixel_off(tb, pl, b, l, gy, gx, m) + (unsigned)c * 4u), 0, 0);
+            }
+        }
+    }
+}
+
 // ----------------------------------------------------------------------------------------
 // host side
 // ----------------------------------------------------------------------------------------
@@ -1128,10 +1338,12 @@ int backward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart,
     int variant = opt_bwd_variant.load();
     const long value_bytes = (long)N * S * M * D * (long)sizeof(TV);
     const bool can32 = allow_d32 && d32_ok(D, L, value_bytes);
-    // Measured on MI355X (profiles/): the backward is bound by L2 float-atomic throughput, and the
-    // row-per-block kernel's 32-consecutive-lane atomics run 4x faster than the 8-lane-strided
-    // pattern of the gather kernel, so it is the default until the tiled backward pre-reduces in LDS.
-    if (variant == 0) variant = 1;
+    // Measured on MI355X (profiles/): per-contribution global float atomics cap the backward at ~1.1 ms
+    // for the encoder call (L2 atomic throughput; the row-per-block kernel's 32-consecutive-lane pattern
+    // is the fastest of them).  Self-attention over the pyramid (Lq == S, host shapes known) therefore
+    // takes the region-tiled kernel that pre-reduces grad_value in fixed-point LDS windows (2x faster on
+    // encoder-like sampling); every other call takes the row-per-block kernel.
+    if (variant == 0) variant = (can32 && shapes_host && Lq == S && L <= kTileMaxL) ? 6 : 1;
     if (variant >= 2 && !can32) variant = 1;
     if (variant == 1) {
         int block = ((D + 63) / 64) * 64;
@@ -1144,6 +1356,31 @@ int backward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart,
         return check_launch("msda_bwd_generic");
     }
     if constexpr (sizeof(TV) == 4 && sizeof(TC) == 4 && sizeof(TG) == 4) {
+        if (variant == 6 || variant == 7) {
+            TilePlan pl;
+            size_t lds = 0;
+            const size_t rec_bytes = (size_t)32 * (3 * L * P + 1) * 16 + (size_t)32 * (3 * L * P + 1) * 4;
+            if (make_tile_plan(pl, shapes_host, N, S, M, D, L, Lq, P, value_bytes, opt_bwd_tile_margin.load(), 0,
+                               rec_bytes, lds)) {
+                const int grid = (pl.n_blocks + 7) & ~7;
+#define MSDA_LAUNCH_TQ(PTS)                                                                                          \
+    rc = allow_big_lds(msda_bwd_d32_tile_q<PTS>, lds);                                                               \
+    if (rc) return rc;                                                                                               \
+    hipLaunchKernelGGL(msda_bwd_d32_tile_q<PTS>, dim3(grid), dim3(kTileThreads), lds, stream, (const float *)value,  \
+                       lstart, (const float *)loc, (const float *)attn, (const float *)grad_out,                     \
+                       (float *)grad_value, (float *)grad_loc, (float *)grad_attn, pl)
+                if (variant == 7) {
+                    g_kernel = "msda_bwd_d32_tile_q<8>";
+                    MSDA_LAUNCH_TQ(8);
+                } else {
+                    g_kernel = "msda_bwd_d32_tile_q<4>";
+                    MSDA_LAUNCH_TQ(4);
+                }
+#undef MSDA_LAUNCH_TQ
+                return check_launch(g_kernel);
+            }
+            variant = 1;
+        }
         if (variant == 5) {
             TilePlan pl;
             size_t lds = 0;

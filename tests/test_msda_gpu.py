@@ -217,21 +217,23 @@ def test_region_tiled_kernels_match_oracle(msda, hip_lib, case, margin):
     ref_out = oracle.forward(g["value"], g["shapes"], g["level_start"], g["loc"], g["attn"])
     rgv, rgl, rga = oracle.backward(g["value"], g["shapes"], g["level_start"], g["loc"], g["attn"], g["grad_out"])
     hip_lib.set_option("fwd_variant", 5)
-    hip_lib.set_option("bwd_variant", 5)
     hip_lib.set_option("fwd_tile_margin", margin)
     hip_lib.set_option("bwd_tile_margin", margin)
     try:
         out = run_fwd(msda, g)
         assert hip_lib.last_kernel() == "msda_fwd_d32_tile"
-        gv, gl, ga = run_bwd(msda, g)
-        assert hip_lib.last_kernel() == "msda_bwd_d32_tile"
+        np.testing.assert_allclose(out, ref_out, **tol(np.float32, 2))
+        # 5: float LDS atomics; 6/7: fixed-point window accumulation (4 / 8 points in flight)
+        for variant, kernel in ((5, "msda_bwd_d32_tile"), (6, "msda_bwd_d32_tile_q<4>"), (7, "msda_bwd_d32_tile_q<8>")):
+            hip_lib.set_option("bwd_variant", variant)
+            gv, gl, ga = run_bwd(msda, g)
+            assert hip_lib.last_kernel() == kernel
+            np.testing.assert_allclose(gv, rgv, **tol(np.float32, 8))
+            np.testing.assert_allclose(gl, rgl, **tol(np.float32, 100))
+            np.testing.assert_allclose(ga, rga, **tol(np.float32, 40))
     finally:
         hip_lib.set_option("fwd_tile_margin", 3)
         hip_lib.set_option("bwd_tile_margin", 2)
-    np.testing.assert_allclose(out, ref_out, **tol(np.float32, 2))
-    np.testing.assert_allclose(gv, rgv, **tol(np.float32, 8))
-    np.testing.assert_allclose(gl, rgl, **tol(np.float32, 100))
-    np.testing.assert_allclose(ga, rga, **tol(np.float32, 40))
 
 
 def test_tiled_variant_falls_back_when_queries_are_not_the_pyramid(msda, hip_lib):
@@ -265,10 +267,10 @@ def test_full_size_specialised_equals_generic(msda, hip_lib, full_inputs):
         torch.testing.assert_close(out, ref, rtol=1e-4, atol=2e-5)
     hip_lib.set_option("bwd_variant", 1)
     ref_g = msda.ms_deform_attn_backward(*args, x["grad_out"], 64)
-    for v in (2, 3, 5):
+    for v in (2, 3, 5, 6, 7):
         hip_lib.set_option("bwd_variant", v)
         got = msda.ms_deform_attn_backward(*args, x["grad_out"], 64)
-        assert (v == 5) == ("tile" in hip_lib.last_kernel())
+        assert (v >= 5) == ("tile" in hip_lib.last_kernel())
         torch.testing.assert_close(got[0], ref_g[0], rtol=1e-3, atol=2e-4)   # atomics: order-dependent sums
         torch.testing.assert_close(got[1], ref_g[1], rtol=1e-3, atol=5e-3)
         torch.testing.assert_close(got[2], ref_g[2], rtol=1e-3, atol=5e-4)

@@ -27,7 +27,7 @@ def main():
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--out", default="gpurun_out/kbench.json")
     ap.add_argument("--fwd-variants", default="1,2,3,4,5")
-    ap.add_argument("--bwd-variants", default="1,2,3,90,5")
+    ap.add_argument("--bwd-variants", default="1,2,3,90,5,6,7")
     ap.add_argument("--blocks", default="64,256")
     ap.add_argument("--margins", default="1,2,3,4,5")
     ap.add_argument("--grid-mults", default="8,16,32")
@@ -69,13 +69,13 @@ def main():
                           f"({gbps/80:5.1f}%)  err {err:.1e}  {_lib.last_kernel()}", flush=True)
             for v in bv:
                 combos = [(256, 8)] if v == 1 else itertools.product(blocks, gms)
-                if v == 5:
+                if v in (5, 6, 7):
                     if nq is not None:
                         continue
                     combos = [(256, mg) for mg in margins]
                 for blk, gm in combos:
                     _lib.set_option("bwd_variant", v); _lib.set_option("bwd_block", blk)
-                    _lib.set_option("bwd_tile_margin" if v == 5 else "bwd_grid_mult", gm)
+                    _lib.set_option("bwd_tile_margin" if v in (5, 6, 7) else "bwd_grid_mult", gm)
                     call.bwd(); torch.cuda.synchronize()
                     errs = [float((a - b).abs().max()) for a, b in zip((call.gv, call.gl, call.ga), ref[1:])]
                     ms = time_kernel(call.bwd, iters=10 if nq is None else 50)
