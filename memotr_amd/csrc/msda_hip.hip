@@ -954,6 +954,15 @@ __global__ __launch_bounds__(kTileThreads) void msda_bwd_d32_tile(
 // the quantisation step is B * 2^-(30 - log2(rows*P)) (~2^-21 B for L = P = 4).  The flush converts
 // back (exact power-of-two scaling) and adds into grad_value with float atomics like every other
 // path.  Integer adds commute, so the in-window part of the result is order-independent.
+//
+// Records are 32 bytes per (row, point): {global offset of corner 00, window cells 00|01, 10|11
+// (0xffff = outside the window), valid mask} + {lh, lw, attn}.  For the scatter each lane owns
+// channels {sub, sub+8, sub+16, sub+24} (its own strided copy of grad_out): the 8 lanes of a row then
+// write 32 contiguous bytes per atomic -- twice the L2 atomic rate of the 16-byte-strided float4
+// layout on the fallback path -- and rotating the channel group by the row slot spreads one ds_add
+// over all 32 LDS banks.
+constexpr unsigned kNoCell = 0xffffu;
+
 template <int PTS>
 __global__ __launch_bounds__(kTileThreads) void msda_bwd_d32_tile_q(
     const float *__restrict__ value, const int64_t *__restrict__ lstart, const float *__restrict__ loc,
@@ -979,14 +988,13 @@ __global__ __launch_bounds__(kTileThreads) void msda_bwd_d32_tile_q(
     u32x4 *win_u4 = reinterpret_cast<u32x4 *>(s_dyn);
     int *win_i = reinterpret_cast<int *>(s_dyn);
     const int win_px = tb.base[pl.L];
-    const int rec_stride = 3 * LP + 1;
+    const int rec_stride = 2 * LP + 1;
     u32x4 *rec = reinterpret_cast<u32x4 *>(s_dyn + (size_t)win_px * 128) + (size_t)(wave * 8 + grp) * rec_stride;
     float *res = reinterpret_cast<float *>(s_dyn + (size_t)win_px * 128 + (size_t)32 * rec_stride * 16) +
                  (size_t)(wave * 8 + grp) * (3 * LP + 1);
 
     for (int i = threadIdx.x; i < win_px * 8; i += kTileThreads) win_u4[i] = u32x4{0u, 0u, 0u, 0u};
-    // contribution bound of this region: max|grad_out| and max|attn| over its rows
-    {
+    {   // contribution bound of this region: max|grad_out| and max|attn| over its rows
         float gmax = 0.f, amax = 0.f;
         for (int i = threadIdx.x; i < pl.rows * 8; i += kTileThreads) {
             const TileRow row = tile_row(tb, pl.L, pl.rows, i >> 3, b, ry, rx, m, pl.M, pl.Lq);
@@ -1023,7 +1031,13 @@ __global__ __launch_bounds__(kTileThreads) void msda_bwd_d32_tile_q(
     const float inv_scale = bound > 0.f ? ldexpf(1.0f, -e) : 0.f;
 
     const unsigned lane_off = (unsigned)sub * 16u;
-    const unsigned dead_target = kGlobalTag | 0x7fffff00u;
+    const unsigned ps = (unsigned)pl.M * 128u;
+    const int rot = grp & 3;
+    // byte offset (inside a 128-byte pixel row) of the channel this lane scatters in step j
+    unsigned ch_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ch_off[j] = (unsigned)(sub + 8 * ((j + rot) & 3)) * 4u;
+
     for (int r0 = 0; r0 < pl.rows; r0 += 32) {
         const TileRow row = tile_row(tb, pl.L, pl.rows, r0 + wave * 8 + grp, b, ry, rx, m, pl.M, pl.Lq);
         for (int t = sub; t < LP; t += 8) {
@@ -1036,52 +1050,52 @@ __global__ __launch_bounds__(kTileThreads) void msda_bwd_d32_tile_q(
             const bool livep = s.gate && row.ok;
             const bool okh0 = livep && h0 >= 0, okh1 = livep && h1 <= H - 1;
             const bool okw0 = w0 >= 0, okw1 = w1 <= W - 1;
-            const unsigned ps = (unsigned)pl.M * 128u;
-            const unsigned o00 = tile_pixel_off(tb, pl, b, l, h0, w0, m);
-            u32x4 go, to;
-            go.x = (okh0 && okw0) ? o00 : kOobOffset;
-            go.y = (okh0 && okw1) ? o00 + ps : kOobOffset;
-            go.z = (okh1 && okw0) ? o00 + (unsigned)W * ps : kOobOffset;
-            go.w = (okh1 && okw1) ? o00 + (unsigned)W * ps + ps : kOobOffset;
-            to.x = tile_corner_target(tb, pl, b, l, h0, w0, m, okh0 && okw0, dead_target);
-            to.y = tile_corner_target(tb, pl, b, l, h0, w1, m, okh0 && okw1, dead_target);
-            to.z = tile_corner_target(tb, pl, b, l, h1, w0, m, okh1 && okw0, dead_target);
-            to.w = tile_corner_target(tb, pl, b, l, h1, w1, m, okh1 && okw1, dead_target);
+            const int win = tb.win[l], base = tb.base[l];
+            const int wy0 = h0 - tb.oy[l], wx0 = w0 - tb.ox[l];
+            const bool iy0 = (unsigned)wy0 < (unsigned)win, iy1 = (unsigned)(wy0 + 1) < (unsigned)win;
+            const bool ix0 = (unsigned)wx0 < (unsigned)win, ix1 = (unsigned)(wx0 + 1) < (unsigned)win;
+            const unsigned c00 = (unsigned)(base + wy0 * win + wx0);
+            u32x4 r0v;
+            r0v.x = tile_pixel_off(tb, pl, b, l, h0, w0, m);
+            r0v.y = ((iy0 && ix0) ? c00 : kNoCell) | (((iy0 && ix1) ? c00 + 1u : kNoCell) << 16);
+            r0v.z = ((iy1 && ix0) ? c00 + (unsigned)win : kNoCell) | (((iy1 && ix1) ? c00 + (unsigned)win + 1u : kNoCell) << 16);
+            r0v.w = (unsigned)(okh0 && okw0) | ((unsigned)(okh0 && okw1) << 1) | ((unsigned)(okh1 && okw0) << 2) |
+                    ((unsigned)(okh1 && okw1) << 3);
             f32x4 w;
             w.x = s.lh;
             w.y = s.lw;
             w.z = a;
             w.w = 0.f;
-            rec[3 * t] = go;
-            rec[3 * t + 1] = to;
-            rec[3 * t + 2] = __builtin_bit_cast(u32x4, w);
+            rec[2 * t] = r0v;
+            rec[2 * t + 1] = __builtin_bit_cast(u32x4, w);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const f32x4 g = row.ok ? *reinterpret_cast<const f32x4 *>(grad_out + row.pm * D + sub * 4)
                                : f32x4{0.f, 0.f, 0.f, 0.f};
-        const int rot = grp & 3;   // spread the 64 lanes of one ds_add over all banks (rows are 128-B aligned)
-        const f32x4 g_rot = rot == 0 ? g : rot == 1 ? f32x4{g.y, g.z, g.w, g.x}
-                                  : rot == 2 ? f32x4{g.z, g.w, g.x, g.y} : f32x4{g.w, g.x, g.y, g.z};
-        const unsigned c0 = (unsigned)((0 + rot) & 3) * 4u, c1 = (unsigned)((1 + rot) & 3) * 4u;
-        const unsigned c2 = (unsigned)((2 + rot) & 3) * 4u, c3 = (unsigned)((3 + rot) & 3) * 4u;
+        f32x4 gs;   // grad_out at the scatter channels of this lane, pre-multiplied by the fixed-point scale
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gs[j] = row.ok ? grad_out[row.pm * D + (ch_off[j] >> 2)] : 0.f;
         for (int t0 = 0; t0 < LP; t0 += PTS) {
-            u32x4 go[PTS], to[PTS];
+            u32x4 ra[PTS];
             f32x4 rw[PTS], v[PTS][4];
+            unsigned go[PTS][4];
 #pragma unroll
             for (int i = 0; i < PTS; ++i) {
                 const int t = (t0 + i < LP) ? t0 + i : LP - 1;
-                go[i] = rec[3 * t];
-                to[i] = rec[3 * t + 1];
-                rw[i] = __builtin_bit_cast(f32x4, rec[3 * t + 2]);
+                ra[i] = rec[2 * t];
+                rw[i] = __builtin_bit_cast(f32x4, rec[2 * t + 1]);
+                const unsigned wps = (unsigned)tb.W[t / pl.P] * ps;
+                const unsigned mask = ra[i].w;
+                go[i][0] = (mask & 1u) ? ra[i].x : kOobOffset;
+                go[i][1] = (mask & 2u) ? ra[i].x + ps : kOobOffset;
+                go[i][2] = (mask & 4u) ? ra[i].x + wps : kOobOffset;
+                go[i][3] = (mask & 8u) ? ra[i].x + wps + ps : kOobOffset;
             }
 #pragma unroll
-            for (int i = 0; i < PTS; ++i) {
-                v[i][0] = buf_load_f4(vr, go[i].x + lane_off);
-                v[i][1] = buf_load_f4(vr, go[i].y + lane_off);
-                v[i][2] = buf_load_f4(vr, go[i].z + lane_off);
-                v[i][3] = buf_load_f4(vr, go[i].w + lane_off);
-            }
+            for (int i = 0; i < PTS; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[i][k] = buf_load_f4(vr, go[i][k] + lane_off);
 #pragma unroll
             for (int i = 0; i < PTS; ++i) {
                 const int t = t0 + i;
@@ -1089,24 +1103,23 @@ __global__ __launch_bounds__(kTileThreads) void msda_bwd_d32_tile_q(
                     const float lh = rw[i].x, lw = rw[i].y, a = rw[i].z;
                     const float hh = 1.f - lh, hw = 1.f - lw;
                     const f32x4 tga = g * a;
-                    const f32x4 tga_rot = g_rot * a;
+                    const f32x4 sa = gs * a;            // contributions before the corner weight
                     const float wk[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
+                    const unsigned cells[4] = {ra[i].y & 0xffffu, ra[i].y >> 16, ra[i].z & 0xffffu, ra[i].z >> 16};
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const unsigned tk = to[i][k];
-                        const f32x4 c = wk[k] * tga_rot;
-                        if (tk & kGlobalTag) {
-                            const unsigned o = (tk & ~kGlobalTag) + lane_off;
-                            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(c.x, gr, (int)(o + c0), 0, 0);
-                            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(c.y, gr, (int)(o + c1), 0, 0);
-                            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(c.z, gr, (int)(o + c2), 0, 0);
-                            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(c.w, gr, (int)(o + c3), 0, 0);
+                        if (go[i][k] == kOobOffset) continue;        // dead corner (zero padding / gated point)
+                        const f32x4 c = wk[k] * sa;
+                        if (cells[k] == kNoCell) {                     // outside the window: global float atomics
+                            const unsigned o = go[i][k];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(c[j], gr, (int)(o + ch_off[j]), 0, 0);
                         } else {
-                            unsigned char *p = s_dyn + tk + lane_off;
-                            atomicAdd(reinterpret_cast<int *>(p + c0), __float2int_rn(c.x * scale));
-                            atomicAdd(reinterpret_cast<int *>(p + c1), __float2int_rn(c.y * scale));
-                            atomicAdd(reinterpret_cast<int *>(p + c2), __float2int_rn(c.z * scale));
-                            atomicAdd(reinterpret_cast<int *>(p + c3), __float2int_rn(c.w * scale));
+                            unsigned char *p = s_dyn + cells[k] * 128u;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                atomicAdd(reinterpret_cast<int *>(p + ch_off[j]), __float2int_rn(c[j] * scale));
                         }
                     }
                     const f32x4 val = wk[0] * v[i][0] + wk[1] * v[i][1] + wk[2] * v[i][2] + wk[3] * v[i][3];
@@ -1164,7 +1177,7 @@ thread_local const char *g_kernel = "";
 std::atomic<int> opt_fwd_variant{0}, opt_bwd_variant{0};
 std::atomic<int> opt_fwd_block{256}, opt_bwd_block{256};
 std::atomic<int> opt_fwd_grid_mult{32}, opt_bwd_grid_mult{16};
-std::atomic<int> opt_fwd_tile_margin{3}, opt_bwd_tile_margin{2};
+std::atomic<int> opt_fwd_tile_margin{3}, opt_bwd_tile_margin{3};
 
 int fail(int code, const char *msg) {
     snprintf(g_err, sizeof(g_err), "%s", msg);
@@ -1245,12 +1258,20 @@ bool make_tile_plan(TilePlan &pl, const int64_t *shapes_host, int N, int S, int 
     return lds <= 160 * 1024 - 512;
 }
 
+// Dynamic LDS above 64 KiB needs an opt-in per kernel; do it once per kernel and device for the full
+// 160 KiB (the call costs host time, too much to repeat per launch).
 template <typename K>
 int allow_big_lds(K kernel, size_t lds) {
     if (lds <= 64 * 1024) return MSDA_OK;
+    static std::atomic<unsigned long long> done{0};   // one bit per device ordinal (per template instance)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return MSDA_OK;
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
     if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+    done.fetch_or(bit, std::memory_order_release);
     return MSDA_OK;
 }
 
@@ -1359,7 +1380,7 @@ int backward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart,
         if (variant == 6 || variant == 7) {
             TilePlan pl;
             size_t lds = 0;
-            const size_t rec_bytes = (size_t)32 * (3 * L * P + 1) * 16 + (size_t)32 * (3 * L * P + 1) * 4;
+            const size_t rec_bytes = (size_t)32 * (2 * L * P + 1) * 16 + (size_t)32 * (3 * L * P + 1) * 4;
             if (make_tile_plan(pl, shapes_host, N, S, M, D, L, Lq, P, value_bytes, opt_bwd_tile_margin.load(), 0,
                                rec_bytes, lds)) {
                 const int grid = (pl.n_blocks + 7) & ~7;

@@ -25,9 +25,9 @@ def run_train(args, rank: int, world: int, clip_len: int = None, height: int = 8
     cfg = config or dancetrack_config()
     torch.backends.cuda.matmul.allow_tf32 = False     # main.py:96-97 of the reference: strict fp32
     torch.backends.cudnn.allow_tf32 = False
-    # MIOpen: benchmark every applicable solver once per conv shape (warm-up steps absorb the search).  Without
-    # it the immediate-mode heuristic can land on MIOpen's naive reference kernels for some gfx950 shapes.
-    torch.backends.cudnn.benchmark = os.environ.get("MEMOTR_MIOPEN_FIND", "1") == "1"
+    # MIOpen exhaustive find (cudnn.benchmark) was measured on MI355X: no gain for these shapes (13.2 vs 13.7
+    # frames/s) and minutes of search per process, so immediate mode stays the default.
+    torch.backends.cudnn.benchmark = os.environ.get("MEMOTR_MIOPEN_FIND", "0") == "1"
     dev = torch.device("cuda", torch.cuda.current_device())
     set_seed(cfg["SEED"])
     cfg = dict(cfg, DEVICE="cuda", AVAILABLE_GPUS="0")

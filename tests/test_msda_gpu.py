@@ -233,7 +233,7 @@ def test_region_tiled_kernels_match_oracle(msda, hip_lib, case, margin):
             np.testing.assert_allclose(ga, rga, **tol(np.float32, 40))
     finally:
         hip_lib.set_option("fwd_tile_margin", 3)
-        hip_lib.set_option("bwd_tile_margin", 2)
+        hip_lib.set_option("bwd_tile_margin", 3)
 
 
 def test_tiled_variant_falls_back_when_queries_are_not_the_pyramid(msda, hip_lib):
