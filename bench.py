@@ -139,10 +139,25 @@ def cpu_baseline_msda(args, enc_shape_kwargs, dec_shape_kwargs):
     from memotr_amd.synth import make_inputs
     from oracle import msda_oracle as oracle
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
     if args.cpu_threads > 0:
         cores = args.cpu_threads
-        torch.set_num_threads(cores)
+    else:
+        # the fallback is a chain of small ops: more threads than it can feed only adds overhead, so the thread
+        # count is the best of a quick probe on a reduced shape (reported as `cores`)
+        probe_kw = dict(dec_shape_kwargs, height=200, width=336)
+        best = None
+        for n in sorted({cores, min(cores, 64), min(cores, 32), min(cores, 16)}, reverse=True):
+            torch.set_num_threads(n)
+            xp = make_inputs(device="cpu", **probe_kw)
+            oracle.grid_sample_forward(xp["value"], xp["shapes_list"], xp["loc"], xp["attn"])   # warm
+            t0 = time.perf_counter()
+            for _ in range(3):
+                oracle.grid_sample_forward(xp["value"], xp["shapes_list"], xp["loc"], xp["attn"])
+            dt = time.perf_counter() - t0
+            if best is None or dt < best[0]:
+                best = (dt, n)
+        cores = best[1]
+    torch.set_num_threads(cores)
 
     def one(kw):
         x = make_inputs(device="cpu", **kw)
@@ -275,9 +290,10 @@ def main():
     else:
         raise SystemExit(f"unknown workload {args.workload}")
     if rank == 0:
-        print(json.dumps(result))
-    if world > 1:
+        print(json.dumps(result), flush=True)
+    if world > 1:   # rank 0 did extra kernel timing: leave together
         import torch.distributed as dist
+        dist.barrier()
         dist.destroy_process_group()
 
 
