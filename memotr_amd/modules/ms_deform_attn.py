@@ -86,6 +86,11 @@ class MSDeformAttn(nn.Module):
         w = torch.cat((self.sampling_offsets.weight, self.attention_weights.weight), 0)
         b = torch.cat((self.sampling_offsets.bias, self.attention_weights.bias), 0)
         proj = F.linear(query, w, b)
+        if proj.dtype == torch.bfloat16:
+            # bf16 mixed precision (no reference counterpart; policy in DESIGN.md): GEMMs and `value` in bf16,
+            # sampling locations / attention weights / index arithmetic stay fp32
+            proj = proj.float()
+            reference_points = reference_points.float()
         offsets = proj[..., :n_off].reshape(N, Lq, M, L, P, 2)
         logits = proj[..., n_off:].reshape(N, Lq, M, L * P)
         if self.sigmoid_attn:

@@ -83,3 +83,18 @@ def test_dropin_module_name_resolves():
     finally:
         sys.path.pop(0)
         sys.modules.pop("MultiScaleDeformableAttention", None)
+
+
+def test_algorithmic_byte_counts_match_the_survey():
+    """SURVEY.md 8(d): 80,005,632 B (+96 B of int64 metadata) forward, 137,152,512 B backward at the encoder shape;
+    decoder-shape calls cannot read more of `value` than the corners they touch."""
+    from memotr_amd.synth import algorithmic_bytes, level_start_index, pyramid_shapes
+    shapes = pyramid_shapes(800, 1333)
+    assert shapes == [(100, 168), (50, 84), (25, 42), (13, 21)]
+    assert level_start_index(shapes) == [0, 16800, 21000, 22050]
+    S = sum(h * w for h, w in shapes)
+    assert S == 22323
+    assert algorithmic_bytes(1, S, S, 8, 32, 4, 4) == 80_005_632 + 96
+    assert algorithmic_bytes(1, S, S, 8, 32, 4, 4, backward=True) == 137_152_512 + 96
+    assert algorithmic_bytes(1, S, 300, 8, 32, 4, 4) == 20_428_800 + 96
+    assert pyramid_shapes(720, 1280) == [(92, 160), (46, 80), (23, 40), (12, 20)]

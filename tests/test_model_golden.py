@@ -256,3 +256,33 @@ def test_param_groups_follow_the_reference_keywords():
     assert sum(p.numel() for gr in groups for p in gr["params"]) == n_all
     point_names = [n for n, _ in model.named_parameters() if "sampling_offsets" in n]
     assert len(groups[1]["params"]) == len(point_names) > 0
+
+
+def test_sequence_tracker_reproduces_the_submit_loop(monkeypatch):
+    """submit_engine.py:58-120,171-184: per-frame filter (score > thresh, area > 100), xyxy pixel boxes and MOT lines,
+    checked against the tracks the reference produced for the same two frames."""
+    from memotr_amd.inference import SequenceTracker
+    patch_operator(monkeypatch)
+    g = load_model_golden("M5_memotr_two_frames")
+    model = build_memotr(g)
+    thresh = float(g["score_thresh"])
+    st = SequenceTracker(model, dataset_name="DanceTrack", det_score_thresh=thresh, track_score_thresh=thresh,
+                         result_score_thresh=thresh, miss_tolerance=30, use_dab=True)
+    ori_h, ori_w = 240, 300
+    for i in range(2):
+        out = st.step(t(g[f"frame{i}"]), ori_h, ori_w)
+        boxes, scores, ids = g[f"f{i}_next_boxes"], g[f"f{i}_next_scores"], g[f"f{i}_next_ids"]
+        area = boxes[:, 2] * ori_w * boxes[:, 3] * ori_h
+        keep = (scores.max(-1) > thresh) & (area > 100)
+        assert np.array_equal(out.ids.numpy(), ids[keep])
+        cx, cy, w, h = boxes[keep].T
+        want = np.stack([(cx - 0.5 * w) * ori_w, (cy - 0.5 * h) * ori_h, (cx + 0.5 * w) * ori_w,
+                         (cy + 0.5 * h) * ori_h], -1)
+        np.testing.assert_allclose(out.boxes.numpy(), want, rtol=1e-4, atol=2e-2)
+        lines = st.mot_lines(i, out)
+        assert len(lines) == int(keep.sum()) and all(ln.endswith(",1,-1,-1,-1\n") for ln in lines)
+        if lines:
+            f, tid = lines[0].split(",")[:2]
+            assert int(f) == i + 1 and int(tid) == int(ids[keep][0])
+    js = st.bdd_frame_result(1, out, "a/b/video-0000001.jpg")
+    assert js["frameIndex"] == 1 and len(js["labels"]) == len(out) and js["name"] == "video-0000001.jpg"

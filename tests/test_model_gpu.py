@@ -125,3 +125,29 @@ def test_d32_model_hip_operator_vs_oracle_operator(monkeypatch, hip_lib):
     for n in g_h:
         denom = float(g_o[n].norm()) + 1e-6
         assert float((g_h[n] - g_o[n]).norm()) / denom < 5e-3, n
+
+
+def test_bf16_autocast_module_tracks_fp32(hip_lib):
+    """bf16 extension (BASELINE config 5 has no reference counterpart): under autocast the projections and `value`
+    run in bf16, locations/weights/accumulation in fp32 (msda_*_bf16 entry points); result stays near the fp32 one."""
+    from memotr_amd.modules import MSDeformAttn
+    torch.manual_seed(1)
+    mod = MSDeformAttn(d_model=256, n_levels=4, n_heads=8, n_points=4).cuda()
+    with torch.no_grad():
+        mod.sampling_offsets.weight.normal_(0, 0.02)
+        mod.attention_weights.weight.normal_(0, 0.05)
+    shapes_l = [(12, 16), (6, 8), (3, 4), (2, 2)]
+    shapes = torch.tensor(shapes_l, device="cuda")
+    lsi = torch.tensor([0, 192, 240, 252], device="cuda")
+    S = 256
+    src = torch.randn(2, S, 256, device="cuda")
+    query = torch.randn(2, 40, 256, device="cuda", requires_grad=True)
+    ref = torch.rand(2, 40, 4, 2, device="cuda")
+    out32 = mod(query, ref, src, shapes, lsi)
+    (g32,) = torch.autograd.grad(out32.sum(), query)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out16 = mod(query, ref, src, shapes, lsi)
+    assert out16.dtype == torch.bfloat16 and "generic" in hip_lib.last_kernel()
+    (g16,) = torch.autograd.grad(out16.float().sum(), query)
+    assert float((out16.float() - out32).abs().max()) < 0.06 * float(out32.abs().max()) + 0.02
+    assert float((g16.float() - g32).norm()) < 0.05 * float(g32.norm()) + 1e-3
