@@ -94,50 +94,82 @@ class ClipCriterion:
 
     # ------------------------------------------------------------------ one frame
     def process_single_frame(self, model_outputs: dict, tracked_instances: List[TrackInstances], frame_idx: int):
+        """Returns (tracked, new, unmatched) TrackInstances lists and accumulates this frame's losses.
+
+        All decoder layers are handled together: one stacked cost tensor -> ONE device->host copy -> scipy on the
+        host -> one small index upload -> stacked focal / L1 / GIoU losses.  Track bookkeeping uses slices and
+        ``torch.where`` (boolean-mask indexing would synchronise once per field).
+        """
         nd = self.n_det_queries
         gts = self.gt_trackinstances_list[frame_idx]
         B = len(tracked_instances)
+        dev = self.device
         tracked_instances = self.update_tracked_instances(model_outputs, tracked_instances)
+        layers = [model_outputs] + (list(model_outputs["aux_outputs"]) if self.aux_loss else [])
+        n_layers = len(layers)
+        early = [li > 0 and (li - 1) < self.merge_det_track_layer for li in range(n_layers)]
+        logits_all = torch.stack([o["pred_logits"] for o in layers])      # (n_layers, B, Nq, K)
+        boxes_all = torch.stack([o["pred_bboxes"] for o in layers])       # (n_layers, B, Nq, 4)
 
-        # which ground truth does every carried track own (-1: its identity left the scene / never had one)
-        untracked, untracked_global = [], []
+        # ---- device side: ownership of ground truths + stacked cost tensors, then one transfer ----
+        payload, n_gt_list = [], []
         for b in range(B):
             tr, gt = tracked_instances[b], gts[b]
-            if len(tr) > 0 and len(gt) > 0:
+            n_gt, n_tr = len(gt), len(tr)
+            n_gt_list.append(n_gt)
+            if n_tr > 0 and n_gt > 0:
                 eq = tr.ids[:, None] == gt.ids[None, :]
                 tr.matched_idx = torch.where(eq.any(1), eq.float().argmax(1), torch.full_like(tr.ids, -1))
+                free = ~eq.any(0)
             else:
-                tr.matched_idx = torch.full((len(tr),), -1, dtype=torch.long, device=gt.ids.device)
-            free = torch.ones((len(gt),), dtype=torch.bool, device=gt.ids.device)
-            free[tr.matched_idx[tr.matched_idx >= 0]] = False
-            untracked.append(gt[free] if len(gt) > 0 else gt)
-            untracked_global.append(torch.nonzero(free).squeeze(1))
+                tr.matched_idx = torch.full((n_tr,), -1, dtype=torch.long, device=dev)
+                free = torch.ones((n_gt,), dtype=torch.bool, device=dev)
+            cost = self.matcher.cost_matrix_stacked(logits_all[:, b, :nd].detach(), boxes_all[:, b, :nd].detach(),
+                                                    gt.labels, gt.boxes)                  # (n_layers, nd, n_gt)
+            payload += [free.to(cost.dtype).reshape(-1), cost.reshape(-1)]
+        host = torch.cat(payload).cpu() if payload else torch.zeros(0)
 
-        # every assignment problem of this frame (last layer + aux layers) from one host transfer
-        layers = [model_outputs] + (list(model_outputs["aux_outputs"]) if self.aux_loss else [])
-        costs, plan = [], []
-        for li, out in enumerate(layers):
-            against_all = li > 0 and (li - 1) < self.merge_det_track_layer
-            for b in range(B):
-                tgt = gts[b] if against_all else untracked[b]
-                costs.append(self.matcher.cost_matrix(out["pred_logits"][b, :nd].detach(),
-                                                      out["pred_bboxes"][b, :nd].detach(), tgt.labels, tgt.boxes))
-                plan.append((li, b, against_all))
-        solved = self.matcher.solve_many(costs)
-        dev = self.device
-        match = {}
-        for (li, b, against_all), (qi, tj) in zip(plan, solved):
-            qi, tj = qi.to(dev), tj.to(dev)
-            match[(li, b)] = (qi, tj if against_all else untracked_global[b][tj])
-
-        # new tracks from the matched detect queries of the last layer
-        new_tracks = []
+        # ---- host side: the assignment problems ----
+        pos = 0
+        rows_layer, rows_q, rows_g = [[] for _ in range(B)], [[] for _ in range(B)], [[] for _ in range(B)]
+        main_q = []
         for b in range(B):
-            q_idx, gt_idx = match[(0, b)]
-            nt = TrackInstances(frame_height=tracked_instances[b].frame_height,
-                                frame_width=tracked_instances[b].frame_width,
-                                hidden_dim=tracked_instances[b].hidden_dim, num_classes=self.num_classes)
-            nt.ids = gts[b].ids[gt_idx]
+            n_gt = n_gt_list[b]
+            free_h = host[pos:pos + n_gt].bool().numpy()
+            pos += n_gt
+            cost_h = host[pos:pos + n_layers * nd * n_gt].view(n_layers, nd, n_gt).numpy()
+            pos += n_layers * nd * n_gt
+            free_idx = free_h.nonzero()[0]
+            for li in range(n_layers):
+                if early[li]:
+                    qi, gj = self.matcher.solve(cost_h[li])
+                else:
+                    qi, tj = self.matcher.solve(cost_h[li][:, free_idx])
+                    gj = free_idx[tj]
+                rows_layer[b].append([li] * len(qi))
+                rows_q[b].append(qi)
+                rows_g[b].append(gj)
+                if li == 0:
+                    main_q.append((qi, gj))
+
+        # ---- back on the device: new tracks, losses, unmatched detections ----
+        new_tracks, unmatched = [], []
+        loss_label = torch.zeros((n_layers,), device=dev)
+        loss_l1 = torch.zeros((n_layers,), device=dev)
+        loss_giou = torch.zeros((n_layers,), device=dev)
+        n_det_out = len(model_outputs["det_query_embed"])
+        for b in range(B):
+            tr, gt = tracked_instances[b], gts[b]
+            n_tr = len(tr)
+            flat = lambda rows: [x for r in rows for x in r]                       # noqa: E731
+            idx = torch.as_tensor([flat(rows_layer[b]), flat(rows_q[b]), flat(rows_g[b])], dtype=torch.long).to(dev)
+            lay_i, q_i, g_i = idx[0], idx[1], idx[2]
+            n_main = len(main_q[b][0])
+            q_idx, gt_idx = q_i[:n_main], g_i[:n_main]                              # layer 0 comes first
+
+            nt = TrackInstances(frame_height=tr.frame_height, frame_width=tr.frame_width, hidden_dim=tr.hidden_dim,
+                                num_classes=self.num_classes)
+            nt.ids = gt.ids[gt_idx]
             nt.matched_idx = gt_idx
             queries = model_outputs["aux_outputs"][-1]["queries"][b][q_idx]
             nt.query_embed = queries if self.use_dab else torch.cat(
@@ -146,89 +178,97 @@ class ClipCriterion:
             nt.output_embed = model_outputs["outputs"][b][q_idx]
             nt.boxes = model_outputs["pred_bboxes"][b][q_idx]
             nt.logits = model_outputs["pred_logits"][b][q_idx]
-            nt.iou = torch.zeros((len(gt_idx),), dtype=torch.float)
-            new_tracks.append(nt.to(dev))
+            nt.iou = torch.zeros((n_main,), dtype=torch.float)
+            nt = nt.to(dev)
 
-        tracked_pairs = [(torch.arange(nd, nd + len(tracked_instances[b]), device=dev),
-                          tracked_instances[b].matched_idx.to(dev)) for b in range(B)]
+            # classification targets of every layer: matched detect queries + (late layers) the carried tracks
+            n_q = nd + n_tr                                                        # real (unpadded) queries of clip b
+            labels = torch.full((n_layers, n_q), self.num_classes, dtype=torch.int64, device=dev)
+            labels[lay_i, q_i] = gt.labels[g_i]
+            late = torch.as_tensor([not e for e in early], device=dev)
+            if n_tr > 0:
+                has = tr.matched_idx >= 0
+                tr_lab = torch.where(has, gt.labels[tr.matched_idx.clamp(min=0)] if len(gt) > 0
+                                     else torch.full_like(tr.matched_idx, self.num_classes),
+                                     torch.full_like(tr.matched_idx, self.num_classes))
+                labels[:, nd:] = torch.where(late[:, None], tr_lab[None, :], labels[:, nd:])
+            one_hot = F.one_hot(labels, self.num_classes + 1)[..., :-1].to(logits_all.dtype)
+            loss_label = loss_label + sigmoid_focal_loss_per_layer(logits_all[:, b, :n_q], one_hot)
 
-        def pairs_for(li):
-            res = []
-            for b in range(B):
-                q, g = match[(li, b)]
-                if li > 0 and (li - 1) < self.merge_det_track_layer:
-                    res.append((q, g))          # early layers: detect queries against all ground truths
-                else:
-                    res.append((torch.cat((q, tracked_pairs[b][0])), torch.cat((g, tracked_pairs[b][1]))))
-            return res
+            # box losses: detect pairs of every layer + tracked pairs of the late layers
+            p_boxes, t_boxes, p_layer = [boxes_all[lay_i, b, q_i]], [gt.boxes[g_i]], [lay_i]
+            if n_tr > 0 and len(gt) > 0:
+                w_pair = (has[None, :] & late[:, None]).to(boxes_all.dtype)           # (n_layers, n_tr) 0/1 weights
+                tb = gt.boxes[tr.matched_idx.clamp(min=0)]                            # (n_tr, 4)
+                pb = boxes_all[:, b, nd:n_q]                                          # (n_layers, n_tr, 4)
+                l1_t = (F.l1_loss(pb, tb[None].expand_as(pb), reduction="none").sum(-1) * w_pair).sum(1)
+                gi_t = ((1 - paired_giou(box_cxcywh_to_xyxy(pb), box_cxcywh_to_xyxy(tb)[None].expand_as(pb))) * w_pair).sum(1)
+                loss_l1 = loss_l1 + l1_t
+                loss_giou = loss_giou + gi_t
+            pb, tb = torch.cat(p_boxes), torch.cat(t_boxes)
+            l1_pair = F.l1_loss(pb, tb, reduction="none").sum(-1)
+            gi_pair = 1 - paired_giou(box_cxcywh_to_xyxy(pb), box_cxcywh_to_xyxy(tb))
+            loss_l1 = loss_l1.index_add(0, lay_i, l1_pair)
+            loss_giou = loss_giou.index_add(0, lay_i, gi_pair)
 
-        main_pairs = pairs_for(0)
-        loss_label = self.get_loss_label(model_outputs, gts, main_pairs)
-        loss_l1, loss_giou = self.get_loss_box(model_outputs, gts, main_pairs)
-        fw = self.frame_weights[frame_idx]
-        self.loss["box_l1_loss"] = self.loss["box_l1_loss"] + loss_l1 * fw
-        self.loss["box_giou_loss"] = self.loss["box_giou_loss"] + loss_giou * fw
-        self.loss["label_focal_loss"] = self.loss["label_focal_loss"] + loss_label * fw
-        self.log[f"frame{frame_idx}_box_l1_loss"] = loss_l1.detach()
-        self.log[f"frame{frame_idx}_box_giou_loss"] = loss_giou.detach()
-        self.log[f"frame{frame_idx}_label_focal_loss"] = loss_label.detach()
-        self.n_gts.append(sum(len(g) for g in gts))
-
-        if self.aux_loss:
-            for i, aux in enumerate(model_outputs["aux_outputs"]):
-                pairs = pairs_for(i + 1)
-                a_label = self.get_loss_label(aux, gts, pairs)
-                a_l1, a_giou = self.get_loss_box(aux, gts, pairs)
-                w = fw * self.aux_weights[i]
-                self.loss["aux_box_l1_loss"] = self.loss["aux_box_l1_loss"] + a_l1 * w
-                self.loss["aux_box_giou_loss"] = self.loss["aux_box_giou_loss"] + a_giou * w
-                self.loss["aux_label_focal_loss"] = self.loss["aux_label_focal_loss"] + a_label * w
-
-        # detections nobody claimed, handed to the query updater
-        unmatched = []
-        n_det_out = len(model_outputs["det_query_embed"])
-        for b in range(B):
-            taken = torch.zeros((n_det_out,), dtype=torch.bool, device=dev)
-            q_all = main_pairs[b][0]
-            taken[q_all[q_all < n_det_out]] = True
-            idx = torch.nonzero(~taken).squeeze(1)
+            # detections nobody claimed (host knows the matched detect queries of the last layer)
+            taken = set(int(q) for q in main_q[b][0])
+            free_q = torch.as_tensor([q for q in range(n_det_out) if q not in taken], dtype=torch.long).to(dev)
             d = TrackInstances(hidden_dim=model_outputs["outputs"].shape[-1],
                                num_classes=model_outputs["pred_logits"].shape[-1]).to(dev)
-            d.ref_pts = model_outputs["init_ref_pts"][b][idx]
-            d.output_embed = model_outputs["outputs"][b][idx]
-            d.logits = model_outputs["pred_logits"][b][idx]
-            d.boxes = model_outputs["pred_bboxes"][b][idx]
-            queries = model_outputs["aux_outputs"][-1]["queries"][b][idx]
+            d.ref_pts = model_outputs["init_ref_pts"][b][free_q]
+            d.output_embed = model_outputs["outputs"][b][free_q]
+            d.logits = model_outputs["pred_logits"][b][free_q]
+            d.boxes = model_outputs["pred_bboxes"][b][free_q]
+            queries = model_outputs["aux_outputs"][-1]["queries"][b][free_q]
             d.query_embed = queries if self.use_dab else torch.cat(
-                (model_outputs["det_query_embed"][idx][:, :self.hidden_dim], queries), dim=-1)
-            d.ids = -torch.ones((len(idx),), dtype=torch.long, device=dev)
-            d.matched_idx = -torch.ones((len(idx),), dtype=torch.long, device=dev)
-            d.iou = torch.zeros((len(idx),), dtype=torch.float, device=dev)
+                (model_outputs["det_query_embed"][free_q][:, :self.hidden_dim], queries), dim=-1)
+            d.ids = -torch.ones((len(free_q),), dtype=torch.long, device=dev)
+            d.matched_idx = -torch.ones((len(free_q),), dtype=torch.long, device=dev)
+            d.iou = torch.zeros((len(free_q),), dtype=torch.float, device=dev)
             unmatched.append(d)
 
-        for b in range(B):
-            tracked_instances[b] = tracked_instances[b].to(dev)
-            for tr in (new_tracks[b], tracked_instances[b]):
-                has = tr.matched_idx >= 0
-                if len(tr) > 0:
-                    iou = box_iou_union(box_cxcywh_to_xyxy(tr.boxes[has]),
-                                        box_cxcywh_to_xyxy(gts[b].boxes[tr.matched_idx[has]]))[0]
-                    tr.iou[has] = torch.diag(iou)
+            # IoU of every track with the ground truth it owns (kept where it owns none)
+            tracked_instances[b] = tr = tr.to(dev)
+            if len(gt) > 0:
+                if n_main > 0:
+                    nt.iou = paired_iou(box_cxcywh_to_xyxy(nt.boxes), box_cxcywh_to_xyxy(gt.boxes[nt.matched_idx]))
+                if n_tr > 0:
+                    has = tr.matched_idx >= 0
+                    iou = paired_iou(box_cxcywh_to_xyxy(tr.boxes), box_cxcywh_to_xyxy(gt.boxes[tr.matched_idx.clamp(min=0)]))
+                    tr.iou = torch.where(has, iou, tr.iou)
+            new_tracks.append(nt)
+
+        fw = self.frame_weights[frame_idx]
+        self.loss["box_l1_loss"] = self.loss["box_l1_loss"] + loss_l1[0] * fw
+        self.loss["box_giou_loss"] = self.loss["box_giou_loss"] + loss_giou[0] * fw
+        self.loss["label_focal_loss"] = self.loss["label_focal_loss"] + loss_label[0] * fw
+        self.log[f"frame{frame_idx}_box_l1_loss"] = loss_l1[0].detach()
+        self.log[f"frame{frame_idx}_box_giou_loss"] = loss_giou[0].detach()
+        self.log[f"frame{frame_idx}_label_focal_loss"] = loss_label[0].detach()
+        self.n_gts.append(sum(n_gt_list))
+        if self.aux_loss and n_layers > 1:
+            aw = torch.as_tensor(self.aux_weights[:n_layers - 1], dtype=loss_l1.dtype, device=dev) * fw
+            self.loss["aux_box_l1_loss"] = self.loss["aux_box_l1_loss"] + (loss_l1[1:] * aw).sum()
+            self.loss["aux_box_giou_loss"] = self.loss["aux_box_giou_loss"] + (loss_giou[1:] * aw).sum()
+            self.loss["aux_label_focal_loss"] = self.loss["aux_label_focal_loss"] + (loss_label[1:] * aw).sum()
         return tracked_instances, new_tracks, unmatched
 
     def update_tracked_instances(self, model_outputs: dict, tracked_instances: List[TrackInstances]):
+        """Refresh the carried tracks from their query slots.  Padded slots (other clips of the batch carrying
+        more tracks) sit behind the real ones, so a slice equals the reference's ``[~query_mask]`` selection."""
         nd = self.n_det_queries
         for b, tr in enumerate(tracked_instances):
-            if len(tr) > 0:
-                keep = ~model_outputs["query_mask"][b][nd:]
-                tr.boxes = model_outputs["pred_bboxes"][b][nd:][keep]
-                tr.logits = model_outputs["pred_logits"][b][nd:][keep]
-                tr.output_embed = model_outputs["outputs"][b][nd:][keep]
+            n = len(tr)
+            if n > 0:
+                tr.boxes = model_outputs["pred_bboxes"][b][nd:nd + n]
+                tr.logits = model_outputs["pred_logits"][b][nd:nd + n]
+                tr.output_embed = model_outputs["outputs"][b][nd:nd + n]
                 tr.matched_idx = torch.zeros((0,), dtype=tr.matched_idx.dtype)
                 tr.labels = torch.zeros((0,), dtype=tr.matched_idx.dtype)
         return tracked_instances
 
-    # ------------------------------------------------------------------ losses
+    # ------------------------------------------------------------------ reference-shaped single-layer losses
     def get_loss_label(self, outputs, gt_trackinstances: List[TrackInstances], idx_to_gts_idx):
         logits, labels = [], []
         for b, gt in enumerate(gt_trackinstances):
@@ -255,6 +295,45 @@ class ClipCriterion:
         loss_l1 = F.l1_loss(pred, tgt, reduction="none").sum()
         loss_giou = (1 - torch.diag(generalized_box_iou(box_cxcywh_to_xyxy(pred), box_cxcywh_to_xyxy(tgt)))).sum()
         return loss_l1, loss_giou
+
+
+def paired_iou(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """IoU of xyxy boxes paired along the leading dims (the diagonal of box_iou_union, without the matrix)."""
+    lt = torch.max(a[..., :2], b[..., :2])
+    rb = torch.min(a[..., 2:], b[..., 2:])
+    wh = (rb - lt).clamp(min=0)
+    inter = wh[..., 0] * wh[..., 1]
+    area_a = (a[..., 2] - a[..., 0]) * (a[..., 3] - a[..., 1])
+    area_b = (b[..., 2] - b[..., 0]) * (b[..., 3] - b[..., 1])
+    return inter / (area_a + area_b - inter)
+
+
+def paired_giou(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """Generalised IoU of paired xyxy boxes: elementwise the same arithmetic as diag(generalized_box_iou)."""
+    lt = torch.max(a[..., :2], b[..., :2])
+    rb = torch.min(a[..., 2:], b[..., 2:])
+    wh = (rb - lt).clamp(min=0)
+    inter = wh[..., 0] * wh[..., 1]
+    area_a = (a[..., 2] - a[..., 0]) * (a[..., 3] - a[..., 1])
+    area_b = (b[..., 2] - b[..., 0]) * (b[..., 3] - b[..., 1])
+    union = area_a + area_b - inter
+    iou = inter / union
+    lt_h = torch.min(a[..., :2], b[..., :2])
+    rb_h = torch.max(a[..., 2:], b[..., 2:])
+    wh_h = (rb_h - lt_h).clamp(min=0)
+    hull = wh_h[..., 0] * wh_h[..., 1]
+    return iou - (hull - union) / hull
+
+
+def sigmoid_focal_loss_per_layer(inputs, targets, alpha: float = 0.25, gamma: float = 2):
+    """Focal loss of stacked layers: (n_layers, Nq, K) -> (n_layers,) (mean over classes, sum over queries)."""
+    prob = inputs.sigmoid()
+    ce = F.binary_cross_entropy_with_logits(inputs, targets, reduction="none")
+    p_t = prob * targets + (1 - prob) * (1 - targets)
+    loss = ce * ((1 - p_t) ** gamma)
+    if alpha >= 0:
+        loss = (alpha * targets + (1 - alpha) * (1 - targets)) * loss
+    return loss.mean(2).sum(1)
 
 
 def sigmoid_focal_loss(inputs, targets, alpha: float = 0.25, gamma: float = 2):

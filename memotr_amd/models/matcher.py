@@ -40,6 +40,40 @@ class HungarianMatcher(nn.Module):
         cost_giou = -generalized_box_iou(box_cxcywh_to_xyxy(pred_boxes), box_cxcywh_to_xyxy(tgt_boxes))
         return self.cost_bbox * cost_bbox + self.cost_class * cost_class + self.cost_giou * cost_giou
 
+    @torch.no_grad()
+    def cost_matrix_stacked(self, pred_logits: torch.Tensor, pred_boxes: torch.Tensor, tgt_labels: torch.Tensor,
+                            tgt_boxes: torch.Tensor) -> torch.Tensor:
+        """Focal-style cost of several decoder layers at once: (n_layers, Q, K) / (n_layers, Q, 4) against (T,) /
+        (T, 4) -> (n_layers, Q, T).  Elementwise the same arithmetic as ``cost_matrix`` per layer."""
+        prob = pred_logits.sigmoid()
+        alpha, gamma = 0.25, 2.0
+        neg = (1 - alpha) * (prob ** gamma) * (-(1 - prob + 1e-8).log())
+        pos = alpha * ((1 - prob) ** gamma) * (-(prob + 1e-8).log())
+        cost_class = pos[..., tgt_labels] - neg[..., tgt_labels]
+        cost_bbox = (pred_boxes[:, :, None, :] - tgt_boxes[None, None, :, :]).abs().sum(-1)
+        a = box_cxcywh_to_xyxy(pred_boxes)[:, :, None, :]
+        b = box_cxcywh_to_xyxy(tgt_boxes)[None, None, :, :]
+        lt = torch.max(a[..., :2], b[..., :2])
+        rb = torch.min(a[..., 2:], b[..., 2:])
+        wh = (rb - lt).clamp(min=0)
+        inter = wh[..., 0] * wh[..., 1]
+        union = (a[..., 2] - a[..., 0]) * (a[..., 3] - a[..., 1]) + (b[..., 2] - b[..., 0]) * (b[..., 3] - b[..., 1]) - inter
+        iou = inter / union
+        wh_h = (torch.max(a[..., 2:], b[..., 2:]) - torch.min(a[..., :2], b[..., :2])).clamp(min=0)
+        hull = wh_h[..., 0] * wh_h[..., 1]
+        giou = iou - (hull - union) / hull
+        return self.cost_bbox * cost_bbox + self.cost_class * cost_class + self.cost_giou * (-giou)
+
+    @staticmethod
+    def solve(cost):
+        """One (Q, T) assignment problem on the host (numpy array or CPU tensor)."""
+        import numpy as np
+        c = np.asarray(cost)
+        if c.size == 0:
+            return np.zeros((0,), dtype=np.int64), np.zeros((0,), dtype=np.int64)
+        i, j = linear_sum_assignment(c)
+        return i.astype(np.int64), j.astype(np.int64)
+
     @staticmethod
     def solve_many(costs: Sequence[torch.Tensor]) -> List[Tuple[torch.Tensor, torch.Tensor]]:
         """Solve every (Q_i, T_i) assignment problem with a single device->host transfer."""

@@ -69,7 +69,8 @@ class QueryUpdater(nn.Module):
             scores = torch.max(logits_to_scores(t.logits), dim=1).values
             is_pos = scores > self.update_threshold
             pos_col = is_pos.reshape(-1, 1)
-            t.ref_pts[is_pos] = inverse_sigmoid(t[is_pos].boxes.detach().clone())
+            # (masked assignments of the reference are written as selects: no boolean-index synchronisation)
+            t.ref_pts = torch.where(pos_col, inverse_sigmoid(t.boxes.detach()), t.ref_pts)
 
             query_pos = self.query_pos_head(pos_to_pos_embed(t.ref_pts.sigmoid(), num_pos_feats=C // 2))
             out_embed = t.output_embed
@@ -89,12 +90,12 @@ class QueryUpdater(nn.Module):
             t.last_output = t.last_output * ~pos_col + out_embed * pos_col
 
             if self.use_dab:
-                t.query_embed[is_pos] = query_feat[is_pos]
+                t.query_embed = torch.where(pos_col, query_feat, t.query_embed)
             else:
-                t.query_embed[:, C:][is_pos] = query_feat[is_pos]
                 refreshed = self.norm_pos(t.query_embed[:, :C]
                                           + self.linear_pos2(self.activation(self.linear_pos1(out_embed))))
-                t.query_embed[:, :C][is_pos] = refreshed[is_pos]
+                t.query_embed = torch.cat((torch.where(pos_col, refreshed, t.query_embed[:, :C]),
+                                           torch.where(pos_col, query_feat, t.query_embed[:, C:])), dim=-1)
         return tracks
 
     # ------------------------------------------------------------------ track selection
@@ -136,7 +137,7 @@ class QueryUpdater(nn.Module):
                 active = cat(cat(previous_tracks[b], new_tracks[b]), unmatched_dets[b])
                 scores = torch.max(logits_to_scores(active.logits), dim=1).values
                 active = active[(scores > self.update_threshold) | (active.ids >= 0)]
-                active.ids[active.iou < 0.5] = -1
+                active.ids = torch.where(active.iou < 0.5, torch.full_like(active.ids, -1), active.ids)
             else:
                 active = cat(previous_tracks[b], new_tracks[b])
                 active = active[(active.iou > 0.5) & (active.ids >= 0)]

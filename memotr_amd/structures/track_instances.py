@@ -61,6 +61,9 @@ class TrackInstances:
             if item >= n or item < -n:
                 raise IndexError("TrackInstances index out of range!")
             item = slice(item, None, n)
+        if torch.is_tensor(item) and item.dtype == torch.bool:
+            # one nonzero (one device sync) for all fields instead of one per boolean-indexed field
+            item = item.nonzero().squeeze(1)
         res = self._blank_like()
         for k, v in vars(self).items():
             if hasattr(v, "__getitem__") and v.shape[0] != 0:
