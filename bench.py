@@ -44,6 +44,11 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores")
+    # BASELINE.json configs 4 / 5 (secondary; the default line is config 2: DanceTrack, fp32, no checkpointing)
+    ap.add_argument("--config", default="dancetrack", choices=["dancetrack", "mot17", "bdd100k"])
+    ap.add_argument("--use-checkpoint", action="store_true", help="activation checkpointing (CHECKPOINT_LEVEL 2)")
+    ap.add_argument("--clip-len", type=int, default=0, help="0 = longest clip of the config")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="bf16 = autocast extension (config 5)")
     return ap.parse_args()
 
 
@@ -277,8 +282,13 @@ def main():
     if args.workload == "msda":
         result = run_msda(args, rank, world)
     elif args.workload == "train":
+        from memotr_amd import configs as C
         from memotr_amd.train_bench import run_train
-        result = run_train(args, rank, world)
+        cfg = {"dancetrack": C.dancetrack_config, "mot17": C.mot17_config, "bdd100k": C.bdd100k_config}[args.config](
+            USE_CHECKPOINT=args.use_checkpoint)
+        hw = (720, 1280) if args.config == "bdd100k" else (800, 1333)
+        result = run_train(args, rank, world, clip_len=args.clip_len or max(cfg["SAMPLE_LENGTHS"]), height=hw[0],
+                           width=hw[1], config=cfg, dtype=args.dtype)
         if rank == 0:   # the kernel roofline and the CPU fallback baseline ride along on rank 0
             k = run_msda_kernels_only(args)
             result["roofline"] = k["roofline"]

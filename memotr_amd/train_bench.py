@@ -14,7 +14,7 @@ import torch
 
 
 def run_train(args, rank: int, world: int, clip_len: int = None, height: int = 800, width: int = 1333,
-              n_gts: int = 10, config: dict = None):
+              n_gts: int = 10, config: dict = None, dtype: str = "f32"):
     from .configs import dancetrack_config
     from .engine import build_optimizer, clip_forward_backward, clip_to_device, make_synthetic_clip, optimizer_step
     from .models import build_model
@@ -41,7 +41,11 @@ def run_train(args, rank: int, world: int, clip_len: int = None, height: int = 8
     batch = clip_to_device(make_synthetic_clip(clip_len, height, width, n_gts, seed=cfg["SEED"] + rank), dev)
 
     def step():
-        loss, _ = clip_forward_backward(model, criterion, batch, dev, use_dab=cfg["USE_DAB"])
+        if dtype == "bf16":     # extension: bf16 GEMMs/convs/value under autocast, fp32 master weights and optimizer
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss, _ = clip_forward_backward(model, criterion, batch, dev, use_dab=cfg["USE_DAB"])
+        else:
+            loss, _ = clip_forward_backward(model, criterion, batch, dev, use_dab=cfg["USE_DAB"])
         optimizer_step(model, optimizer, cfg["CLIP_MAX_NORM"])
         return loss
 
@@ -68,8 +72,9 @@ def run_train(args, rank: int, world: int, clip_len: int = None, height: int = 8
     return {
         "metric": "train_frames_per_sec", "value": world * clip_len * args.steps / dt, "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"train_dancetrack.yaml clip step: R50 + 6-enc/6-dec deformable transformer + query "
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+        "config": {"workload": f"train_{cfg['DATASET'].lower()}.yaml clip step"
+                               f"{' (--use-checkpoint)' if cfg['USE_CHECKPOINT'] else ''}: R50 + 6-enc/6-dec deformable transformer + query "
                                f"updater, clip length {clip_len}, {height}x{width} frames, bs=1/GPU, {n_gts} GT "
                                f"tracks, AdamW, grad-clip 0.1, random-init weights",
                    "parallelism": f"dp{world}", "trainable_params": n_params,

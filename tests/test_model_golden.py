@@ -286,3 +286,61 @@ def test_sequence_tracker_reproduces_the_submit_loop(monkeypatch):
             assert int(f) == i + 1 and int(tid) == int(ids[keep][0])
     js = st.bdd_frame_result(1, out, "a/b/video-0000001.jpg")
     assert js["frameIndex"] == 1 and len(js["labels"]) == len(out) and js["name"] == "video-0000001.jpg"
+
+
+def test_activation_checkpointing_matches_plain_train_step(monkeypatch):
+    """--use-checkpoint (CHECKPOINT_LEVEL 2: backbone + whole encoder + every decoder layer, all
+    use_reentrant=False; reference memotr.py:102-103, deformable_transformer.py:223-226, deformable_decoder.py:104-118):
+    same loss and gradients as the plain step (the reference run gives bit-identical values)."""
+    from memotr_amd.engine import clip_forward_backward
+    from memotr_amd.models.criterion import build as build_criterion
+    patch_operator(monkeypatch)
+    g = load_model_golden("M6_train_step")
+    cfg = small_config()
+    cfg.update(MATCH_COST_CLASS=2, MATCH_COST_BBOX=5, MATCH_COST_GIOU=2, LOSS_WEIGHT_FOCAL=2, LOSS_WEIGHT_L1=5,
+               LOSS_WEIGHT_GIOU=2, AUX_LOSS_WEIGHT=[1.0], SAMPLE_LENGTHS=[2, 3, 4, 5])
+    batch = {"imgs": [[t(g[f"img{i}"]) for i in range(3)]],
+             "infos": [[{"ids": t(g[f"gt{i}_ids"]), "labels": torch.zeros(6, dtype=torch.long),
+                         "boxes": t(g[f"gt{i}_boxes"])} for i in range(3)]]}
+    results = []
+    for level in (None, 1, 2, 3):
+        model = build_memotr(g).train()
+        if level is not None:
+            model.use_checkpoint = True
+            model.checkpoint_level = level
+            tr = model.transformer
+            tr.use_checkpoint, tr.checkpoint_level = True, level
+            tr.encoder.use_checkpoint = level == 1
+            tr.decoder.use_checkpoint = True
+        loss, _ = clip_forward_backward(model, build_criterion(cfg), batch, torch.device("cpu"))
+        gn = torch.sqrt(sum((p.grad ** 2).sum() for p in model.parameters() if p.grad is not None))
+        results.append((float(loss.detach()), float(gn)))
+    for loss, gn in results[1:]:
+        assert loss == pytest.approx(results[0][0], rel=1e-6) and gn == pytest.approx(results[0][1], rel=1e-5)
+    assert results[0][0] == pytest.approx(float(g["total_loss"]), rel=2e-4)
+
+
+def test_bdd100k_eight_class_model_runs_two_frames(monkeypatch):
+    """BDD100K config (8 classes): heads, criterion one-hot and track logits widen to K=8 (memotr.py:291-297)."""
+    from memotr_amd.configs import bdd100k_config
+    from memotr_amd.engine import clip_forward_backward, make_synthetic_clip
+    from memotr_amd.models.backbone import BackboneWithPE
+    from memotr_amd.models.criterion import build as build_criterion
+    from memotr_amd.models.deformable_transformer import build as build_tr
+    from memotr_amd.models.memotr import DATASET_NUM_CLASSES, MeMOTR
+    from memotr_amd.models.position_embedding import build as build_pe
+    from memotr_amd.models.query_updater import build as build_qu
+    patch_operator(monkeypatch)
+    cfg = bdd100k_config(HIDDEN_DIM=64, FFN_DIM=128, NUM_ENC_LAYERS=1, NUM_DEC_LAYERS=2, NUM_DET_QUERIES=20,
+                         DEVICE="cpu", AUX_LOSS_WEIGHT=[1.0])
+    K = DATASET_NUM_CLASSES[cfg["DATASET"]]
+    assert K == 8 and cfg["MISS_TOLERANCE"] == 10 and cfg["SAMPLE_LENGTHS"] == [2, 3, 4]
+    torch.manual_seed(0)
+    model = MeMOTR(backbone=BackboneWithPE(TinyBackbone(), build_pe(cfg)), transformer=build_tr(cfg),
+                   query_updater=build_qu(cfg), num_classes=K, n_det_queries=20, n_feature_levels=4, hidden_dim=64,
+                   ffn_dim=128, dropout=0.0, use_dab=True).train()
+    batch = make_synthetic_clip(clip_len=2, height=96, width=160, n_gts=5, seed=3, num_classes=K)
+    loss, loss_dict = clip_forward_backward(model, build_criterion(cfg), batch, torch.device("cpu"))
+    assert torch.isfinite(loss) and set(loss_dict) >= {"label_focal_loss", "aux_box_giou_loss"}
+    assert model.class_embed[0].weight.shape == (8, 64)
+    assert all(p.grad is not None for p in model.parameters() if p.requires_grad)
