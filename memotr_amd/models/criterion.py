@@ -64,6 +64,8 @@ class ClipCriterion:
                 gts[b].ids, gts[b].labels, gts[b].boxes = info["ids"], info["labels"], info["boxes"]
                 gts[b] = gts[b].to(device)
             self.gt_trackinstances_list.append(gts)
+        if clip_len > len(self.frame_weights):     # clips longer than SAMPLE_LENGTHS (synthetic stress runs)
+            self.frame_weights = self.frame_weights + [1.0] * (clip_len - len(self.frame_weights))
         self.n_gts = []
         self.log = {}
         keys = _LOSS_KEYS + tuple("aux_" + k for k in _LOSS_KEYS) if self.aux_loss else _LOSS_KEYS
