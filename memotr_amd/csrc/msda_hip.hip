@@ -410,6 +410,161 @@ __global__ __launch_bounds__(256) void msda_fwd_d32_gather(
     }
 }
 
+// forward, variant 6: gather with the coarsest pyramid level resident in LDS.
+// The last level is tiny (13x21 pixels at 800x1333: 35 KB per head) yet receives 1/L of all corner reads.
+// A workgroup serves ONE (batch, head): it copies that head's last-level rows into LDS once and then walks
+// groups of 8 consecutive queries (a wavefront owns 8 queries x this head).  Points of the last level read
+// their corners with ds_read_b128 (the whole level is resident: no window placement, no fallback); all other
+// points take the buffer-load path of msda_fwd_d32_gather.  The level of point t is the same for every row,
+// so the LDS/global choice is a wave-uniform branch.
+struct GatherLdsPlan {
+    int px_last;     // H*W of the last level
+    int H_last, W_last;
+    int chunks8;     // chunks per XCD residue; a (batch, head) is split into 8*chunks8 chunks
+    int gpc;         // query groups (of 8) per chunk
+    int Gb;          // query groups per batch element = ceil(Lq / 8)
+    int n_blocks;    // N * M * 8 * chunks8
+};
+
+template <int PTS>
+__global__ __launch_bounds__(256) void msda_fwd_d32_gather_lds(
+    const float *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ lstart,
+    const float *__restrict__ loc, const float *__restrict__ attn, int N, int S, int M, int L, int Lq, int P,
+    float *__restrict__ out, unsigned value_bytes, const GatherLdsPlan gp) {
+    constexpr int D = 32;
+    __shared__ int s_H[kMaxLevels], s_W[kMaxLevels], s_start[kMaxLevels];
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    if (threadIdx.x < L) {
+        s_H[threadIdx.x] = (int)shapes[2 * threadIdx.x];
+        s_W[threadIdx.x] = (int)shapes[2 * threadIdx.x + 1];
+        s_start[threadIdx.x] = (int)lstart[threadIdx.x];
+    }
+    // block -> (xcd slab, batch, head, chunk): bid % 8 is the XCD, each XCD owns a contiguous eighth of the queries
+    const int bid = blockIdx.x;
+    if (bid >= gp.n_blocks) return;
+    const int xcd = bid & 7;
+    int r = bid >> 3;
+    const int m = r % M;
+    r /= M;
+    const int ci = r % gp.chunks8;
+    const int b = r / gp.chunks8;
+    const int chunk = xcd * gp.chunks8 + ci;
+    const int g_begin = chunk * gp.gpc;
+    const int g_end = (g_begin + gp.gpc < gp.Gb) ? g_begin + gp.gpc : gp.Gb;
+    __syncthreads();
+
+    const int LP = L * P;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane >> 3, sub = lane & 7;
+    const __amdgpu_buffer_rsrc_t vr = make_rsrc(value, value_bytes);
+    f32x4 *lvl_f4 = reinterpret_cast<f32x4 *>(s_dyn);
+    const unsigned zero_row = (unsigned)gp.px_last * 128u;
+    const int rec_stride = 2 * LP + 1;
+    u32x4 *rec = reinterpret_cast<u32x4 *>(s_dyn + (size_t)(gp.px_last + 1) * 128) + (size_t)(wave * 8 + grp) * rec_stride;
+    const unsigned row_base = ((unsigned)b * (unsigned)S * (unsigned)M + (unsigned)m) * (D * 4u);
+    const unsigned pix_stride = (unsigned)M * (D * 4u);
+
+    // ---- resident level: coalesced 128-byte rows of this head ----
+    if (g_begin < g_end) {
+        const unsigned lvl_off = row_base + (unsigned)s_start[L - 1] * pix_stride;
+        const int n = gp.px_last * 8;
+        for (int i0 = threadIdx.x; i0 < n; i0 += 256 * 4) {
+            f32x4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = i0 + j * 256;
+                v[j] = buf_load_f4(vr, i < n ? lvl_off + (unsigned)(i >> 3) * pix_stride + (unsigned)(i & 7) * 16u
+                                             : kOobOffset);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = i0 + j * 256;
+                if (i < n) lvl_f4[i] = v[j];
+            }
+        }
+        if (threadIdx.x < 8) lvl_f4[gp.px_last * 8 + threadIdx.x] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+
+    const unsigned lane_off = (unsigned)sub * 16u;
+    const int last = L - 1;
+    for (int g = g_begin + wave; g < g_end; g += 4) {
+        const int q = g * 8 + grp;
+        const bool row_ok = q < Lq;
+        const long pm = (((long)b * Lq + (row_ok ? q : Lq - 1)) * M + m);
+        // ---- stage: each lane prepares LP/8 records of its row ----
+        for (int t = sub; t < LP; t += 8) {
+            const int l = t / P;
+            const f32x2 xy = *reinterpret_cast<const f32x2 *>(loc + (pm * LP + t) * 2);
+            const float a = attn[pm * LP + t];
+            const int H = s_H[l], W = s_W[l];
+            const Sample<float> s = sample_setup<float>(xy.x, xy.y, H, W);
+            const float hh = 1.f - s.lh, hw = 1.f - s.lw;
+            const int h0 = s.h_low, w0 = s.w_low, h1 = h0 + 1, w1 = w0 + 1;
+            const bool live = s.gate && row_ok;
+            const bool okh0 = live && h0 >= 0, okh1 = live && h1 <= H - 1;
+            const bool okw0 = w0 >= 0, okw1 = w1 <= W - 1;
+            u32x4 off;
+            if (l == last) {   // LDS byte offsets inside the resident level
+                const unsigned c00 = (unsigned)(h0 * W + w0) * 128u;
+                off.x = (okh0 && okw0) ? c00 : zero_row;
+                off.y = (okh0 && okw1) ? c00 + 128u : zero_row;
+                off.z = (okh1 && okw0) ? c00 + (unsigned)W * 128u : zero_row;
+                off.w = (okh1 && okw1) ? c00 + (unsigned)W * 128u + 128u : zero_row;
+            } else {
+                const unsigned o00 = row_base + (unsigned)(s_start[l] + h0 * W + w0) * pix_stride;
+                off.x = (okh0 && okw0) ? o00 : kOobOffset;
+                off.y = (okh0 && okw1) ? o00 + pix_stride : kOobOffset;
+                off.z = (okh1 && okw0) ? o00 + (unsigned)W * pix_stride : kOobOffset;
+                off.w = (okh1 && okw1) ? o00 + (unsigned)W * pix_stride + pix_stride : kOobOffset;
+            }
+            f32x4 w;
+            w.x = (hh * hw) * a;
+            w.y = (hh * s.lw) * a;
+            w.z = (s.lh * hw) * a;
+            w.w = (s.lh * s.lw) * a;
+            rec[2 * t] = off;
+            rec[2 * t + 1] = __builtin_bit_cast(u32x4, w);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int t0 = 0; t0 < LP; t0 += PTS) {
+            u32x4 o[PTS];
+            f32x4 w[PTS], v[PTS][4];
+#pragma unroll
+            for (int i = 0; i < PTS; ++i) {
+                const int t = t0 + i < LP ? t0 + i : LP - 1;
+                o[i] = rec[2 * t];
+                w[i] = __builtin_bit_cast(f32x4, rec[2 * t + 1]);
+                if (t0 + i >= LP) w[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int i = 0; i < PTS; ++i) {
+                const int t = t0 + i < LP ? t0 + i : LP - 1;
+                if (t / P == last) {     // wave-uniform
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        v[i][k] = *reinterpret_cast<const f32x4 *>(s_dyn + (o[i][k] + lane_off));
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[i][k] = buf_load_f4(vr, o[i][k] + lane_off);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < PTS; ++i) {
+                acc += w[i].x * v[i][0];
+                acc += w[i].y * v[i][1];
+                acc += w[i].z * v[i][2];
+                acc += w[i].w * v[i][3];
+            }
+        }
+        if (row_ok) *reinterpret_cast<f32x4 *>(out + pm * D + sub * 4) = acc;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // DPP butterfly over the 8 lanes that own one row.
 __device__ __forceinline__ float sum8(float x) {
     x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
@@ -1296,6 +1451,38 @@ int forward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart, 
         return check_launch("msda_fwd_generic");
     }
     if constexpr (sizeof(TV) == 4 && sizeof(TC) == 4) {
+        if (variant == 6 || variant == 7) {
+            // gather with the last level resident in LDS: needs the host shapes, a last level of <= 48 KB per head
+            // and enough rows to amortise the fill
+            const long px_last = shapes_host ? shapes_host[2 * (L - 1)] * shapes_host[2 * (L - 1) + 1] : 0;
+            if (shapes_host && L >= 2 && px_last > 0 && px_last * 128 <= 48 * 1024 && (long)N * Lq * M >= 1024) {
+                GatherLdsPlan gp;
+                gp.px_last = (int)px_last;
+                gp.H_last = (int)shapes_host[2 * (L - 1)];
+                gp.W_last = (int)shapes_host[2 * (L - 1) + 1];
+                gp.Gb = (Lq + 7) / 8;
+                int chunks8 = opt_fwd_grid_mult.load() / 4;   // grid_mult 32 -> 8 chunks per XCD -> 64 chunks per (batch, head)
+                if (chunks8 < 1) chunks8 = 1;
+                while (chunks8 > 1 && (long)8 * chunks8 * 8 > gp.Gb) chunks8 >>= 1;   // at least ~8 groups per chunk
+                gp.chunks8 = chunks8;
+                gp.gpc = (gp.Gb + 8 * chunks8 - 1) / (8 * chunks8);
+                gp.n_blocks = N * M * 8 * chunks8;
+                const size_t lds = (size_t)(px_last + 1) * 128 + (size_t)32 * (2 * L * P + 1) * 16;
+                if (variant == 7) {
+                    g_kernel = "msda_fwd_d32_gather_lds<2>";
+                    hipLaunchKernelGGL(msda_fwd_d32_gather_lds<2>, dim3(gp.n_blocks), dim3(256), lds, stream,
+                                       (const float *)value, shapes, lstart, (const float *)loc, (const float *)attn, N,
+                                       S, M, L, Lq, P, (float *)out, (unsigned)value_bytes, gp);
+                } else {
+                    g_kernel = "msda_fwd_d32_gather_lds<4>";
+                    hipLaunchKernelGGL(msda_fwd_d32_gather_lds<4>, dim3(gp.n_blocks), dim3(256), lds, stream,
+                                       (const float *)value, shapes, lstart, (const float *)loc, (const float *)attn, N,
+                                       S, M, L, Lq, P, (float *)out, (unsigned)value_bytes, gp);
+                }
+                return check_launch(g_kernel);
+            }
+            variant = 3;
+        }
         if (variant == 5) {
             TilePlan pl;
             size_t lds = 0;

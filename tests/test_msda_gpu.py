@@ -223,6 +223,13 @@ def test_region_tiled_kernels_match_oracle(msda, hip_lib, case, margin):
         out = run_fwd(msda, g)
         assert hip_lib.last_kernel() == "msda_fwd_d32_tile"
         np.testing.assert_allclose(out, ref_out, **tol(np.float32, 2))
+        for variant in (6, 7):                     # gather with the coarsest level resident in LDS
+            hip_lib.set_option("fwd_variant", variant)
+            out = run_fwd(msda, g)
+            rows = g["loc"].shape[0] * g["loc"].shape[1] * g["loc"].shape[2]
+            if rows >= 1024 and len(shapes) >= 2:
+                assert "gather_lds" in hip_lib.last_kernel()
+            np.testing.assert_allclose(out, ref_out, **tol(np.float32, 2))
         # 5: float LDS atomics; 6/7: fixed-point window accumulation (4 / 8 points in flight)
         for variant, kernel in ((5, "msda_bwd_d32_tile"), (6, "msda_bwd_d32_tile_q<4>"), (7, "msda_bwd_d32_tile_q<8>")):
             hip_lib.set_option("bwd_variant", variant)
@@ -259,11 +266,11 @@ def test_full_size_specialised_equals_generic(msda, hip_lib, full_inputs):
     args = (x["value"], x["shapes"], x["level_start"], x["loc"], x["attn"])
     hip_lib.set_option("fwd_variant", 1)
     ref = msda.ms_deform_attn_forward(*args, 64)
-    for v in (2, 3, 4, 5):
+    for v in (2, 3, 4, 5, 6, 7):
         hip_lib.set_option("fwd_variant", v)
         out = msda.ms_deform_attn_forward(*args, 64)
         assert "d32" in hip_lib.last_kernel()
-        assert (v == 5) == ("tile" in hip_lib.last_kernel())
+        assert (v == 5) == ("tile" in hip_lib.last_kernel()) and (v >= 6) == ("gather_lds" in hip_lib.last_kernel())
         torch.testing.assert_close(out, ref, rtol=1e-4, atol=2e-5)
     hip_lib.set_option("bwd_variant", 1)
     ref_g = msda.ms_deform_attn_backward(*args, x["grad_out"], 64)

@@ -52,13 +52,13 @@ def main():
             ref = (call.out.clone(), call.gv.clone(), call.gl.clone(), call.ga.clone())
             for v in fv:
                 combos = [(256, 8)] if v == 1 else itertools.product(blocks, gms)
-                if v in (5, 6):
+                if v == 5:
                     if nq is not None:
                         continue
                     combos = [(256, mg) for mg in margins]
                 for blk, gm in combos:
                     _lib.set_option("fwd_variant", v); _lib.set_option("fwd_block", blk)
-                    _lib.set_option("fwd_tile_margin" if v in (5, 6) else "fwd_grid_mult", gm)
+                    _lib.set_option("fwd_tile_margin" if v == 5 else "fwd_grid_mult", gm)
                     call.out.zero_(); call.fwd(); torch.cuda.synchronize()
                     err = float((call.out - ref[0]).abs().max())
                     ms = time_kernel(call.fwd, iters=30 if nq is None else 100)
