@@ -7,6 +7,7 @@ import torch.nn as nn
 from torch.utils.checkpoint import checkpoint
 
 from ..modules import MSDeformAttn
+from ..modules.linear import long_linear
 from .utils import get_activation_layer, get_clones
 
 
@@ -73,8 +74,8 @@ class DeformableEncoderLayer(nn.Module):
         return tensor if pos is None else tensor + pos
 
     def forward_ffn(self, src):
-        hidden = self.dropout2(self.activation(self.linear1(src)))
-        return self.norm2(src + self.dropout3(self.linear2(hidden)))
+        hidden = self.dropout2(self.activation(long_linear(src, self.linear1.weight, self.linear1.bias)))
+        return self.norm2(src + self.dropout3(long_linear(hidden, self.linear2.weight, self.linear2.bias)))
 
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None):
         attn = self.self_attn(self.with_pos_embed(src, pos), reference_points, src, spatial_shapes,

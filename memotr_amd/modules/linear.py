@@ -1,0 +1,65 @@
+"""Linear layers over the flattened pyramid (tens of thousands of rows).
+
+``y = x W^T + b`` with ``x`` of shape (..., K) and M = prod(...) rows.  Forward and input gradient are ordinary
+GEMMs.  The weight gradient ``dW = dY^T X`` contracts over M (22,323 at 800x1333) into a small (N, K) output:
+a single GEMM call leaves most of the 256 CUs idle (measured on MI355X, fp32, hipBLASLt: 27 TFLOP/s for
+N = K = 256, 69 for 2048x256).  Splitting the contraction into row chunks -- one batched GEMM + a sum of the
+partial products -- keeps the chip busy: 64 / 111 TFLOP/s for the same shapes (tools/gemm_probe.py).
+Only the summation order of the fp32 partial products changes (relative difference ~3e-6).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+MIN_ROWS = 8192          # below this the plain GEMM is already fine (decoder-sized inputs)
+TARGET_CHUNKS = 24
+
+
+def _pick_chunks(rows: int) -> int:
+    for c in range(TARGET_CHUNKS, TARGET_CHUNKS + 24):      # prefer an exact divisor near the target
+        if rows % c == 0:
+            return c
+    for c in range(TARGET_CHUNKS - 1, 11, -1):
+        if rows % c == 0:
+            return c
+    return TARGET_CHUNKS
+
+
+class _SplitKLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, weight = ctx.saved_tensors
+        gx = gw = gb = None
+        K, N = weight.shape[1], weight.shape[0]
+        g2 = grad_out.reshape(-1, N)
+        cdt = g2.dtype                      # bf16 under autocast (forward ran in bf16), else the parameter dtype
+        if ctx.needs_input_grad[0]:
+            gx = (g2 @ weight.to(cdt)).view(x.shape).to(x.dtype)
+        if ctx.needs_input_grad[1]:
+            x2 = x.reshape(-1, K).to(cdt)
+            rows = x2.shape[0]
+            c = _pick_chunks(rows)
+            r = rows // c
+            main = r * c
+            gw = torch.bmm(g2[:main].view(c, r, N).transpose(1, 2), x2[:main].view(c, r, K)).sum(0)
+            if main < rows:
+                gw = gw + g2[main:].t() @ x2[main:]
+            gw = gw.to(weight.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g2.sum(0).to(weight.dtype)
+        return gx, gw, gb
+
+
+def long_linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor = None, min_rows: int = None) -> torch.Tensor:
+    """F.linear whose weight gradient uses a split contraction when x has many rows."""
+    rows = x.numel() // x.shape[-1]
+    if rows >= (MIN_ROWS if min_rows is None else min_rows) and torch.is_grad_enabled() and weight.requires_grad:
+        return _SplitKLinear.apply(x, weight, bias)
+    return F.linear(x, weight, bias)

@@ -18,6 +18,7 @@ from torch import nn
 from torch.nn.init import constant_, xavier_uniform_
 
 from ..functions import MSDeformAttnFunction
+from .linear import long_linear
 
 
 def _is_power_of_2(n) -> bool:
@@ -76,7 +77,7 @@ class MSDeformAttn(nn.Module):
         S = input_flatten.shape[1]
         M, L, P = self.n_heads, self.n_levels, self.n_points
 
-        value = self.value_proj(input_flatten)
+        value = long_linear(input_flatten, self.value_proj.weight, self.value_proj.bias)
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], 0.0)
         value = value.view(N, S, M, self.d_model // M)
@@ -85,7 +86,7 @@ class MSDeformAttn(nn.Module):
         n_off = M * L * P * 2
         w = torch.cat((self.sampling_offsets.weight, self.attention_weights.weight), 0)
         b = torch.cat((self.sampling_offsets.bias, self.attention_weights.bias), 0)
-        proj = F.linear(query, w, b)
+        proj = long_linear(query, w, b)
         if proj.dtype == torch.bfloat16:
             # bf16 mixed precision (no reference counterpart; policy in DESIGN.md): GEMMs and `value` in bf16,
             # sampling locations / attention weights / index arithmetic stay fp32
@@ -111,4 +112,4 @@ class MSDeformAttn(nn.Module):
 
         out = MSDeformAttnFunction.apply(value.contiguous(), input_spatial_shapes, input_level_start_index,
                                          loc.contiguous(), attn.contiguous(), self.im2col_step)
-        return self.output_proj(out)
+        return long_linear(out, self.output_proj.weight, self.output_proj.bias)

@@ -102,3 +102,25 @@ def test_pretrained_key_remap():
     assert torch.equal(out["feature_projs.0.0.weight"], torch.ones(2))
     assert torch.equal(out["backbone.backbone.backbone.conv1.weight"], torch.ones(3))
     assert "tgt_embed.weight" not in out and torch.equal(out["fresh"], torch.ones(1))
+
+
+def test_split_contraction_linear_matches_plain_linear():
+    """memotr_amd/modules/linear.py: only the weight-gradient summation order changes."""
+    from memotr_amd.modules.linear import _pick_chunks, long_linear
+    assert 22323 % _pick_chunks(22323) == 0 and 12 <= _pick_chunks(22323) <= 48
+    torch.manual_seed(0)
+    for rows in (1063 * 21, 1000 + 7):         # exact divisor / remainder rows
+        x = torch.randn(1, rows, 32, dtype=torch.float64, requires_grad=True)
+        w = torch.randn(48, 32, dtype=torch.float64, requires_grad=True)
+        b = torch.randn(48, dtype=torch.float64, requires_grad=True)
+        go = torch.randn(1, rows, 48, dtype=torch.float64)
+        y0 = F.linear(x, w, b)
+        g0 = torch.autograd.grad(y0, (x, w, b), go)
+        y1 = long_linear(x, w, b, min_rows=64)
+        assert y1.grad_fn.__class__.__name__.startswith("_SplitKLinear")
+        g1 = torch.autograd.grad(y1, (x, w, b), go)
+        assert torch.equal(y0, y1)
+        for a, c in zip(g0, g1):
+            torch.testing.assert_close(a, c, rtol=1e-12, atol=1e-10)
+    small = long_linear(torch.randn(4, 32, requires_grad=True), torch.randn(8, 32, requires_grad=True))
+    assert "SplitK" not in small.grad_fn.__class__.__name__
