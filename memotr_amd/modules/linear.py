@@ -61,5 +61,8 @@ def long_linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor = None
     """F.linear whose weight gradient uses a split contraction when x has many rows."""
     rows = x.numel() // x.shape[-1]
     if rows >= (MIN_ROWS if min_rows is None else min_rows) and torch.is_grad_enabled() and weight.requires_grad:
-        return _SplitKLinear.apply(x, weight, bias)
+        # 2-d in, 2-d out: the Function's output is then a fresh tensor (an N-d F.linear returns a view, and a
+        # view made inside a custom Function may not be modified in place -- the FFN applies ReLU in place)
+        y = _SplitKLinear.apply(x.reshape(rows, x.shape[-1]), weight, bias)
+        return y.view(*x.shape[:-1], weight.shape[0])
     return F.linear(x, weight, bias)
