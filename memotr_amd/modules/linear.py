@@ -60,7 +60,8 @@ class _SplitKLinear(torch.autograd.Function):
 def long_linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor = None, min_rows: int = None) -> torch.Tensor:
     """F.linear whose weight gradient uses a split contraction when x has many rows."""
     rows = x.numel() // x.shape[-1]
-    if rows >= (MIN_ROWS if min_rows is None else min_rows) and torch.is_grad_enabled() and weight.requires_grad:
+    if (rows >= (MIN_ROWS if min_rows is None else min_rows) and torch.is_grad_enabled() and weight.requires_grad
+            and x.dtype == weight.dtype and not torch.is_autocast_enabled()):   # mixed precision keeps the library path
         # 2-d in, 2-d out: the Function's output is then a fresh tensor (an N-d F.linear returns a view, and a
         # view made inside a custom Function may not be modified in place -- the FFN applies ReLU in place)
         y = _SplitKLinear.apply(x.reshape(rows, x.shape[-1]), weight, bias)
