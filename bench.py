@@ -287,6 +287,11 @@ def main():
         cfg = {"dancetrack": C.dancetrack_config, "mot17": C.mot17_config, "bdd100k": C.bdd100k_config}[args.config](
             USE_CHECKPOINT=args.use_checkpoint)
         hw = (720, 1280) if args.config == "bdd100k" else (800, 1333)
+        if hw != (800, 1333):
+            # MIOpen's immediate-mode heuristic picks slow solvers for the 736x1280 pyramid (8.9 vs 19.4 frames/s
+            # measured); the exhaustive find costs minutes once per process but is worth it there.  At 800x1344 both
+            # modes pick the same kernels, so the default line keeps the quick start-up.
+            os.environ.setdefault("MEMOTR_MIOPEN_FIND", "1")
         result = run_train(args, rank, world, clip_len=args.clip_len or max(cfg["SAMPLE_LENGTHS"]), height=hw[0],
                            width=hw[1], config=cfg, dtype=args.dtype)
         if rank == 0:   # the kernel roofline and the CPU fallback baseline ride along on rank 0

@@ -57,7 +57,16 @@ def timed_forward(frame, tracks):
     return srcs, masks, pos, qe, ref, qm
 
 
+import contextlib
+BF16 = os.environ.get("PHASE_BF16", "0") == "1"
+
+
 def step(profile):
+    with (torch.autocast("cuda", dtype=torch.bfloat16) if BF16 else contextlib.nullcontext()):
+        _step(profile)
+
+
+def _step(profile):
     tracks = TrackInstances.init_tracks(batch, hidden_dim=256, num_classes=1, device=dev, use_dab=True)
     criterion.init_a_clip(batch, 256, 1, dev)
     for t in range(T):
