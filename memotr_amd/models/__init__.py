@@ -1,4 +1,5 @@
-"""``build_model(config)`` -- same entry point as the reference's models/__init__.py:9-15."""
+"""Model factory with the reference's entry point name (models/__init__.py:9-15): ``build_model(config)``
+returns a MeMOTR on ``config["DEVICE"]`` (one GPU per process: the device index is the process rank)."""
 import torch
 
 from ..utils.utils import distributed_rank
@@ -6,10 +7,10 @@ from .memotr import MeMOTR
 from .memotr import build as build_memotr
 
 
+def _target_device(config: dict) -> torch.device:
+    on_gpu = config["DEVICE"] == "cuda" and config["AVAILABLE_GPUS"] is not None
+    return torch.device("cuda", distributed_rank()) if on_gpu else torch.device(config["DEVICE"])
+
+
 def build_model(config: dict) -> MeMOTR:
-    model = build_memotr(config=config)
-    if config["AVAILABLE_GPUS"] is not None and config["DEVICE"] == "cuda":
-        model.to(device=torch.device(config["DEVICE"], distributed_rank()))
-    else:
-        model.to(device=torch.device(config["DEVICE"]))
-    return model
+    return build_memotr(config=config).to(device=_target_device(config))

@@ -1,0 +1,1 @@
+"""Tensor / distributed helpers used by the per-frame path."""
