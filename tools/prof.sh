@@ -11,6 +11,12 @@ export TMPDIR=/tmp
 WORKLOAD=${2:-train}
 CMD="python bench.py --workload $WORKLOAD --steps 3 --warmup 2 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- $CMD > "$OUT/stats.log" 2>&1
+if [ "$WORKLOAD" = "train" ]; then
+  # counter passes serialise ~30k dispatches per step: only the stats pass for the full train step
+  python tools/prof_summary.py "$OUT" "$TAG" "$CMD"
+  mkdir -p gpurun_out/profiles && cp "$OUT"/stats/*kernel_stats.csv gpurun_out/profiles/${TAG}_kernel_stats.csv 2>/dev/null
+  rm -rf "$OUT"; exit 0
+fi
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o fetch -- $CMD > "$OUT/pmc_fetch.log" 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d "$OUT/pmc_write" -o write -- $CMD > "$OUT/pmc_write.log" 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc TCC_HIT_sum TCC_MISS_sum -d "$OUT/pmc_l2" -o l2 -- $CMD > "$OUT/pmc_l2.log" 2>&1

@@ -2,6 +2,7 @@
 """Condense rocprofv3 output dirs into profiles/<tag>_*.{md,json} (small, committed)."""
 import csv
 import glob
+import re
 import json
 import os
 import sys
@@ -43,7 +44,8 @@ def main():
                 dur = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
                 total_ns += dur
                 if "msda" in r["Kernel_Name"]:
-                    short = r["Kernel_Name"].split("::")[-1].split("(")[0]
+                    mm = re.search(r"msda_\w+(<[^>]*>)?", r["Kernel_Name"])
+                    short = mm.group(0) if mm else r["Kernel_Name"][:60]
                     groups[(short, int(r["Grid_Size_X"]), int(r["Workgroup_Size_X"]), int(r["VGPR_Count"]),
                             int(r["LDS_Block_Size"]))].append(dur)
         lines += ["", "## MSDeformAttn launches by launch shape", "",
@@ -66,7 +68,8 @@ def main():
                 if r.get("Counter_Name") != ctr:
                     continue
                 k = r.get("Kernel_Name", "")
-                k = k.split("::")[-1].split("(")[0] if "msda" in k else k[:60]
+                mm = re.search(r"msda_\w+(<[^>]*>)?", k)
+                k = mm.group(0) if mm else k[:60]
                 k = f"{k}@grid{r.get('Grid_Size_X', r.get('Grid_Size', '?'))}"
                 agg[k][0] += float(r.get("Counter_Value", 0))
                 agg[k][1] += 1
