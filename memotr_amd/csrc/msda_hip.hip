@@ -9,6 +9,12 @@
 //   host side models/ops/src/cuda/ms_deform_attn_cuda.cu:20-153
 // C ABI: include/msda_hip.h.  Design notes, byte counts and rooflines: DESIGN.md.
 //
+// Variant numbers (msda_set_option "fwd_variant" / "bwd_variant"; 0 = auto):
+//   forward : 1 generic | 2,3,4 d32 gather with 2,4,1 points in flight (3 = default for D = 32 fp32) |
+//             5 region-tiled LDS windows | 6,7 gather with the coarsest level resident in LDS
+//   backward: 1 generic (default unless tiled applies) | 2,3 d32 gather | 5 tiled, float LDS atomics |
+//             6,7 tiled, fixed-point LDS windows (6 = default for pyramid self-attention) | 90 ablation (no scatter)
+//
 // Kernel families
 //   *_generic   any D/L/P, f32 / f64 / bf16 storage: one thread per output scalar
 //               (forward) or one block per (n,q,m) row (backward).  Correctness path for
@@ -890,7 +896,6 @@ __global__ __launch_bounds__(kTileThreads) void msda_fwd_d32_tile(
 
     // ---- passes of 32 rows (8 per wavefront) ----
     const unsigned lane_off = (unsigned)sub * 16u;
-    const unsigned pix_stride = (unsigned)pl.M * 128u;
     for (int r0 = 0; r0 < pl.rows; r0 += 32) {
         const TileRow row = tile_row(tb, pl.L, pl.rows, r0 + wave * 8 + grp, b, ry, rx, m, pl.M, pl.Lq);
         for (int t = sub; t < LP; t += 8) {
@@ -941,7 +946,6 @@ __global__ __launch_bounds__(kTileThreads) void msda_fwd_d32_tile(
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    (void)pix_stride;
 }
 
 // ---- backward ------------------------------------------------------------------------------

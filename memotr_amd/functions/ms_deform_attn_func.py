@@ -18,6 +18,9 @@ class MSDeformAttnFunction(Function):
     def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights,
                 im2col_step):
         ctx.im2col_step = im2col_step
+        # keep the python-side copy of the pyramid with the graph node: the backward must not have to read
+        # spatial_shapes back from the device if the saved tensor comes back as a fresh python object
+        ctx.shapes_host = getattr(value_spatial_shapes, "_msda_host", None)
         output = MSDA.ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index,
                                              sampling_locations, attention_weights, ctx.im2col_step)
         ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, sampling_locations,
@@ -28,6 +31,8 @@ class MSDeformAttnFunction(Function):
     @once_differentiable
     def backward(ctx, grad_output):
         value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights = ctx.saved_tensors
+        if ctx.shapes_host is not None and getattr(value_spatial_shapes, "_msda_host", None) is None:
+            value_spatial_shapes._msda_host = (ctx.shapes_host[0], value_spatial_shapes._version)
         grad_value, grad_sampling_loc, grad_attn_weight = MSDA.ms_deform_attn_backward(
             value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights,
             grad_output.contiguous(), ctx.im2col_step)
