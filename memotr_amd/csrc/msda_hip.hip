@@ -1148,11 +1148,14 @@ __global__ __launch_bounds__(kTileThreads) void msda_bwd_d32_tile_q(
     int *win_i = reinterpret_cast<int *>(s_dyn);
     const int win_px = tb.base[pl.L];
     const int rec_stride = 2 * LP + 1;
-    u32x4 *rec = reinterpret_cast<u32x4 *>(s_dyn + (size_t)win_px * 128) + (size_t)(wave * 8 + grp) * rec_stride;
-    float *res = reinterpret_cast<float *>(s_dyn + (size_t)win_px * 128 + (size_t)32 * rec_stride * 16) +
+    // layout: [windows | 8 dump rows (one per row slot: dead / out-of-window corners add zeros there, so the
+    // in-window scatter needs no branches) | records | results]
+    const unsigned dump_cell = (unsigned)(win_px + grp);
+    u32x4 *rec = reinterpret_cast<u32x4 *>(s_dyn + (size_t)(win_px + 8) * 128) + (size_t)(wave * 8 + grp) * rec_stride;
+    float *res = reinterpret_cast<float *>(s_dyn + (size_t)(win_px + 8) * 128 + (size_t)32 * rec_stride * 16) +
                  (size_t)(wave * 8 + grp) * (3 * LP + 1);
 
-    for (int i = threadIdx.x; i < win_px * 8; i += kTileThreads) win_u4[i] = u32x4{0u, 0u, 0u, 0u};
+    for (int i = threadIdx.x; i < (win_px + 8) * 8; i += kTileThreads) win_u4[i] = u32x4{0u, 0u, 0u, 0u};
     {   // contribution bound of this region: max|grad_out| and max|attn| over its rows
         float gmax = 0.f, amax = 0.f;
         for (int i = threadIdx.x; i < pl.rows * 8; i += kTileThreads) {
@@ -1263,22 +1266,31 @@ __global__ __launch_bounds__(kTileThreads) void msda_bwd_d32_tile_q(
                     const float hh = 1.f - lh, hw = 1.f - lw;
                     const f32x4 tga = g * a;
                     const f32x4 sa = gs * a;            // contributions before the corner weight
+                    const f32x4 sa_q = sa * scale;      // ... in fixed-point units
                     const float wk[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
                     const unsigned cells[4] = {ra[i].y & 0xffffu, ra[i].y >> 16, ra[i].z & 0xffffu, ra[i].z >> 16};
+                    bool any_fallback = false;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        if (go[i][k] == kOobOffset) continue;        // dead corner (zero padding / gated point)
-                        const f32x4 c = wk[k] * sa;
-                        if (cells[k] == kNoCell) {                     // outside the window: global float atomics
-                            const unsigned o = go[i][k];
+                        // branch-free window scatter: dead and out-of-window corners add 0 to this row slot's dump row
+                        const bool alive = go[i][k] != kOobOffset;
+                        const bool inwin = alive && cells[k] != kNoCell;
+                        any_fallback |= alive && !inwin;
+                        const float wq = inwin ? wk[k] : 0.f;
+                        unsigned char *p = s_dyn + (inwin ? cells[k] : dump_cell) * 128u;
 #pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(c[j], gr, (int)(o + ch_off[j]), 0, 0);
-                        } else {
-                            unsigned char *p = s_dyn + cells[k] * 128u;
+                        for (int j = 0; j < 4; ++j)
+                            atomicAdd(reinterpret_cast<int *>(p + ch_off[j]), __float2int_rn(wq * sa_q[j]));
+                    }
+                    if (__builtin_amdgcn_ballot_w64(any_fallback) != 0ull) {   // rare: corners outside the windows
 #pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                atomicAdd(reinterpret_cast<int *>(p + ch_off[j]), __float2int_rn(c[j] * scale));
+                        for (int k = 0; k < 4; ++k) {
+                            if (go[i][k] != kOobOffset && cells[k] == kNoCell) {
+                                const f32x4 c = wk[k] * sa;
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+                                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(c[j], gr, (int)(go[i][k] + ch_off[j]), 0, 0);
+                            }
                         }
                     }
                     const f32x4 val = wk[0] * v[i][0] + wk[1] * v[i][1] + wk[2] * v[i][2] + wk[3] * v[i][3];
@@ -1572,7 +1584,7 @@ int backward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart,
             TilePlan pl;
             size_t lds = 0;
             const size_t rec_bytes = (size_t)32 * (2 * L * P + 1) * 16 + (size_t)32 * (3 * L * P + 1) * 4;
-            if (make_tile_plan(pl, shapes_host, N, S, M, D, L, Lq, P, value_bytes, opt_bwd_tile_margin.load(), 0,
+            if (make_tile_plan(pl, shapes_host, N, S, M, D, L, Lq, P, value_bytes, opt_bwd_tile_margin.load(), 8 * 128,
                                rec_bytes, lds)) {
                 const int grid = (pl.n_blocks + 7) & ~7;
 #define MSDA_LAUNCH_TQ(PTS)                                                                                          \
