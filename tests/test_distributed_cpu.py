@@ -57,10 +57,14 @@ def _worker(rank, world, port, out_path):
     batch = make_synthetic_clip(clip_len=2, height=96, width=128, n_gts=n_gts, seed=7 + rank)
     loss, loss_dict = clip_forward_backward(ddp, criterion, batch, torch.device("cpu"))
     grads_ok = all(p.grad is not None for p in ddp.parameters() if p.requires_grad)
+    l1_sum, n_gts_seen = float(criterion.loss["box_l1_loss"]), list(criterion.n_gts)
+    optimizer_step(ddp, opt, cfg["CLIP_MAX_NORM"])
+    # a second step: DDP raises here if the first backward left any bucket unreduced
+    loss2, _ = clip_forward_backward(ddp, criterion, batch, torch.device("cpu"))
     optimizer_step(ddp, opt, cfg["CLIP_MAX_NORM"])
     flat = torch.cat([p.detach().reshape(-1) for p in ddp.parameters()])
-    torch.save({"flat": flat, "loss": float(loss), "grads_ok": grads_ok, "n_gts": criterion.n_gts,
-                "l1_sum": float(criterion.loss["box_l1_loss"]), "l1_mean": float(loss_dict["box_l1_loss"])},
+    torch.save({"flat": flat, "loss": float(loss), "loss2": float(loss2), "grads_ok": grads_ok, "n_gts": n_gts_seen,
+                "l1_sum": l1_sum, "l1_mean": float(loss_dict["box_l1_loss"])},
                f"{out_path}.{rank}")
     dist.destroy_process_group()
 
@@ -77,3 +81,4 @@ def test_two_rank_clip_step_keeps_replicas_in_sync(tmp_path):
     assert r0["l1_mean"] == pytest.approx(r0["l1_sum"] / 10.0, rel=1e-5)
     assert r1["l1_mean"] == pytest.approx(r1["l1_sum"] / 10.0, rel=1e-5)
     assert r0["loss"] != r1["loss"]            # different clips per rank
+    assert r0["loss2"] == r0["loss2"] and r1["loss2"] == r1["loss2"]     # second step ran and is finite (not NaN)

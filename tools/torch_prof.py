@@ -37,10 +37,47 @@ t0 = time.perf_counter(); step(); torch.cuda.synchronize(); print("step wall ms"
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     step()
     torch.cuda.synchronize()
-ka = prof.key_averages()
-rows = sorted(ka, key=lambda e: -getattr(e, "self_device_time_total", getattr(e, "self_cuda_time_total", 0)))
-tot = sum(getattr(e, "self_device_time_total", getattr(e, "self_cuda_time_total", 0)) for e in ka)
-print(f"total device time {tot/1e3:.1f} ms")
-for e in rows[:45]:
-    dt = getattr(e, "self_device_time_total", getattr(e, "self_cuda_time_total", 0))
-    print(f"{dt/1e3:9.2f} ms {100*dt/tot:5.1f}%  n={e.count:5d}  {e.key[:110]}")
+from collections import defaultdict
+from torch.autograd import DeviceType
+
+agg = defaultdict(lambda: [0.0, 0])
+t_min, t_max = None, None
+for e in prof.events():
+    if e.device_type != DeviceType.CUDA:
+        continue
+    dur = e.time_range.end - e.time_range.start
+    agg[e.name][0] += dur
+    agg[e.name][1] += 1
+    t_min = e.time_range.start if t_min is None else min(t_min, e.time_range.start)
+    t_max = e.time_range.end if t_max is None else max(t_max, e.time_range.end)
+tot = sum(v[0] for v in agg.values())
+n_k = sum(v[1] for v in agg.values())
+print(f"device kernels: {n_k} launches, busy {tot/1e3:.1f} ms, span {(t_max - t_min)/1e3:.1f} ms "
+      f"(idle {(t_max - t_min - tot)/1e3:.1f} ms)")
+
+
+def family(name):
+    if name.startswith("Cijk_") or "gemm" in name.lower() and "conv" not in name.lower():
+        return "gemm"
+    if "conv" in name.lower() or "igemm" in name or "Sp3Asm" in name or "transpose" in name.lower():
+        return "conv"
+    if "msda_" in name:
+        return "msda"
+    if "Memcpy" in name or "copyBuffer" in name or "Memset" in name:
+        return "copy"
+    if "reduce_kernel" in name or "layer_norm" in name or "softmax" in name.lower():
+        return "reduce/norm"
+    if "multi_tensor" in name or "adam" in name.lower():
+        return "optimizer"
+    return "elementwise/other"
+
+
+fam = defaultdict(lambda: [0.0, 0])
+for k, (d, n) in agg.items():
+    fam[family(k)][0] += d
+    fam[family(k)][1] += n
+for k, (d, n) in sorted(fam.items(), key=lambda kv: -kv[1][0]):
+    print(f"  {k:20s} {d/1e3:8.2f} ms {100*d/tot:5.1f}%  n={n}")
+print("top kernels:")
+for k, (d, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:60]:
+    print(f"{d/1e3:9.2f} ms {100*d/tot:5.1f}%  n={n:5d}  avg {d/n:8.1f} us  {k[:120]}")
