@@ -8,9 +8,35 @@ random 800x1333 frames, persistent ground-truth identities.  value = frames/s ov
 from __future__ import annotations
 
 import os
+import sys
 import time
 
 import torch
+
+
+def load_gemm_tuning() -> int:
+    """Opt-in (MEMOTR_GEMM_TUNING=<csv>): load rocBLAS / hipBLASLt solution picks for the pyramid-sized fp32
+    GEMMs (a TunableOp CSV written by tools/tune_gemm.py), read-only -- nothing is tuned at run time and GEMMs
+    missing from the file keep the library default.  Measured on MI355X: the tuner's tight-loop winners (28-46 us
+    for the 22323x256 projections vs 80 us default) do not carry over in situ (step time 262 vs 257 ms on the
+    same box), so no file ships and the default is off.  Returns the number of entries in effect."""
+    path = os.environ.get("MEMOTR_GEMM_TUNING", "0")
+    if path == "0" or not os.path.exists(path):
+        return 0
+    import torch.cuda.tunable as tn
+    try:
+        tn.enable(True)
+        tn.tuning_enable(False)
+        tn.set_filename(os.devnull, False)      # never write next to the given file
+        ok = tn.read_file(path)
+        n = len(tn.get_results()) if ok else 0
+        if not n:
+            tn.enable(False)
+        return n
+    except Exception as exc:  # noqa: BLE001  (an optimisation only: the default library path stays valid)
+        print(f"[memotr_amd] GEMM tuning file ignored: {exc}", file=sys.stderr)
+        tn.enable(False)
+        return 0
 
 
 def run_train(args, rank: int, world: int, clip_len: int = None, height: int = 800, width: int = 1333,
@@ -29,6 +55,7 @@ def run_train(args, rank: int, world: int, clip_len: int = None, height: int = 8
     # frames/s) and minutes of search per process, so immediate mode stays the default.
     torch.backends.cudnn.benchmark = os.environ.get("MEMOTR_MIOPEN_FIND", "0") == "1"
     dev = torch.device("cuda", torch.cuda.current_device())
+    n_tuned = load_gemm_tuning()
     set_seed(cfg["SEED"])
     cfg = dict(cfg, DEVICE="cuda", AVAILABLE_GPUS="0")
     model = build_model(cfg).to(dev)
@@ -77,7 +104,7 @@ def run_train(args, rank: int, world: int, clip_len: int = None, height: int = 8
                                f"{' (--use-checkpoint)' if cfg['USE_CHECKPOINT'] else ''}: R50 + 6-enc/6-dec deformable transformer + query "
                                f"updater, clip length {clip_len}, {height}x{width} frames, bs=1/GPU, {n_gts} GT "
                                f"tracks, AdamW, grad-clip 0.1, random-init weights",
-                   "parallelism": f"dp{world}", "trainable_params": n_params,
+                   "parallelism": f"dp{world}", "trainable_params": n_params, "tuned_gemms": n_tuned,
                    "frames_per_gpu_per_sec": clip_len * args.steps / dt, "final_loss": float(loss.detach())},
         "max_memory_MB": torch.cuda.max_memory_allocated() // (1024 ** 2),
     }

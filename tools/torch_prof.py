@@ -15,6 +15,8 @@ from memotr_amd.engine import (build_optimizer, clip_forward_backward, clip_to_d
 from memotr_amd.models import build_model  # noqa: E402
 from memotr_amd.models.criterion import build as build_criterion  # noqa: E402
 
+from memotr_amd.train_bench import load_gemm_tuning  # noqa: E402
+print("tuned GEMM entries:", load_gemm_tuning())
 clip_len = int(os.environ.get("MEMOTR_BENCH_CLIP_LEN", "5"))
 cfg = dancetrack_config(DEVICE="cuda", AVAILABLE_GPUS="0")
 dev = torch.device("cuda", 0)
