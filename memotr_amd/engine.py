@@ -10,6 +10,8 @@ from __future__ import annotations
 
 from typing import Dict, List, Tuple
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -73,6 +75,39 @@ def clip_to_device(batch: dict, device) -> dict:
             "infos": [[{k: v.to(device) for k, v in info.items()} for info in clip] for clip in batch["infos"]]}
 
 
+def encode_chunks(core, clip_len: int):
+    """How the frames of a clip are grouped for the backbone + encoder: ``None`` = frame by frame in the
+    reference's order, else a list of group sizes summing to clip_len.  ``core.encode_chunks`` (int or list) or
+    the environment variable MEMOTR_ENCODE_CHUNKS ("all", "5", "1,4", "0" = off) override the default ("all": one
+    batched encode per clip -- measured on MI355X, DanceTrack clip of 5: 244 ms per step vs 254 ms frame by frame,
+    tools/ab_step.py); gradient checkpointing keeps the reference's order."""
+    if getattr(core, "use_checkpoint", False):
+        return None
+    spec = getattr(core, "encode_chunks", None)
+    if spec is None:
+        spec = os.environ.get("MEMOTR_ENCODE_CHUNKS", DEFAULT_ENCODE_CHUNKS)
+    if isinstance(spec, str):
+        spec = [clip_len] if spec.strip() == "all" else [int(x) for x in spec.split(",") if x.strip()]
+    if isinstance(spec, int):
+        spec = [spec]
+    spec = [int(x) for x in spec if int(x) > 0]
+    if not spec:
+        return None
+    out, left = [], clip_len
+    for n in spec:
+        if left <= 0:
+            break
+        out.append(min(n, left))
+        left -= out[-1]
+    while left > 0:                                  # the last group size repeats
+        out.append(min(spec[-1], left))
+        left -= out[-1]
+    return out
+
+
+DEFAULT_ENCODE_CHUNKS = "all"
+
+
 def clip_forward_backward(model: nn.Module, criterion, batch: dict, device, use_dab: bool = True,
                           accumulation_steps: int = 1, backward: bool = True):
     """One clip through model + criterion (+ backward).  Returns (loss tensor, loss_dict)."""
@@ -81,11 +116,45 @@ def clip_forward_backward(model: nn.Module, criterion, batch: dict, device, use_
                                         device=device, use_dab=use_dab)
     criterion.init_a_clip(batch=batch, hidden_dim=core.hidden_dim, num_classes=core.num_classes, device=device)
     clip_len = len(batch["imgs"][0])
+
+    n_clips = len(batch["imgs"])
+
+    def frames(lo, hi):
+        """Frames lo..hi-1 of every clip as ONE padded batch, frame-major: rows [k*B, (k+1)*B) are frame lo+k."""
+        return tensor_list_to_nested_tensor([clip[t] for t in range(lo, hi) for clip in batch["imgs"]]).to(device)
+
+    # The backbone + encoder do not depend on the tracks, so the frames of a clip need not take that half one at
+    # a time (train_engine.py:196-221 does): ``chunks`` groups consecutive frames into one batched encode call.
+    # Same operations per frame (FrozenBN / GroupNorm / LayerNorm are per-sample), 1/len(chunk) of the kernel
+    # launches, larger GEMMs and convolutions; the decoder still runs frame by frame on the carried tracks.
+    chunks = encode_chunks(core, clip_len)
+    starts = [sum(chunks[:i]) for i in range(len(chunks))] if chunks is not None else []
+    encoded = {}                                   # frame index -> encode result of that frame
+
+    def encode_chunk(ci):
+        lo, n = starts[ci], chunks[ci]
+        enc = model(frame=frames(lo, lo + n), stage="encode")
+        if n == 1:
+            encoded[lo] = enc
+            return
+        per_frame = {k: (v.split(n_clips, dim=0) if k in ("memory", "valid_ratios", "mask_flatten") else None)
+                     for k, v in enc.items()}
+        for j in range(n):
+            encoded[lo + j] = {k: (per_frame[k][j] if per_frame[k] is not None else v) for k, v in enc.items()}
+
+    if chunks is not None:
+        encode_chunk(0)
     for frame_idx in range(clip_len):
-        frame = tensor_list_to_nested_tensor([clip[frame_idx] for clip in batch["imgs"]]).to(device)
-        res = model(frame=frame, tracks=tracks)
-        previous, new, unmatched = criterion.process_single_frame(model_outputs=res, tracked_instances=tracks,
-                                                                  frame_idx=frame_idx)
+        if chunks is None:                          # the reference's order: everything of a frame, then the next
+            res = model(frame=frames(frame_idx, frame_idx + 1), tracks=tracks)
+            previous, new, unmatched = criterion.process_single_frame(model_outputs=res, tracked_instances=tracks,
+                                                                      frame_idx=frame_idx)
+        else:
+            res = model(tracks=tracks, encoded=encoded.pop(frame_idx))
+            pending = criterion.begin_frame(model_outputs=res, tracked_instances=tracks, frame_idx=frame_idx)
+            if frame_idx in starts and starts.index(frame_idx) + 1 < len(chunks):
+                encode_chunk(starts.index(frame_idx) + 1)     # queued before the host blocks on this frame's costs
+            previous, new, unmatched = criterion.finish_frame(pending)
         if frame_idx < clip_len - 1:
             tracks = core.postprocess_single_frame(previous, new, unmatched)
     loss_dict, _ = criterion.get_mean_by_n_gts()

@@ -30,9 +30,24 @@ class FrozenBatchNorm2d(nn.Module):
         super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
                                       error_msgs)
 
+    def _apply(self, fn, *args, **kwargs):
+        self._folded = None                      # .to() / .cuda() replace the buffers
+        return super()._apply(fn, *args, **kwargs)
+
     def scale_shift(self):
-        scale = self.weight * (self.running_var + self.eps).rsqrt()
-        return scale, self.bias - self.running_mean * scale
+        """(scale, shift), cached: the four buffers are constants, so the five tiny kernels that derive them run
+        once instead of once per convolution per frame; any in-place write to a buffer (checkpoint load, DDP
+        buffer broadcast) bumps its version counter and refreshes the cache."""
+        bufs = (self.weight, self.bias, self.running_mean, self.running_var)
+        key = tuple((id(b), b._version) for b in bufs) + (torch.is_inference_mode_enabled(),)
+        cached = getattr(self, "_folded", None)
+        if cached is None or cached[0] != key:
+            with torch.no_grad():
+                scale = self.weight * (self.running_var + self.eps).rsqrt()
+                shift = self.bias - self.running_mean * scale
+            cached = (key, scale, shift)
+            self._folded = cached
+        return cached[1], cached[2]
 
     def fold_into_conv(self, conv_weight: torch.Tensor):
         """(W * scale[:,None,None,None], shift): conv(x, W') + shift == norm(conv(x, W))."""

@@ -27,6 +27,16 @@ from .matcher import build as build_matcher
 _LOSS_KEYS = ("box_l1_loss", "box_giou_loss", "label_focal_loss")
 
 
+
+def upload(values, dtype, device):
+    """Host list -> device tensor without stalling the host: a pageable-memory copy blocks until everything
+    already queued on the stream has run, a pinned-memory one is queued like a kernel."""
+    t = torch.as_tensor(values, dtype=dtype)
+    if torch.device(device).type == "cuda":
+        return t.pin_memory().to(device, non_blocking=True)
+    return t.to(device)
+
+
 class ClipCriterion:
     def __init__(self, num_classes, matcher: HungarianMatcher, n_det_queries, aux_loss: bool, weight: dict,
                  max_frame_length: int, n_aux: int, merge_det_track_layer: int = 0, aux_weights: List = None,
@@ -101,7 +111,15 @@ class ClipCriterion:
         All decoder layers are handled together: one stacked cost tensor -> ONE device->host copy -> scipy on the
         host -> one small index upload -> stacked focal / L1 / GIoU losses.  Track bookkeeping uses slices and
         ``torch.where`` (boolean-mask indexing would synchronise once per field).
+
+        ``begin_frame`` / ``finish_frame`` are the two halves either side of the device->host copy; a training
+        loop may queue other GPU work (the next frame's backbone + encoder) between them.
         """
+        return self.finish_frame(self.begin_frame(model_outputs, tracked_instances, frame_idx))
+
+    def begin_frame(self, model_outputs: dict, tracked_instances: List[TrackInstances], frame_idx: int) -> dict:
+        """Device side of the matching: ownership of ground truths + stacked cost tensors, and the (asynchronous,
+        pinned-memory) copy of both to the host.  Returns the state ``finish_frame`` consumes."""
         nd = self.n_det_queries
         gts = self.gt_trackinstances_list[frame_idx]
         B = len(tracked_instances)
@@ -129,7 +147,53 @@ class ClipCriterion:
             cost = self.matcher.cost_matrix_stacked(logits_all[:, b, :nd].detach(), boxes_all[:, b, :nd].detach(),
                                                     gt.labels, gt.boxes)                  # (n_layers, nd, n_gt)
             payload += [free.to(cost.dtype).reshape(-1), cost.reshape(-1)]
-        host = torch.cat(payload).cpu() if payload else torch.zeros(0)
+        ready = keep = None
+        if not payload:
+            host = torch.zeros(0)
+        else:
+            flat = torch.cat(payload)
+            if flat.is_cuda:
+                # copy on a side stream: the event then depends on the work queued up to here only, and the host
+                # wait in finish_frame is not held back by kernels the caller queues on the main stream meanwhile
+                side = self._copy_stream(flat.device)
+                computed = torch.cuda.Event()
+                computed.record()
+                side.wait_event(computed)
+                host = torch.empty(flat.shape, dtype=flat.dtype, pin_memory=True)
+                with torch.cuda.stream(side):
+                    host.copy_(flat, non_blocking=True)
+                    ready = torch.cuda.Event()
+                    ready.record(side)
+                keep = flat                             # stays referenced until the copy has completed
+            else:
+                host = flat
+        return {"model_outputs": model_outputs, "tracked_instances": tracked_instances, "frame_idx": frame_idx,
+                "layers": layers, "early": early, "logits_all": logits_all, "boxes_all": boxes_all,
+                "n_gt_list": n_gt_list, "host": host, "ready": ready, "keep": keep}
+
+    def _constant(self, key, values, dtype, device):
+        """Small per-configuration device constants (uploaded once, not once per frame)."""
+        cache = self.__dict__.setdefault("_constants", {})
+        key = (key, dtype, str(device))
+        if key not in cache:
+            cache[key] = torch.as_tensor(values, dtype=dtype, device=device)
+        return cache[key]
+
+    def _copy_stream(self, device):
+        streams = self.__dict__.setdefault("_copy_streams", {})
+        if device not in streams:
+            streams[device] = torch.cuda.Stream(device=device)
+        return streams[device]
+
+    def finish_frame(self, state: dict):
+        """Host side (assignment problems) and the device work that depends on it; see process_single_frame."""
+        model_outputs, tracked_instances, frame_idx = state["model_outputs"], state["tracked_instances"], state["frame_idx"]
+        early, logits_all, boxes_all, n_gt_list = state["early"], state["logits_all"], state["boxes_all"], state["n_gt_list"]
+        nd, dev, B, n_layers = self.n_det_queries, self.device, len(tracked_instances), len(state["layers"])
+        gts = self.gt_trackinstances_list[frame_idx]
+        if state["ready"] is not None:
+            state["ready"].synchronize()            # waits for the copy only, not for work queued after it
+        host = state["host"]
 
         # ---- host side: the assignment problems ----
         pos = 0
@@ -164,7 +228,7 @@ class ClipCriterion:
             tr, gt = tracked_instances[b], gts[b]
             n_tr = len(tr)
             flat = lambda rows: [x for r in rows for x in r]                       # noqa: E731
-            idx = torch.as_tensor([flat(rows_layer[b]), flat(rows_q[b]), flat(rows_g[b])], dtype=torch.long).to(dev)
+            idx = upload([flat(rows_layer[b]), flat(rows_q[b]), flat(rows_g[b])], torch.long, dev)
             lay_i, q_i, g_i = idx[0], idx[1], idx[2]
             n_main = len(main_q[b][0])
             q_idx, gt_idx = q_i[:n_main], g_i[:n_main]                              # layer 0 comes first
@@ -180,14 +244,14 @@ class ClipCriterion:
             nt.output_embed = model_outputs["outputs"][b][q_idx]
             nt.boxes = model_outputs["pred_bboxes"][b][q_idx]
             nt.logits = model_outputs["pred_logits"][b][q_idx]
-            nt.iou = torch.zeros((n_main,), dtype=torch.float)
+            nt.iou = torch.zeros((n_main,), dtype=torch.float, device=dev)
             nt = nt.to(dev)
 
             # classification targets of every layer: matched detect queries + (late layers) the carried tracks
             n_q = nd + n_tr                                                        # real (unpadded) queries of clip b
             labels = torch.full((n_layers, n_q), self.num_classes, dtype=torch.int64, device=dev)
             labels[lay_i, q_i] = gt.labels[g_i]
-            late = torch.as_tensor([not e for e in early], device=dev)
+            late = self._constant(("late", tuple(early)), [not e for e in early], torch.bool, dev)
             if n_tr > 0:
                 has = tr.matched_idx >= 0
                 tr_lab = torch.where(has, gt.labels[tr.matched_idx.clamp(min=0)] if len(gt) > 0
@@ -215,7 +279,7 @@ class ClipCriterion:
 
             # detections nobody claimed (host knows the matched detect queries of the last layer)
             taken = set(int(q) for q in main_q[b][0])
-            free_q = torch.as_tensor([q for q in range(n_det_out) if q not in taken], dtype=torch.long).to(dev)
+            free_q = upload([q for q in range(n_det_out) if q not in taken], torch.long, dev)
             d = TrackInstances(hidden_dim=model_outputs["outputs"].shape[-1],
                                num_classes=model_outputs["pred_logits"].shape[-1]).to(dev)
             d.ref_pts = model_outputs["init_ref_pts"][b][free_q]
@@ -250,7 +314,7 @@ class ClipCriterion:
         self.log[f"frame{frame_idx}_label_focal_loss"] = loss_label[0].detach()
         self.n_gts.append(sum(n_gt_list))
         if self.aux_loss and n_layers > 1:
-            aw = torch.as_tensor(self.aux_weights[:n_layers - 1], dtype=loss_l1.dtype, device=dev) * fw
+            aw = self._constant(("aux_w", n_layers), self.aux_weights[:n_layers - 1], loss_l1.dtype, dev) * fw
             self.loss["aux_box_l1_loss"] = self.loss["aux_box_l1_loss"] + (loss_l1[1:] * aw).sum()
             self.loss["aux_box_giou_loss"] = self.loss["aux_box_giou_loss"] + (loss_giou[1:] * aw).sum()
             self.loss["aux_label_focal_loss"] = self.loss["aux_label_focal_loss"] + (loss_label[1:] * aw).sum()

@@ -71,23 +71,33 @@ class DeformableTransformer(nn.Module):
         valid_w = torch.sum(~mask[:, 0, :], 1).float() / W
         return torch.stack([valid_w, valid_h], -1)
 
-    def forward(self, srcs: List[torch.Tensor], masks: List[torch.Tensor], pos_embeds: List[torch.Tensor],
-                query_embed, ref_pts, query_mask):
-        assert query_embed is not None
+    def _pyramid_tensors(self, shapes_list, device):
+        """(L, 2) int64 ``spatial_shapes`` and (L,) ``level_start_index`` on the device, uploaded once per pyramid
+        geometry (a pageable host->device copy per frame would stall the host behind everything queued)."""
+        cache = self.__dict__.setdefault("_pyramids", {})
+        key = (tuple(shapes_list), str(device))
+        if key not in cache:
+            if len(cache) >= 16:
+                cache.clear()
+            spatial_shapes = torch.as_tensor(shapes_list, dtype=torch.long, device=device)
+            starts = [0]
+            for h, w in shapes_list[:-1]:
+                starts.append(starts[-1] + h * w)
+            level_start_index = torch.as_tensor(starts, dtype=torch.long, device=device)
+            # the pyramid is known as python ints: hand it to the operator so it never reads it back
+            MSDA.tag_host_shapes(spatial_shapes, shapes_list)
+            cache[key] = (spatial_shapes, level_start_index)
+        return cache[key]
+
+    def encode(self, srcs: List[torch.Tensor], masks: List[torch.Tensor], pos_embeds: List[torch.Tensor]) -> dict:
+        """Query-independent half: flatten the pyramid and run the encoder.  Returns what ``decode`` needs."""
         shapes_list = [(int(s.shape[2]), int(s.shape[3])) for s in srcs]
         src_flatten = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)                 # (B, S, C)
         mask_flatten = torch.cat([m.flatten(1) for m in masks], 1)                                # (B, S)
         lvl_pos_embed_flatten = torch.cat(
             [p.flatten(2).transpose(1, 2) + self.level_embed[lvl].view(1, 1, -1) for lvl, p in enumerate(pos_embeds)],
             1)
-        device = src_flatten.device
-        spatial_shapes = torch.as_tensor(shapes_list, dtype=torch.long, device=device)           # (L, 2) int64
-        starts = [0]
-        for h, w in shapes_list[:-1]:
-            starts.append(starts[-1] + h * w)
-        level_start_index = torch.as_tensor(starts, dtype=torch.long, device=device)             # (L,) int64
-        # the pyramid is known as python ints: hand it to the operator so it never reads it back
-        MSDA.tag_host_shapes(spatial_shapes, shapes_list)
+        spatial_shapes, level_start_index = self._pyramid_tensors(shapes_list, src_flatten.device)
         valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)                   # (B, L, 2)
 
         if self.use_checkpoint and self.checkpoint_level in (2, 3):
@@ -97,6 +107,13 @@ class DeformableTransformer(nn.Module):
             memory = self.encoder(src=src_flatten, spatial_shapes=spatial_shapes,
                                   level_start_index=level_start_index, valid_ratios=valid_ratios,
                                   pos=lvl_pos_embed_flatten, padding_mask=mask_flatten, shapes_list=shapes_list)
+        return {"memory": memory, "spatial_shapes": spatial_shapes, "level_start_index": level_start_index,
+                "valid_ratios": valid_ratios, "mask_flatten": mask_flatten}
+
+    def decode(self, enc: dict, query_embed, ref_pts, query_mask):
+        """Query-dependent half: the decoder over an ``encode`` result."""
+        assert query_embed is not None
+        memory = enc["memory"]
         c = memory.shape[2]
         if self.use_dab:
             tgt, query_pos = query_embed, None
@@ -105,10 +122,15 @@ class DeformableTransformer(nn.Module):
         assert ref_pts is not None, "ref_pts should not be None."
         init_reference_points = ref_pts.sigmoid()
         output, res_reference_points, inter_queries = self.decoder(
-            tgt=tgt, reference_points=init_reference_points, src=memory, src_spatial_shapes=spatial_shapes,
-            src_level_start_index=level_start_index, src_valid_ratios=valid_ratios, query_pos=query_pos,
-            query_mask=query_mask, src_padding_mask=mask_flatten)
+            tgt=tgt, reference_points=init_reference_points, src=memory, src_spatial_shapes=enc["spatial_shapes"],
+            src_level_start_index=enc["level_start_index"], src_valid_ratios=enc["valid_ratios"],
+            query_pos=query_pos, query_mask=query_mask, src_padding_mask=enc["mask_flatten"])
         return output, init_reference_points, res_reference_points, inter_queries
+
+    def forward(self, srcs: List[torch.Tensor], masks: List[torch.Tensor], pos_embeds: List[torch.Tensor],
+                query_embed, ref_pts, query_mask):
+        assert query_embed is not None
+        return self.decode(self.encode(srcs, masks, pos_embeds), query_embed, ref_pts, query_mask)
 
     def get_d_model(self):
         return self.d_model

@@ -85,7 +85,21 @@ class MeMOTR(nn.Module):
             self.bbox_embed = nn.ModuleList([self.bbox_embed for _ in range(n_dec)])
 
     # ------------------------------------------------------------------ forward
-    def forward(self, frame: NestedTensor, tracks: List[TrackInstances]):
+    def forward(self, frame: Optional[NestedTensor] = None, tracks: Optional[List[TrackInstances]] = None,
+                encoded: Optional[dict] = None, stage: Optional[str] = None):
+        """``model(frame, tracks)`` is the reference contract (models/memotr.py:94-160).  Two extra keywords split
+        it so a training loop can queue the query-independent half of the NEXT frame on the GPU while the host
+        still waits for / solves this frame's assignment: ``model(frame=f, stage="encode")`` returns the encoder
+        result, ``model(tracks=t, encoded=enc)`` finishes the frame.  Both go through ``forward`` so a
+        DistributedDataParallel wrapper sees every call."""
+        if encoded is None:
+            encoded = self.encode_frame(frame)
+        if stage == "encode":
+            return encoded
+        return self.decode_frame(encoded, tracks)
+
+    def encode_frame(self, frame: NestedTensor) -> dict:
+        """Backbone -> feature projections -> encoder (independent of the track queries)."""
         if self.use_checkpoint and self.checkpoint_level != 3:
             features, pos = checkpoint(self.backbone, frame, use_reentrant=False)
         else:
@@ -102,15 +116,17 @@ class MeMOTR(nn.Module):
             pos.append(self.backbone.position_embedding(NestedTensor(src, mask)).to(src.device))
             srcs.append(src)
             masks.append(mask)
+        return self.transformer.encode(srcs=srcs, masks=masks, pos_embeds=pos)
 
-        device = srcs[0].device
+    def decode_frame(self, encoded: dict, tracks: List[TrackInstances]) -> dict:
+        """Query assembly -> decoder -> heads over an ``encode_frame`` result."""
+        device = encoded["memory"].device
         reference_points = self.get_reference_points(tracks).to(device)     # (B, Nd+Nt, 4) logit space
         query_embed = self.get_query_embed(tracks).to(device)               # (B, Nd+Nt, C | 2C)
         query_mask = self.get_query_mask(tracks).to(device)                 # (B, Nd+Nt) bool
 
-        outputs, init_reference, inter_references, inter_queries = self.transformer(
-            srcs=srcs, masks=masks, pos_embeds=pos, query_embed=query_embed, ref_pts=reference_points,
-            query_mask=query_mask)
+        outputs, init_reference, inter_references, inter_queries = self.transformer.decode(
+            encoded, query_embed=query_embed, ref_pts=reference_points, query_mask=query_mask)
         assert outputs.ndim == 4, \
             f"Deformable Transformer's outputs should have shape (n_dec_layers, B, Nd+Nq, C, but get n_dim={outputs.ndim}"
         classes, boxes = [], []

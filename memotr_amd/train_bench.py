@@ -64,7 +64,9 @@ def run_train(args, rank: int, world: int, clip_len: int = None, height: int = 8
     optimizer = build_optimizer(cfg, model)
     if world > 1:
         from torch.nn.parallel import DistributedDataParallel as DDP
-        model = DDP(model, device_ids=[dev.index], find_unused_parameters=False)
+        # the only buffers are frozen-BatchNorm constants (identical on every rank after DDP's initial state sync):
+        # no per-forward buffer broadcast
+        model = DDP(model, device_ids=[dev.index], find_unused_parameters=False, broadcast_buffers=False)
     batch = clip_to_device(make_synthetic_clip(clip_len, height, width, n_gts, seed=cfg["SEED"] + rank), dev)
 
     def step():

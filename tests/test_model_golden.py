@@ -196,7 +196,8 @@ def test_memotr_two_frame_inference_matches_reference(monkeypatch):
     assert len(tracks[0]) == g["f1_next_ids"].shape[0] > 0
 
 
-def test_train_step_matches_reference(monkeypatch):
+@pytest.mark.parametrize("chunks", ["0", "1", "all", "1,2"])
+def test_train_step_matches_reference(monkeypatch, chunks):
     """the body of train_engine.py:192-238 (criterion + matcher + query updater + backward)
     on the reference's seeded 3-frame clip: per-frame track sets, every loss term, and the gradient norm of
     every trainable parameter."""
@@ -215,16 +216,18 @@ def test_train_step_matches_reference(monkeypatch):
                          "boxes": t(g[f"gt{i}_boxes"])} for i in range(T)]]}
 
     seen = {}
-    orig = criterion.process_single_frame
+    orig = criterion.finish_frame       # both loop orders end a frame here (process_single_frame = finish(begin))
 
-    def spy(model_outputs, tracked_instances, frame_idx):
-        res = orig(model_outputs=model_outputs, tracked_instances=tracked_instances, frame_idx=frame_idx)
+    def spy(state):
+        res = orig(state)
         # snapshot: the query updater later rewrites some of these objects in place
-        seen[frame_idx] = [[tr[torch.ones(len(tr), dtype=torch.bool)] if len(tr) else tr for tr in group]
-                           for group in res]
+        seen[state["frame_idx"]] = [[tr[torch.ones(len(tr), dtype=torch.bool)] if len(tr) else tr for tr in group]
+                                    for group in res]
         return res
 
-    criterion.process_single_frame = spy
+    criterion.finish_frame = spy
+    # engine.clip_forward_backward: reference order / per-frame encode ahead / all frames in one batched encode / 1+2
+    model.encode_chunks = chunks
     loss, loss_dict = clip_forward_backward(model, criterion, batch, torch.device("cpu"), use_dab=True)
     for i in range(T):
         prev, new, unm = seen[i]

@@ -205,6 +205,7 @@ TILE_CASES = [
     (44, [(6, 8), (3, 4)], 1, 8, 4, "local"),                           # L=2
     (45, [(5, 5)], 1, 8, 4, "local"),                                   # L=1: one query per region
     (46, [(17, 23), (9, 12), (5, 6), (3, 3)], 1, 8, 3, "local"),        # LP=12, non-halving pyramid
+    (48, [(20, 28), (10, 14), (5, 7), (3, 4)], 5, 8, 4, "local"),       # N=5: all frames of a clip in one encode call
 ]
 
 
