@@ -76,23 +76,35 @@ def clip_to_device(batch: dict, device) -> dict:
 
 
 def encode_chunks(core, clip_len: int):
-    """How the frames of a clip are grouped for the backbone + encoder: ``None`` = frame by frame in the
-    reference's order, else a list of group sizes summing to clip_len.  ``core.encode_chunks`` (int or list) or
-    the environment variable MEMOTR_ENCODE_CHUNKS ("all", "5", "1,4", "0" = off) override the default ("all": one
-    batched encode per clip -- measured on MI355X, DanceTrack clip of 5: 244 ms per step vs 254 ms frame by frame,
-    tools/ab_step.py); gradient checkpointing keeps the reference's order."""
+    """How the frames of a clip are grouped for the backbone + encoder.  Returns (groups, lazy): ``groups`` is
+    ``None`` (frame by frame in the reference's order) or a list of group sizes summing to clip_len; ``lazy``
+    = each group is encoded right before its first frame is decoded (else: as early as possible).
+
+    ``core.encode_chunks`` or the environment variable MEMOTR_ENCODE_CHUNKS override the default "auto":
+    "0" (off), "all", "5", "1,4", "lazy:3,2", ... .  Measured on MI355X (DanceTrack clip of 5, tools/ab_step.py,
+    same process): reference order 235 ms per step, "all" 232, "lazy:3,2" (= auto) 219.  Batching divides the
+    number of backbone / encoder launches (the forward is bound by the host's launch rate); two groups instead of
+    one keep GPU-bound encoder backward work (group 2) queued while the host is busy with the launch-bound decoder
+    backward of the earlier frames.  Gradient checkpointing keeps the reference's order."""
     if getattr(core, "use_checkpoint", False):
-        return None
+        return None, False
     spec = getattr(core, "encode_chunks", None)
     if spec is None:
         spec = os.environ.get("MEMOTR_ENCODE_CHUNKS", DEFAULT_ENCODE_CHUNKS)
+    lazy = False
     if isinstance(spec, str):
-        spec = [clip_len] if spec.strip() == "all" else [int(x) for x in spec.split(",") if x.strip()]
+        if spec.startswith("lazy:"):
+            lazy, spec = True, spec[5:]
+        if spec.strip() == "auto":                   # two groups, ~60 % of the clip first, each encoded just in time
+            first = -(-3 * clip_len // 5)
+            lazy, spec = True, [first, clip_len - first]
+        else:
+            spec = [clip_len] if spec.strip() == "all" else [int(x) for x in spec.split(",") if x.strip()]
     if isinstance(spec, int):
         spec = [spec]
     spec = [int(x) for x in spec if int(x) > 0]
     if not spec:
-        return None
+        return None, False
     out, left = [], clip_len
     for n in spec:
         if left <= 0:
@@ -102,10 +114,10 @@ def encode_chunks(core, clip_len: int):
     while left > 0:                                  # the last group size repeats
         out.append(min(spec[-1], left))
         left -= out[-1]
-    return out
+    return out, lazy
 
 
-DEFAULT_ENCODE_CHUNKS = "all"
+DEFAULT_ENCODE_CHUNKS = "auto"
 
 
 def clip_forward_backward(model: nn.Module, criterion, batch: dict, device, use_dab: bool = True,
@@ -127,7 +139,7 @@ def clip_forward_backward(model: nn.Module, criterion, batch: dict, device, use_
     # a time (train_engine.py:196-221 does): ``chunks`` groups consecutive frames into one batched encode call.
     # Same operations per frame (FrozenBN / GroupNorm / LayerNorm are per-sample), 1/len(chunk) of the kernel
     # launches, larger GEMMs and convolutions; the decoder still runs frame by frame on the carried tracks.
-    chunks = encode_chunks(core, clip_len)
+    chunks, lazy = encode_chunks(core, clip_len)
     starts = [sum(chunks[:i]) for i in range(len(chunks))] if chunks is not None else []
     encoded = {}                                   # frame index -> encode result of that frame
 
@@ -142,9 +154,11 @@ def clip_forward_backward(model: nn.Module, criterion, batch: dict, device, use_
         for j in range(n):
             encoded[lo + j] = {k: (per_frame[k][j] if per_frame[k] is not None else v) for k, v in enc.items()}
 
-    if chunks is not None:
+    if chunks is not None and not lazy:
         encode_chunk(0)
     for frame_idx in range(clip_len):
+        if lazy and frame_idx in starts:            # just in time: the group is encoded right before its first decode
+            encode_chunk(starts.index(frame_idx))
         if chunks is None:                          # the reference's order: everything of a frame, then the next
             res = model(frame=frames(frame_idx, frame_idx + 1), tracks=tracks)
             previous, new, unmatched = criterion.process_single_frame(model_outputs=res, tracked_instances=tracks,
@@ -152,7 +166,7 @@ def clip_forward_backward(model: nn.Module, criterion, batch: dict, device, use_
         else:
             res = model(tracks=tracks, encoded=encoded.pop(frame_idx))
             pending = criterion.begin_frame(model_outputs=res, tracked_instances=tracks, frame_idx=frame_idx)
-            if frame_idx in starts and starts.index(frame_idx) + 1 < len(chunks):
+            if not lazy and frame_idx in starts and starts.index(frame_idx) + 1 < len(chunks):
                 encode_chunk(starts.index(frame_idx) + 1)     # queued before the host blocks on this frame's costs
             previous, new, unmatched = criterion.finish_frame(pending)
         if frame_idx < clip_len - 1:

@@ -13,4 +13,8 @@ def _target_device(config: dict) -> torch.device:
 
 
 def build_model(config: dict) -> MeMOTR:
-    return build_memotr(config=config).to(device=_target_device(config))
+    device = _target_device(config)
+    if device.type == "cuda":
+        from ..modules.linear import configure_blas
+        configure_blas()          # rocBLAS for mm / bmm: see the measurements quoted there
+    return build_memotr(config=config).to(device=device)

@@ -9,11 +9,52 @@ Only the summation order of the fp32 partial products changes (relative differen
 """
 from __future__ import annotations
 
+import contextlib
+import os
+
 import torch
 import torch.nn.functional as F
 
 MIN_ROWS = 8192          # below this the plain GEMM is already fine (decoder-sized inputs)
 TARGET_CHUNKS = 24
+ROCBLAS_DGRAD_ROWS = 65536   # input-gradient GEMMs with at least this many rows go to rocBLAS (clip-batched encoder)
+
+
+@contextlib.contextmanager
+def prefer_blas(lib: str):
+    """Route ``mm`` / ``bmm`` to "cublas" (= rocBLAS) or "cublaslt" (= hipBLASLt) inside the block."""
+    prev = torch.backends.cuda.preferred_blas_library()
+    if prev == _BACKENDS[lib]:
+        yield
+        return
+    torch.backends.cuda.preferred_blas_library(lib)
+    try:
+        yield
+    finally:
+        torch.backends.cuda.preferred_blas_library(prev)
+
+
+_BACKENDS = {"cublas": torch._C._BlasBackend.Cublas, "cublaslt": torch._C._BlasBackend.Cublaslt}
+
+
+def configure_blas() -> str:
+    """Process-wide GEMM library choice for ``mm`` / ``bmm`` (``addmm`` with a bias keeps hipBLASLt's fused epilogue
+    either way).  Measured on MI355X, fp32 (tools/small_gemm_probe.py, tools/gemm_probe.py):
+
+    * decoder-sized GEMMs (a few hundred rows): hipBLASLt costs ~19 us of HOST time per call and maps the
+      (256 x K) x (K x 256) weight gradient to a single 256x256 macro-tile -- 80 us for 40 MFLOP, 290 times per
+      step; rocBLAS: ~7 us host, 7-8 us GPU for the same calls;
+    * pyramid-sized GEMMs: the two libraries are within a few percent of each other, except the 22,323-row input
+      gradients (hipBLASLt 33 vs rocBLAS 68 us) -- ``long_linear`` picks per call.
+
+    So rocBLAS is the default and ``long_linear`` opts back into hipBLASLt where it wins.
+    MEMOTR_BLAS=hipblaslt|rocblas|keep overrides.  Returns the choice."""
+    choice = os.environ.get("MEMOTR_BLAS", "rocblas")
+    if choice == "rocblas":
+        torch.backends.cuda.preferred_blas_library("cublas")
+    elif choice == "hipblaslt":
+        torch.backends.cuda.preferred_blas_library("cublaslt")
+    return choice
 
 
 def _pick_chunks(rows: int) -> int:
@@ -40,17 +81,21 @@ class _SplitKLinear(torch.autograd.Function):
         K, N = weight.shape[1], weight.shape[0]
         g2 = grad_out.reshape(-1, N)
         cdt = g2.dtype                      # bf16 under autocast (forward ran in bf16), else the parameter dtype
+        on_gpu = g2.is_cuda
         if ctx.needs_input_grad[0]:
-            gx = (g2 @ weight.to(cdt)).view(x.shape).to(x.dtype)
+            lib = "cublas" if g2.shape[0] >= ROCBLAS_DGRAD_ROWS else "cublaslt"
+            with (prefer_blas(lib) if on_gpu else contextlib.nullcontext()):
+                gx = (g2 @ weight.to(cdt)).view(x.shape).to(x.dtype)
         if ctx.needs_input_grad[1]:
             x2 = x.reshape(-1, K).to(cdt)
             rows = x2.shape[0]
             c = _pick_chunks(rows)
             r = rows // c
             main = r * c
-            gw = torch.bmm(g2[:main].view(c, r, N).transpose(1, 2), x2[:main].view(c, r, K)).sum(0)
-            if main < rows:
-                gw = gw + g2[main:].t() @ x2[main:]
+            with (prefer_blas("cublaslt") if on_gpu else contextlib.nullcontext()):
+                gw = torch.bmm(g2[:main].view(c, r, N).transpose(1, 2), x2[:main].view(c, r, K)).sum(0)
+                if main < rows:
+                    gw = gw + g2[main:].t() @ x2[main:]
             gw = gw.to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = g2.sum(0).to(weight.dtype)
@@ -67,3 +112,4 @@ def long_linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor = None
         y = _SplitKLinear.apply(x.reshape(rows, x.shape[-1]), weight, bias)
         return y.view(*x.shape[:-1], weight.shape[0])
     return F.linear(x, weight, bias)
+

@@ -6,7 +6,7 @@ import time
 import torch
 import torch.nn.functional as F
 
-S = 22323
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 22323
 SHAPES = [  # (name, M, K, N, kind)  kind: "fwd" y = x W^T + b ; "dgrad" dx = dy W ; "wgrad" dW = dy^T x
     ("ffn1 fwd", S, 256, 2048), ("ffn2 fwd", S, 2048, 256), ("proj256 fwd", S, 256, 256), ("proj384 fwd", S, 256, 384),
 ]
@@ -49,7 +49,7 @@ for name, M, K, N in SHAPES:
     dy = torch.randn(M, N, device="cuda")
     ref = dy.t() @ x
     gf = 2.0 * M * K * N / 1e9
-    for chunks in (3, 7, 21, 63):
+    for chunks in (3, 7, 21, 35, 63, 105):
         if M % chunks:
             continue
         r = M // chunks
