@@ -115,7 +115,7 @@ class MsdaCall:
         return algorithmic_bytes(self.N, self.S, self.Lq, self.M, self.D, self.L, self.P, 4, backward)
 
 
-def time_kernel(fn, iters=50, warmup=5):
+def time_kernel(fn, iters=200, warmup=20):
     """Average launch duration (ms) from HIP events on the launch stream."""
     for _ in range(warmup):
         fn()
@@ -259,7 +259,7 @@ def run_msda_kernels_only(args):
     dec = MsdaCall(make_inputs(device=dev, dist=args.dist, seed=103, n_queries=300 + args.n_track))
     ms_fwd = time_kernel(enc.fwd)
     kernel = enc._lib.last_kernel()
-    ms_bwd = time_kernel(enc.bwd, iters=20)
+    ms_bwd = time_kernel(enc.bwd, iters=50)
     kernel_bwd = enc._lib.last_kernel()
     ms_dec = time_kernel(dec.fwd)
     ach = enc.bytes() / (ms_fwd * 1e-3) / 1e9
