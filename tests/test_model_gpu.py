@@ -65,11 +65,13 @@ def test_two_frame_inference_on_hip_operator_matches_reference(hip_lib):
             assert np.array_equal(tracks[0].ids.cpu().numpy(), g[f"f{i}_next_ids"])
 
 
-def test_train_step_on_hip_operator_matches_reference():
+@pytest.mark.parametrize("chunks", ["0", "all", "auto"])
+def test_train_step_on_hip_operator_matches_reference(chunks):
     from memotr_amd.engine import clip_forward_backward
     from memotr_amd.models.criterion import build as build_criterion
     g = load_model_golden("M6_train_step")
     model = build_memotr_cuda(g).train()
+    model.encode_chunks = chunks        # reference frame order / one batched encode of the clip / two groups
     cfg = small_config()
     cfg.update(MATCH_COST_CLASS=2, MATCH_COST_BBOX=5, MATCH_COST_GIOU=2, LOSS_WEIGHT_FOCAL=2, LOSS_WEIGHT_L1=5,
                LOSS_WEIGHT_GIOU=2, AUX_LOSS_WEIGHT=[1.0], SAMPLE_LENGTHS=[2, 3, 4, 5])
@@ -125,6 +127,39 @@ def test_d32_model_hip_operator_vs_oracle_operator(monkeypatch, hip_lib):
     for n in g_h:
         denom = float(g_o[n].norm()) + 1e-6
         assert float((g_h[n] - g_o[n]).norm()) / denom < 5e-3, n
+
+
+def test_batched_encode_equals_per_frame_encode_d32(hip_lib):
+    """The encode half of the model over a batch of frames (what the training loop issues per clip) against the
+    same frames one at a time, at the MeMOTR head geometry (D = 32: region-tiled backward with N > 1)."""
+    import memotr_amd.modules.ms_deform_attn as mod
+    from memotr_amd.utils.nested_tensor import tensor_list_to_nested_tensor
+    torch.manual_seed(1)
+    model = build_memotr_cuda(None, hidden=256, ffn=256, NUM_ENC_LAYERS=2, NUM_DEC_LAYERS=1).train()
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, mod.MSDeformAttn):
+                m.sampling_offsets.weight.normal_(0, 0.02)
+                m.attention_weights.weight.normal_(0, 0.05)
+    imgs = [torch.randn(3, 200, 300, device="cuda") for _ in range(3)]
+    probe = torch.randn(3, 1, 256, device="cuda")
+
+    def run(batched):
+        model.zero_grad()
+        if batched:
+            mem = model(frame=tensor_list_to_nested_tensor(imgs), stage="encode")["memory"]
+        else:
+            mem = torch.cat([model(frame=tensor_list_to_nested_tensor([im]), stage="encode")["memory"] for im in imgs])
+        (mem * probe).sum().backward()
+        return mem.detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    mem_b, g_b = run(True)
+    assert "d32" in hip_lib.last_kernel()             # (the backward's kernel name lives in autograd's thread)
+    mem_s, g_s = run(False)
+    torch.testing.assert_close(mem_b, mem_s, rtol=1e-4, atol=1e-4)
+    assert g_b.keys() == g_s.keys() and len(g_b) > 20
+    for n in g_b:
+        assert float((g_b[n] - g_s[n]).norm()) / (float(g_s[n].norm()) + 1e-6) < 2e-3, n
 
 
 def test_bf16_autocast_module_tracks_fp32(hip_lib):
