@@ -74,7 +74,7 @@ class DeformableEncoderLayer(nn.Module):
         return tensor if pos is None else tensor + pos
 
     def forward_ffn(self, src):
-        hidden = self.dropout2(self.activation(long_linear(src, self.linear1.weight, self.linear1.bias)))
+        hidden = self.dropout2(long_linear(src, self.linear1.weight, self.linear1.bias, activation=self.activation))
         return self.norm2(src + self.dropout3(long_linear(hidden, self.linear2.weight, self.linear2.bias)))
 
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None):
