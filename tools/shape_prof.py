@@ -20,6 +20,10 @@ rows = [e for e in ka if e.key in ("aten::mm", "aten::addmm", "aten::bmm", "aten
 rows.sort(key=lambda e: -e.device_time_total)
 for e in rows[:45]:
     print(f"{e.device_time_total/1e3:8.2f} ms n={e.count:4d} avg {e.device_time_total/e.count:8.1f} us cpu {e.cpu_time_total/e.count:7.1f} us  {e.key:28s} {str(e.input_shapes)[:110]}")
+print("all ops by shape, self device time:")
+allops = sorted(ka, key=lambda e: -e.self_device_time_total)
+for e in allops[:70]:
+    print(f"{e.self_device_time_total/1e3:8.2f} ms n={e.count:4d} avg {e.self_device_time_total/max(e.count,1):8.1f} us  {e.key[:42]:42s} {str(e.input_shapes)[:100]}")
 print("copies by shape (device time):")
 cp = [e for e in ka if e.key in ("aten::copy_", "aten::clone", "aten::contiguous", "aten::cat", "aten::_to_copy", "aten::fill_", "aten::zero_", "aten::add_", "aten::add", "aten::mul", "aten::sum")]
 cp.sort(key=lambda e: -e.self_device_time_total)
