@@ -7,6 +7,7 @@ import torch.nn as nn
 from torch.utils.checkpoint import checkpoint
 
 from ..modules import MSDeformAttn
+from ..modules.attention import self_attention
 from ..utils.utils import inverse_sigmoid
 from .mlp import MLP
 from .utils import get_activation_layer, get_clones, pos_to_pos_embed
@@ -114,7 +115,7 @@ class DeformableDecoderLayer(nn.Module):
 
     def forward_self_attn(self, tgt, query_pos, query_mask):
         qk = self.with_pos_embed(tgt, query_pos)
-        attn, _ = self.self_attn(qk, qk, tgt, key_padding_mask=query_mask, need_weights=False)
+        attn = self_attention(self.self_attn, qk, tgt, key_padding_mask=query_mask)
         return self.norm2(tgt + self.dropout2(attn))
 
     def forward_track_attn(self, tgt, query_pos, query_mask):
@@ -122,7 +123,7 @@ class DeformableDecoderLayer(nn.Module):
         if tgt.shape[1] <= nd:
             return tgt
         qk = self.with_pos_embed(tgt, query_pos)[:, nd:]
-        attn, _ = self.track_attn(qk, qk, tgt[:, nd:], key_padding_mask=query_mask[:, nd:], need_weights=False)
+        attn = self_attention(self.track_attn, qk, tgt[:, nd:], key_padding_mask=query_mask[:, nd:])
         return torch.cat([tgt[:, :nd], self.norm4(tgt[:, nd:] + self.dropout5(attn))], dim=1)
 
     def forward_ffn(self, tgt):

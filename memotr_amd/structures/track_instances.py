@@ -17,6 +17,19 @@ _TENSOR_FIELDS = (
 )
 
 
+_EMPTY = {}
+
+
+def _empty(shape, dtype=torch.float):
+    """Shared zero-row CPU tensors for the default fields: the container is rebuilt dozens of times per frame and
+    every field is overwritten right away; a tensor with no elements cannot be modified, so sharing is safe."""
+    key = (shape, dtype)
+    t = _EMPTY.get(key)
+    if t is None:
+        t = _EMPTY[key] = torch.zeros(shape, dtype=dtype)
+    return t
+
+
 class TrackInstances:
     def __init__(self, frame_height: float = 1.0, frame_width: float = 1.0, hidden_dim: int = 256,
                  num_classes: int = 1, use_dab: bool = False):
@@ -25,21 +38,21 @@ class TrackInstances:
         self.frame_width = frame_width
         self.hidden_dim = hidden_dim
         self.num_classes = num_classes
-        self.ref_pts = torch.zeros((0, 4))
-        self.query_embed = torch.zeros((0, hidden_dim if use_dab else 2 * hidden_dim))
-        self.ids = torch.zeros((0,), dtype=torch.long)
-        self.boxes = torch.zeros((0, 4))
-        self.labels = torch.zeros((0,), dtype=torch.long)
-        self.logits = torch.zeros((0, num_classes))
-        self.matched_idx = torch.zeros((0,), dtype=torch.long)
-        self.output_embed = torch.zeros((0, hidden_dim))
-        self.disappear_time = torch.zeros((0,), dtype=torch.long)
-        self.scores = torch.zeros((0,), dtype=torch.float)
-        self.area = torch.zeros((0,), dtype=torch.float)
-        self.iou = torch.zeros((0,), dtype=torch.float)
-        self.last_output = torch.zeros((0, hidden_dim), dtype=torch.float)
-        self.long_memory = torch.zeros((0, hidden_dim), dtype=torch.float)
-        self.last_appear_boxes = torch.zeros((0, 4))
+        self.ref_pts = _empty((0, 4))
+        self.query_embed = _empty((0, hidden_dim if use_dab else 2 * hidden_dim))
+        self.ids = _empty((0,), torch.long)
+        self.boxes = _empty((0, 4))
+        self.labels = _empty((0,), torch.long)
+        self.logits = _empty((0, num_classes))
+        self.matched_idx = _empty((0,), torch.long)
+        self.output_embed = _empty((0, hidden_dim))
+        self.disappear_time = _empty((0,), torch.long)
+        self.scores = _empty((0,))
+        self.area = _empty((0,))
+        self.iou = _empty((0,))
+        self.last_output = _empty((0, hidden_dim))
+        self.long_memory = _empty((0, hidden_dim))
+        self.last_appear_boxes = _empty((0, 4))
 
     def _blank_like(self) -> "TrackInstances":
         return TrackInstances(frame_height=self.frame_height, frame_width=self.frame_width,

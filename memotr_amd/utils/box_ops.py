@@ -14,9 +14,25 @@ def box_xyxy_to_cxcywh(boxes: torch.Tensor) -> torch.Tensor:
     return torch.stack(((x1 + x2) / 2, (y1 + y2) / 2, x2 - x1, y2 - y1), dim=-1)
 
 
+_TO_XYXY = {}
+
+
 def box_cxcywh_to_xyxy(boxes: torch.Tensor) -> torch.Tensor:
-    cx, cy, w, h = boxes.unbind(-1)
-    return torch.stack((cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h), dim=-1)
+    """(cx - w/2, cy - h/2, cx + w/2, cy + h/2) as ONE product with a constant 4x4 matrix instead of unbind +
+    4 x (mul, add/sub) + stack: 1 kernel instead of 9 forward (and 1 instead of ~14 backward), ~9 calls per frame
+    in the launch-bound criterion / matcher.  Bit-identical to the elementwise form: every product is with 0, 1 or
+    +-0.5 (exact) and each output has two non-zero terms, so there is a single rounding in either form."""
+    if not boxes.is_floating_point() or boxes.dtype in (torch.float16, torch.bfloat16):
+        cx, cy, w, h = boxes.unbind(-1)
+        return torch.stack((cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h), dim=-1)
+    key = (boxes.device, boxes.dtype)
+    m = _TO_XYXY.get(key)
+    if m is None:
+        m = torch.tensor([[1, 0, 1, 0], [0, 1, 0, 1], [-0.5, 0, 0.5, 0], [0, -0.5, 0, 0.5]], dtype=boxes.dtype,
+                         device=boxes.device)
+        _TO_XYXY[key] = m
+    with torch.autocast(device_type=boxes.device.type, enabled=False):      # never in reduced precision
+        return boxes @ m
 
 
 def box_cxcywh_to_xywh(boxes: torch.Tensor) -> torch.Tensor:

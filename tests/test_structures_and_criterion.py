@@ -126,3 +126,27 @@ def test_matcher_reference_call_signature():
     np.testing.assert_allclose(cs[0].numpy(), c1.numpy(), rtol=1e-5, atol=1e-6)
     with pytest.raises(AssertionError):
         HungarianMatcher(0, 0, 0)
+
+
+def _xyxy_elementwise(b):
+    cx, cy, w, h = b.unbind(-1)
+    return torch.stack((cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h), dim=-1)
+
+
+@pytest.mark.parametrize("device", ["cpu", pytest.param("cuda", marks=pytest.mark.gpu)])
+def test_box_conversion_as_matrix_product_is_bit_identical(device):
+    """utils/box_ops.py:21-25 of the reference is elementwise; the product with the constant 4x4 matrix must
+    give the same bits (products with 0 / 1 / 0.5 are exact, one rounding per output) and the same gradient."""
+    from memotr_amd.utils.box_ops import box_cxcywh_to_xyxy
+    g = torch.Generator().manual_seed(5)
+    for shape in ((7, 4), (6, 300, 4), (6, 1, 1, 4), (0, 4), (100000, 4)):
+        x = (torch.randn(shape, generator=g) * 10.0).to(device).requires_grad_(True)
+        got, want = box_cxcywh_to_xyxy(x), _xyxy_elementwise(x)
+        assert torch.equal(got, want), shape
+        if x.numel():
+            seed = torch.randn(shape, generator=g).to(device)
+            (ga,) = torch.autograd.grad(got, x, seed)
+            (gb,) = torch.autograd.grad(want, x, seed)
+            assert torch.equal(ga, gb), shape
+    sig = torch.rand((50, 4), generator=g).to(device)                    # sigmoid-range boxes, as in the criterion
+    assert torch.equal(box_cxcywh_to_xyxy(sig), _xyxy_elementwise(sig))
