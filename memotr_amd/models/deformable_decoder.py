@@ -36,19 +36,21 @@ class DeformableDecoder(nn.Module):
     def forward(self, tgt, reference_points, src, src_spatial_shapes, src_level_start_index, src_valid_ratios,
                 query_pos, query_mask, src_padding_mask):
         """tgt (B,Nq,C); reference_points (B,Nq,4) in [0,1]; src (B,S,C).
-        Returns stacks over layers: outputs (n,B,Nq,C), refined references (n,B,Nq,4), layer inputs (n,B,Nq,C)."""
+        Returns stacks over layers: outputs (n,B,Nq,C), refined references (n,B,Nq,4), layer inputs (n,B,Nq,C),
+        refined boxes with their graph (n,B,Nq,4) or None without box refinement."""
         if not self.return_intermediate:
             raise NotImplementedError("Not Support for no Inter Outputs.")
         nd = self.n_det_queries
         output = tgt
-        outs, refs, layer_inputs = [], [], []
+        outs, refs, layer_inputs, boxes = [], [], [], []
         ref_backup = None
+        ratios4 = torch.cat([src_valid_ratios, src_valid_ratios], -1)[:, None]      # same for every layer
         for lid, layer in enumerate(self.layers):
             if lid == 0 and not self.use_dab:        # Deformable-DETR variant: 2-d references
                 ref_backup = reference_points.clone()
                 reference_points = reference_points[:, :, :2]
             if reference_points.shape[-1] == 4:
-                ref_in = reference_points[:, :, None] * torch.cat([src_valid_ratios, src_valid_ratios], -1)[:, None]
+                ref_in = reference_points[:, :, None] * ratios4
             else:
                 assert reference_points.shape[-1] == 2
                 ref_in = reference_points[:, :, None] * src_valid_ratios[:, None]
@@ -71,6 +73,7 @@ class DeformableDecoder(nn.Module):
                 else:
                     xy = delta[..., :2] + inverse_sigmoid(reference_points)
                     new_ref = torch.cat((xy, delta[..., 2:]), -1).sigmoid()
+                boxes.append(new_ref)
                 if not merge:   # track queries did not go through the layer: keep their anchors
                     keep = reference_points if self.use_dab else ref_backup
                     reference_points = torch.cat((new_ref[:, :nd].detach(), keep[:, nd:]), dim=1)
@@ -78,7 +81,12 @@ class DeformableDecoder(nn.Module):
                     reference_points = new_ref.detach()
             outs.append(output)
             refs.append(reference_points)
-        return torch.stack(outs), torch.stack(refs), torch.stack(layer_inputs)
+        # ``boxes``: the refined boxes of every layer BEFORE the detach -- exactly what the box head computes from
+        # the same layer output, reference and (aliased) bbox_embed weights (reference models/memotr.py:131-143
+        # recomputes it: 3 GEMMs + inverse_sigmoid + sigmoid per layer, forward and backward).  The decoder's own
+        # use of them is detached, so handing this one copy to the head leaves values and gradients unchanged.
+        return (torch.stack(outs), torch.stack(refs), torch.stack(layer_inputs),
+                torch.stack(boxes) if len(boxes) == len(outs) else None)
 
 
 class DeformableDecoderLayer(nn.Module):

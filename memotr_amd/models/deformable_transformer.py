@@ -110,7 +110,7 @@ class DeformableTransformer(nn.Module):
         return {"memory": memory, "spatial_shapes": spatial_shapes, "level_start_index": level_start_index,
                 "valid_ratios": valid_ratios, "mask_flatten": mask_flatten}
 
-    def decode(self, enc: dict, query_embed, ref_pts, query_mask):
+    def decode(self, enc: dict, query_embed, ref_pts, query_mask, return_boxes: bool = False):
         """Query-dependent half: the decoder over an ``encode`` result."""
         assert query_embed is not None
         memory = enc["memory"]
@@ -121,10 +121,12 @@ class DeformableTransformer(nn.Module):
             query_pos, tgt = torch.split(query_embed, c, dim=2)
         assert ref_pts is not None, "ref_pts should not be None."
         init_reference_points = ref_pts.sigmoid()
-        output, res_reference_points, inter_queries = self.decoder(
+        output, res_reference_points, inter_queries, boxes = self.decoder(
             tgt=tgt, reference_points=init_reference_points, src=memory, src_spatial_shapes=enc["spatial_shapes"],
             src_level_start_index=enc["level_start_index"], src_valid_ratios=enc["valid_ratios"],
             query_pos=query_pos, query_mask=query_mask, src_padding_mask=enc["mask_flatten"])
+        if return_boxes:
+            return output, init_reference_points, res_reference_points, inter_queries, boxes
         return output, init_reference_points, res_reference_points, inter_queries
 
     def forward(self, srcs: List[torch.Tensor], masks: List[torch.Tensor], pos_embeds: List[torch.Tensor],

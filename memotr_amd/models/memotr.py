@@ -125,12 +125,18 @@ class MeMOTR(nn.Module):
         query_embed = self.get_query_embed(tracks).to(device)               # (B, Nd+Nt, C | 2C)
         query_mask = self.get_query_mask(tracks).to(device)                 # (B, Nd+Nt) bool
 
-        outputs, init_reference, inter_references, inter_queries = self.transformer.decode(
-            encoded, query_embed=query_embed, ref_pts=reference_points, query_mask=query_mask)
+        outputs, init_reference, inter_references, inter_queries, refined = self.transformer.decode(
+            encoded, query_embed=query_embed, ref_pts=reference_points, query_mask=query_mask, return_boxes=True)
         assert outputs.ndim == 4, \
             f"Deformable Transformer's outputs should have shape (n_dec_layers, B, Nd+Nq, C, but get n_dim={outputs.ndim}"
         classes, boxes = [], []
+        # with box refinement the decoder already evaluated this head (same layer output, same reference, aliased
+        # bbox_embed weights) to move its anchors: reuse that one evaluation instead of repeating it per layer
+        reuse = refined is not None and self.transformer.decoder.bbox_embed is self.bbox_embed
         for lvl in range(outputs.shape[0]):
+            classes.append(self.class_embed[lvl](outputs[lvl]))
+            if reuse:
+                continue
             reference = inverse_sigmoid(init_reference if lvl == 0 else inter_references[lvl - 1])
             box = self.bbox_embed[lvl](outputs[lvl])
             if reference.shape[-1] == 4:
@@ -138,10 +144,9 @@ class MeMOTR(nn.Module):
             else:
                 assert reference.shape[-1] == 2, f"Reference should have only 2 coord, but get {reference.shape[-1]}."
                 box = torch.cat((box[..., :2] + reference, box[..., 2:]), -1)
-            classes.append(self.class_embed[lvl](outputs[lvl]))
             boxes.append(box.sigmoid())
         classes = torch.stack(classes, dim=0)
-        boxes = torch.stack(boxes, dim=0)
+        boxes = refined if reuse else torch.stack(boxes, dim=0)
         res = {
             "pred_logits": classes[-1],
             "pred_bboxes": boxes[-1],

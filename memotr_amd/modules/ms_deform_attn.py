@@ -27,6 +27,19 @@ def _is_power_of_2(n) -> bool:
     return (n & (n - 1) == 0) and n != 0
 
 
+def _level_sizes(spatial_shapes: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """(L, 2) float (W, H) of an (L, 2) int64 (H, W) tensor, cached on the tensor object (the transformer keeps one
+    ``spatial_shapes`` tensor per pyramid geometry)."""
+    cached = getattr(spatial_shapes, "_msda_wh", None)
+    if cached is None or cached[0] != (spatial_shapes._version, dtype):
+        cached = ((spatial_shapes._version, dtype), spatial_shapes.flip(-1).to(dtype))
+        try:
+            spatial_shapes._msda_wh = cached
+        except AttributeError:      # tensor subclasses without a __dict__
+            pass
+    return cached[1]
+
+
 class MSDeformAttn(nn.Module):
     def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4, sigmoid_attn=False, visualize=False):
         super().__init__()
@@ -92,8 +105,9 @@ class MSDeformAttn(nn.Module):
             # sampling locations / attention weights / index arithmetic stay fp32
             proj = proj.float()
             reference_points = reference_points.float()
-        offsets = proj[..., :n_off].reshape(N, Lq, M, L, P, 2)
-        logits = proj[..., n_off:].reshape(N, Lq, M, L * P)
+        # views (only the last dim is split), not reshape copies: the ops below write contiguous results anyway
+        offsets = proj[..., :n_off].unflatten(-1, (M, L, P, 2))
+        logits = proj[..., n_off:].unflatten(-1, (M, L * P))
         if self.sigmoid_attn:
             attn = logits.sigmoid()
         else:
@@ -101,11 +115,17 @@ class MSDeformAttn(nn.Module):
         attn = attn.view(N, Lq, M, L, P)
 
         if reference_points.shape[-1] == 2:
-            wh = input_spatial_shapes.flip(-1).to(offsets.dtype)  # (L, 2) as (W, H)
+            wh = _level_sizes(input_spatial_shapes, offsets.dtype)  # (L, 2) as (W, H), cached per pyramid tensor
             loc = reference_points[:, :, None, :, None, :] + offsets / wh[None, None, None, :, None, :]
         elif reference_points.shape[-1] == 4:
-            loc = reference_points[:, :, None, :, None, :2] \
-                + offsets / P * reference_points[:, :, None, :, None, 2:] * 0.5
+            if P & (P - 1) == 0:
+                # offsets / P * wh * 0.5 with P a power of two: scaling by powers of two commutes with rounding,
+                # so folding 0.5 / P into the (small) reference tensor gives the same bits with two fewer kernels
+                loc = reference_points[:, :, None, :, None, :2] \
+                    + offsets * (reference_points[:, :, None, :, None, 2:] * (0.5 / P))
+            else:
+                loc = reference_points[:, :, None, :, None, :2] \
+                    + offsets / P * reference_points[:, :, None, :, None, 2:] * 0.5
         else:
             raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead.".format(
                 reference_points.shape[-1]))
