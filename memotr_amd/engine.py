@@ -124,11 +124,7 @@ def clip_forward_backward(model: nn.Module, criterion, batch: dict, device, use_
                           accumulation_steps: int = 1, backward: bool = True):
     """One clip through model + criterion (+ backward).  Returns (loss tensor, loss_dict)."""
     core = get_model(model)
-    tracks = TrackInstances.init_tracks(batch=batch, hidden_dim=core.hidden_dim, num_classes=core.num_classes,
-                                        device=device, use_dab=use_dab)
-    criterion.init_a_clip(batch=batch, hidden_dim=core.hidden_dim, num_classes=core.num_classes, device=device)
     clip_len = len(batch["imgs"][0])
-
     n_clips = len(batch["imgs"])
 
     def frames(lo, hi):
@@ -154,10 +150,23 @@ def clip_forward_backward(model: nn.Module, criterion, batch: dict, device, use_
         for j in range(n):
             encoded[lo + j] = {k: (per_frame[k][j] if per_frame[k] is not None else v) for k, v in enc.items()}
 
-    if chunks is not None and not lazy:
+    def set_up():
+        tr = TrackInstances.init_tracks(batch=batch, hidden_dim=core.hidden_dim, num_classes=core.num_classes,
+                                        device=device, use_dab=use_dab)
+        criterion.init_a_clip(batch=batch, hidden_dim=core.hidden_dim, num_classes=core.num_classes, device=device)
+        return tr
+
+    # ground truth already on the device: the set-up is host-only work, so queue the first encode before it;
+    # otherwise its (pageable) uploads would wait behind the encode -- do them first
+    resident = all(v.device.type == torch.device(device).type for v in batch["infos"][0][0].values()
+                   if torch.is_tensor(v))
+    tracks = None if resident else set_up()
+    if chunks is not None:
         encode_chunk(0)
+    if tracks is None:
+        tracks = set_up()
     for frame_idx in range(clip_len):
-        if lazy and frame_idx in starts:            # just in time: the group is encoded right before its first decode
+        if lazy and frame_idx in starts and frame_idx > 0:   # just in time: encoded right before its first decode
             encode_chunk(starts.index(frame_idx))
         if chunks is None:                          # the reference's order: everything of a frame, then the next
             res = model(frame=frames(frame_idx, frame_idx + 1), tracks=tracks)
