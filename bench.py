@@ -36,8 +36,8 @@ HBM_PEAK_GBPS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=os.environ.get("MEMOTR_BENCH_WORKLOAD", "train"))
     ap.add_argument("--dist", default="encoder_like", choices=["encoder_like", "uniform"])
     ap.add_argument("--n-track", type=int, default=20, help="track queries carried into the frame (Lq = 300 + n)")
