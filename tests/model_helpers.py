@@ -104,3 +104,16 @@ def assert_tracks_close(tr, g, prefix, atol=2e-5, skip=()):
             assert np.array_equal(got, want), k
         else:
             np.testing.assert_allclose(got, want, rtol=1e-4, atol=atol, err_msg=k)
+
+
+def build_small_memotr():
+    """Random-init MeMOTR at the fixtures' reduced size (stand-in backbone body)."""
+    from memotr_amd.models.backbone import BackboneWithPE
+    from memotr_amd.models.deformable_transformer import build as build_tr
+    from memotr_amd.models.memotr import MeMOTR
+    from memotr_amd.models.position_embedding import build as build_pe
+    from memotr_amd.models.query_updater import build as build_qu
+    cfg = small_config()
+    return MeMOTR(backbone=BackboneWithPE(TinyBackbone(), build_pe(cfg)), transformer=build_tr(cfg),
+                  query_updater=build_qu(cfg), num_classes=1, n_det_queries=20, n_feature_levels=4, hidden_dim=64,
+                  ffn_dim=128, dropout=0.0, use_dab=True)

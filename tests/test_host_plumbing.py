@@ -1,0 +1,129 @@
+"""CPU checks of the host-side plumbing added around the reference's frame loop: encode grouping, the lean
+self-attention, the activation-before-reshape linear, BLAS selection knobs and the encode/decode split."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class _Core:
+    pass
+
+
+@pytest.mark.parametrize("spec,clip_len,want", [
+    (None, 5, ([3, 2], True)), ("auto", 5, ([3, 2], True)), ("auto", 4, ([3, 1], True)), ("auto", 2, ([2], True)),
+    ("auto", 1, ([1], True)), ("all", 5, ([5], False)), ("0", 5, (None, False)), ("1", 3, ([1, 1, 1], False)),
+    ("lazy:2", 5, ([2, 2, 1], True)), ("1,4", 5, ([1, 4], False)), ([1, 1, 3], 5, ([1, 1, 3], False)),
+    (8, 5, ([5], False)), ("2,9", 5, ([2, 3], False)),
+])
+def test_encode_chunks_parsing(monkeypatch, spec, clip_len, want):
+    from memotr_amd.engine import encode_chunks
+    monkeypatch.delenv("MEMOTR_ENCODE_CHUNKS", raising=False)
+    core = _Core()
+    if spec is not None:
+        core.encode_chunks = spec
+    assert encode_chunks(core, clip_len) == want
+    groups = want[0]
+    if groups is not None:
+        assert sum(groups) == clip_len and all(g > 0 for g in groups)
+
+
+def test_encode_chunks_env_and_checkpoint(monkeypatch):
+    from memotr_amd.engine import encode_chunks
+    monkeypatch.setenv("MEMOTR_ENCODE_CHUNKS", "all")
+    assert encode_chunks(_Core(), 4) == ([4], False)
+    core = _Core()
+    core.use_checkpoint = True                       # activation checkpointing keeps the reference's frame order
+    assert encode_chunks(core, 4) == (None, False)
+
+
+@pytest.mark.parametrize("masked", [False, True])
+def test_self_attention_equals_multihead_attention(masked):
+    """models/deformable_decoder.py self_attn call of the reference: mha(q=k=tgt+pos, v=tgt, key_padding_mask)."""
+    from memotr_amd.modules.attention import self_attention
+    torch.manual_seed(0)
+    mha = nn.MultiheadAttention(64, 8, dropout=0.0, batch_first=True).train()
+    x = torch.randn(2, 37, 64, requires_grad=True)
+    pos = torch.randn(2, 37, 64)
+    mask = None
+    if masked:
+        mask = torch.zeros(2, 37, dtype=torch.bool)
+        mask[1, 30:] = True
+    got = self_attention(mha, x + pos, x, mask)
+    want = mha(x + pos, x + pos, x, key_padding_mask=mask, need_weights=False)[0]
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-6)
+    params = [x] + list(mha.parameters())
+    g_got = torch.autograd.grad(got.square().sum(), params)
+    g_want = torch.autograd.grad(want.square().sum(), params)
+    for a, b in zip(g_got, g_want):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5)
+
+
+def test_self_attention_falls_back_for_other_layouts():
+    from memotr_amd.modules.attention import self_attention
+    torch.manual_seed(1)
+    mha = nn.MultiheadAttention(32, 4, batch_first=True, kdim=16, vdim=16)       # separate projection weights
+    q = torch.randn(1, 5, 32)
+    with pytest.raises(Exception):                   # the module itself rejects value of the wrong width
+        self_attention(mha, q, q, None)
+
+
+def test_long_linear_applies_activation_before_the_reshape():
+    """An in-place ReLU on the reshaped view of the custom Function's output makes autograd insert CopySlices
+    (whole-gradient copies); applied through ``activation=`` the graph is ReLU -> view."""
+    from memotr_amd.modules.linear import long_linear
+    torch.manual_seed(2)
+    x = torch.randn(1, 64, 16, requires_grad=True)
+    w = torch.randn(32, 16, requires_grad=True)
+    b = torch.randn(32, requires_grad=True)
+    h = long_linear(x, w, b, min_rows=8, activation=nn.ReLU(True))
+    assert type(h.grad_fn).__name__ == "ViewBackward0"
+    assert type(h.grad_fn.next_functions[0][0]).__name__ == "ReluBackward0"
+    ref = torch.relu(F.linear(x, w, b))
+    assert torch.equal(h, ref)
+    g = torch.autograd.grad(h.sum(), (x, w, b))
+    g_ref = torch.autograd.grad(ref.sum(), (x, w, b))
+    for a, r in zip(g, g_ref):
+        torch.testing.assert_close(a, r, rtol=1e-5, atol=1e-5)
+    small = long_linear(x, w, b, activation=torch.relu)          # below min_rows: plain F.linear path
+    assert torch.equal(small, ref)
+
+
+def test_blas_selection_knobs(monkeypatch):
+    from memotr_amd.modules import linear
+    before = torch.backends.cuda.preferred_blas_library()
+    try:
+        monkeypatch.setenv("MEMOTR_BLAS", "keep")
+        assert linear.configure_blas() == "keep"
+        assert torch.backends.cuda.preferred_blas_library() == before
+        monkeypatch.setenv("MEMOTR_BLAS", "rocblas")
+        assert linear.configure_blas() == "rocblas"
+        assert torch.backends.cuda.preferred_blas_library() == torch._C._BlasBackend.Cublas
+        with linear.prefer_blas("cublaslt"):
+            assert torch.backends.cuda.preferred_blas_library() == torch._C._BlasBackend.Cublaslt
+        assert torch.backends.cuda.preferred_blas_library() == torch._C._BlasBackend.Cublas     # restored
+    finally:
+        torch.backends.cuda.preferred_blas_library(before)
+
+
+def test_model_forward_equals_encode_then_decode(monkeypatch):
+    """``model(frame, tracks)`` (the reference contract) == ``model(tracks=, encoded=model(frame=, stage="encode"))``,
+    and a batched encode split per frame equals the per-frame encodes."""
+    from model_helpers import build_small_memotr, patch_operator
+    from memotr_amd.structures.track_instances import TrackInstances
+    from memotr_amd.utils.nested_tensor import tensor_list_to_nested_tensor
+    patch_operator(monkeypatch)
+    torch.manual_seed(3)
+    model = build_small_memotr().eval()
+    imgs = [torch.randn(3, 96, 128), torch.randn(3, 96, 128)]
+    tracks = [TrackInstances(hidden_dim=model.hidden_dim, num_classes=model.num_classes, use_dab=True)]
+    with torch.no_grad():
+        whole = model(frame=tensor_list_to_nested_tensor([imgs[0]]), tracks=tracks)
+        enc = model(frame=tensor_list_to_nested_tensor([imgs[0]]), stage="encode")
+        halves = model(tracks=tracks, encoded=enc)
+        both = model(frame=tensor_list_to_nested_tensor(imgs), stage="encode")
+        enc1 = model(frame=tensor_list_to_nested_tensor([imgs[1]]), stage="encode")
+    for k in ("pred_logits", "pred_bboxes", "outputs", "last_ref_pts"):
+        assert torch.equal(whole[k], halves[k]), k
+    torch.testing.assert_close(both["memory"][0:1], enc["memory"], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(both["memory"][1:2], enc1["memory"], rtol=1e-5, atol=1e-5)
