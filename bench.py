@@ -8,7 +8,7 @@ Prints ONE JSON line on rank 0 (contract in the task description).  Workloads:
   msda   (kernel path) one step = the MSDeformAttn work of one 800x1333 training frame:
          6 encoder calls (Lq = S = 22323) + 6 decoder calls (Lq = 300 + n_track), forward and
          backward, fp32, inputs resident in HBM.  value = frames/s of that path.
-  train  (added when the model path lands) one step = one clip train step of train_dancetrack.yaml.
+  train  (default) one step = one clip train step of train_dancetrack.yaml (clip of 5 frames, 800x1333).
 
 Every rank works on its own synthetic frame (clips shard by rank; no data-path collective), so
 scaling is "weak".  The JSON carries
@@ -25,7 +25,12 @@ import os
 import sys
 import time
 
-import torch
+# Kernel arguments in device memory: the step runs ~13 k kernels, most of them a few microseconds long, and the
+# argument fetch is part of each one's launch latency (203 vs 207 ms per step, tools/ab_step.py).  Read by the HIP
+# runtime when it initialises, hence before torch is imported.
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
