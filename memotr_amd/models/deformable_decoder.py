@@ -131,7 +131,9 @@ class DeformableDecoderLayer(nn.Module):
         if tgt.shape[1] <= nd:
             return tgt
         qk = self.with_pos_embed(tgt, query_pos)[:, nd:]
-        attn = self_attention(self.track_attn, qk, tgt[:, nd:], key_padding_mask=query_mask[:, nd:])
+        track_mask = query_mask[:, nd:]
+        track_mask._no_padding = getattr(query_mask, "_no_padding", False)
+        attn = self_attention(self.track_attn, qk, tgt[:, nd:], key_padding_mask=track_mask)
         return torch.cat([tgt[:, :nd], self.norm4(tgt[:, nd:] + self.dropout5(attn))], dim=1)
 
     def forward_ffn(self, tgt):
@@ -146,6 +148,7 @@ class DeformableDecoderLayer(nn.Module):
             track_tgt = tgt[:, nd:, :]
             tgt, query_pos = tgt[:, :nd, :], query_pos[:, :nd, :]
             reference_points, query_mask = reference_points[:, :nd], query_mask[:, :nd]
+            query_mask._no_padding = True             # padding only ever sits behind the track queries
         if self.extra_track_attn:
             tgt = self.forward_track_attn(tgt, query_pos, query_mask)
         tgt = self.forward_self_attn(tgt, query_pos, query_mask)

@@ -207,6 +207,9 @@ class MeMOTR(nn.Module):
         for i, n in enumerate(lens):
             if n > 0:
                 mask[i, self.n_det_queries + n:] = True
+        # host-side knowledge the attention can use without reading the mask back: nothing is masked unless two
+        # clips of the batch carry different (non-zero) numbers of tracks -- never at batch size 1
+        mask._no_padding = not any(0 < n < max_len for n in lens)
         return mask
 
     def postprocess_single_frame(self, previous_tracks: List[TrackInstances], new_tracks: List[TrackInstances],

@@ -19,7 +19,9 @@ import torch.nn.functional as F
 def self_attention(mha: nn.MultiheadAttention, qk: torch.Tensor, v: torch.Tensor,
                    key_padding_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``mha(qk, qk, v, key_padding_mask=..., need_weights=False)[0]`` for a batch-first module with packed
-    input projections.  ``qk``/``v``: (B, L, E); ``key_padding_mask``: (B, L) bool, True = ignore that key."""
+    input projections.  ``qk``/``v``: (B, L, E); ``key_padding_mask``: (B, L) bool, True = ignore that key.  A mask
+    tagged ``_no_padding = True`` by its maker (``MeMOTR.get_query_mask`` knows the track counts on the host) is
+    all-False and is dropped, which lets the fused attention run without a bias tensor."""
     if (not mha.batch_first or not mha._qkv_same_embed_dim or mha.in_proj_bias is None or mha.bias_k is not None
             or mha.add_zero_attn):
         return mha(qk, qk, v, key_padding_mask=key_padding_mask, need_weights=False)[0]
@@ -31,7 +33,7 @@ def self_attention(mha: nn.MultiheadAttention, qk: torch.Tensor, v: torch.Tensor
     q, k = qk_p[:, :, 0].transpose(1, 2), qk_p[:, :, 1].transpose(1, 2)            # (B, H, L, d)
     vh = F.linear(v, w[2 * E:], b[2 * E:]).view(B, L, H, d).transpose(1, 2)
     mask = None
-    if key_padding_mask is not None:
+    if key_padding_mask is not None and not getattr(key_padding_mask, "_no_padding", False):
         mask = ~key_padding_mask.view(B, 1, 1, L)                                   # True = take part
     out = F.scaled_dot_product_attention(q, k, vh, attn_mask=mask,
                                          dropout_p=mha.dropout if mha.training else 0.0)

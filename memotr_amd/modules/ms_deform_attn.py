@@ -79,6 +79,28 @@ class MSDeformAttn(nn.Module):
         xavier_uniform_(self.output_proj.weight.data)
         constant_(self.output_proj.bias.data, 0.0)
 
+    def _fused_query_projection(self):
+        """Stacked (offsets; attention-logits) weight and bias for the single query GEMM.  The module runs once per
+        frame (decoder) or per encode group within a train step, always with the same parameters, so the two
+        concatenations are made once per step: the cached tensors (and the autograd edge to the four parameters)
+        are reused until a parameter changes or a backward pass has flowed through them."""
+        so, aw = self.sampling_offsets, self.attention_weights
+        key = (id(so.weight), id(aw.weight), so.weight._version, aw.weight._version, so.bias._version,
+               aw.bias._version, so.weight.device, so.weight.dtype, torch.is_grad_enabled())
+        cached = self.__dict__.get("_fused_qproj")
+        if cached is None or cached[0] != key:
+            w = torch.cat((so.weight, aw.weight), 0)
+            b = torch.cat((so.bias, aw.bias), 0)
+            if w.requires_grad:
+                w.register_hook(self._forget_fused_query_projection)
+            cached = (key, w, b)
+            self.__dict__["_fused_qproj"] = cached
+        return cached[1], cached[2]
+
+    def _forget_fused_query_projection(self, grad):
+        self.__dict__.pop("_fused_qproj", None)      # the graph behind the cached tensors ends with this backward
+        return None
+
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
                 input_padding_mask=None):
         """
@@ -97,8 +119,7 @@ class MSDeformAttn(nn.Module):
 
         # one GEMM for both query projections
         n_off = M * L * P * 2
-        w = torch.cat((self.sampling_offsets.weight, self.attention_weights.weight), 0)
-        b = torch.cat((self.sampling_offsets.bias, self.attention_weights.bias), 0)
+        w, b = self._fused_query_projection()
         proj = long_linear(query, w, b)
         if proj.dtype == torch.bfloat16:
             # bf16 mixed precision (no reference counterpart; policy in DESIGN.md): GEMMs and `value` in bf16,

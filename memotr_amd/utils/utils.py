@@ -44,5 +44,6 @@ def yaml_to_dict(path: str) -> dict:
 
 def inverse_sigmoid(x: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
     """logit with both odds clamped at eps (utils/utils.py:61-74)."""
-    x = x.clamp(min=0, max=1)
-    return torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))
+    # clamp(clamp(x, 0, 1), min=eps) == clamp(x, eps, 1) and clamp(1 - clamp(x, 0, 1), min=eps) == clamp(1 - x, eps, 1)
+    # value for value and gradient mask for gradient mask (eps > 0): one kernel fewer, forward and backward
+    return torch.log(x.clamp(min=eps, max=1) / (1 - x).clamp(min=eps, max=1))

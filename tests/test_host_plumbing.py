@@ -127,3 +127,32 @@ def test_model_forward_equals_encode_then_decode(monkeypatch):
         assert torch.equal(whole[k], halves[k]), k
     torch.testing.assert_close(both["memory"][0:1], enc["memory"], rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(both["memory"][1:2], enc1["memory"], rtol=1e-5, atol=1e-5)
+
+
+def test_query_mask_tag_drops_an_all_false_mask():
+    """get_query_mask tags the mask when the host knows nothing is padded; the attention then runs mask-free."""
+    from model_helpers import build_small_memotr
+    from memotr_amd.modules.attention import self_attention
+    from memotr_amd.structures.track_instances import TrackInstances
+    torch.manual_seed(4)
+    model = build_small_memotr()
+
+    def tracks_with(n):
+        t = TrackInstances(hidden_dim=model.hidden_dim, num_classes=model.num_classes, use_dab=True)
+        t.query_embed = torch.randn(n, model.hidden_dim)
+        t.ref_pts = torch.randn(n, 4)
+        return t
+
+    assert model.get_query_mask([tracks_with(0)])._no_padding
+    assert model.get_query_mask([tracks_with(3)])._no_padding
+    assert model.get_query_mask([tracks_with(3), tracks_with(3)])._no_padding
+    ragged = model.get_query_mask([tracks_with(3), tracks_with(1)])
+    assert not ragged._no_padding and bool(ragged[1, -2:].all()) and not bool(ragged[0].any())
+    assert model.get_query_mask([tracks_with(3), tracks_with(0)])._no_padding      # reference :271-274: stays unmasked
+
+    mha = nn.MultiheadAttention(64, 8, batch_first=True)
+    x = torch.randn(1, 9, 64)
+    mask = torch.zeros(1, 9, dtype=torch.bool)
+    mask._no_padding = True
+    torch.testing.assert_close(self_attention(mha, x, x, mask), mha(x, x, x, need_weights=False)[0], rtol=1e-5,
+                               atol=1e-6)
