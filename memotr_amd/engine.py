@@ -8,6 +8,8 @@ for the data pipeline, which is out of scope.
 """
 from __future__ import annotations
 
+import contextlib
+
 from typing import Dict, List, Tuple
 
 import os
@@ -121,8 +123,11 @@ DEFAULT_ENCODE_CHUNKS = "auto"
 
 
 def clip_forward_backward(model: nn.Module, criterion, batch: dict, device, use_dab: bool = True,
-                          accumulation_steps: int = 1, backward: bool = True):
-    """One clip through model + criterion (+ backward).  Returns (loss tensor, loss_dict)."""
+                          accumulation_steps: int = 1, backward: bool = True, no_grad_frames: int = None):
+    """One clip through model + criterion (+ backward).  Returns (loss tensor, loss_dict).
+    ``no_grad_frames`` (config NO_GRAD_FRAMES, reference train_engine.py:202-230): the first that many frames run
+    without a graph, and all but the last of them without query augmentation; they take the reference's frame
+    order (no batched encode: nothing of theirs is differentiated)."""
     core = get_model(model)
     clip_len = len(batch["imgs"][0])
     n_clips = len(batch["imgs"])
@@ -136,6 +141,8 @@ def clip_forward_backward(model: nn.Module, criterion, batch: dict, device, use_
     # Same operations per frame (FrozenBN / GroupNorm / LayerNorm are per-sample), 1/len(chunk) of the kernel
     # launches, larger GEMMs and convolutions; the decoder still runs frame by frame on the carried tracks.
     chunks, lazy = encode_chunks(core, clip_len)
+    if no_grad_frames:
+        chunks, lazy = None, False
     starts = [sum(chunks[:i]) for i in range(len(chunks))] if chunks is not None else []
     encoded = {}                                   # frame index -> encode result of that frame
 
@@ -169,9 +176,17 @@ def clip_forward_backward(model: nn.Module, criterion, batch: dict, device, use_
         if lazy and frame_idx in starts and frame_idx > 0:   # just in time: encoded right before its first decode
             encode_chunk(starts.index(frame_idx))
         if chunks is None:                          # the reference's order: everything of a frame, then the next
-            res = model(frame=frames(frame_idx, frame_idx + 1), tracks=tracks)
-            previous, new, unmatched = criterion.process_single_frame(model_outputs=res, tracked_instances=tracks,
-                                                                      frame_idx=frame_idx)
+            frozen = bool(no_grad_frames) and frame_idx < no_grad_frames
+            with (torch.no_grad() if frozen else contextlib.nullcontext()):
+                res = model(frame=frames(frame_idx, frame_idx + 1), tracks=tracks)
+                previous, new, unmatched = criterion.process_single_frame(model_outputs=res,
+                                                                          tracked_instances=tracks,
+                                                                          frame_idx=frame_idx)
+                if frozen and frame_idx < clip_len - 1:
+                    tracks = core.postprocess_single_frame(previous, new, unmatched,
+                                                           no_augment=frame_idx < no_grad_frames - 1)
+            if frozen:
+                continue
         else:
             res = model(tracks=tracks, encoded=encoded.pop(frame_idx))
             pending = criterion.begin_frame(model_outputs=res, tracked_instances=tracks, frame_idx=frame_idx)

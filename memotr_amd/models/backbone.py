@@ -27,12 +27,22 @@ class FrozenBatchNorm2d(nn.Module):
     def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
                               error_msgs):
         state_dict.pop(prefix + "num_batches_tracked", None)
+        self._folded = None
         super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
                                       error_msgs)
 
     def _apply(self, fn, *args, **kwargs):
         self._folded = None                      # .to() / .cuda() replace the buffers
         return super()._apply(fn, *args, **kwargs)
+
+    def train(self, mode: bool = True):
+        self._folded = None                      # a mode switch is the cheap moment to forget `.data` writes too
+        return super().train(mode)
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state["_folded"] = None                  # derived tensors do not travel with pickles / deepcopies
+        return state
 
     def scale_shift(self):
         """(scale, shift), cached: the four buffers are constants, so the five tiny kernels that derive them run

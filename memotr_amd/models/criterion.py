@@ -139,7 +139,10 @@ class ClipCriterion:
             n_gt_list.append(n_gt)
             if n_tr > 0 and n_gt > 0:
                 eq = tr.ids[:, None] == gt.ids[None, :]
-                tr.matched_idx = torch.where(eq.any(1), eq.float().argmax(1), torch.full_like(tr.ids, -1))
+                # index of the LAST ground truth carrying the id (the reference's ``gt_ids_to_idx`` dict keeps the
+                # last one when a frame repeats an id, criterion.py:166-170), -1 when the identity is gone
+                order = torch.arange(1, n_gt + 1, device=eq.device)
+                tr.matched_idx = (eq * order).amax(1) - 1
                 free = ~eq.any(0)
             else:
                 tr.matched_idx = torch.full((n_tr,), -1, dtype=torch.long, device=dev)

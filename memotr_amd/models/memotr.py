@@ -132,7 +132,9 @@ class MeMOTR(nn.Module):
         classes, boxes = [], []
         # with box refinement the decoder already evaluated this head (same layer output, same reference, aliased
         # bbox_embed weights) to move its anchors: reuse that one evaluation instead of repeating it per layer
-        reuse = refined is not None and self.transformer.decoder.bbox_embed is self.bbox_embed
+        # (DAB only: without DAB the decoder refines from the 2-d slice of the reference while this head adds the
+        # full 4-d inverse sigmoid at level 0, reference models/memotr.py:148-158 -- not the same boxes for tracks)
+        reuse = refined is not None and self.use_dab and self.transformer.decoder.bbox_embed is self.bbox_embed
         for lvl in range(outputs.shape[0]):
             classes.append(self.class_embed[lvl](outputs[lvl]))
             if reuse:

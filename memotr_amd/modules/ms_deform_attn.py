@@ -97,9 +97,38 @@ class MSDeformAttn(nn.Module):
             self.__dict__["_fused_qproj"] = cached
         return cached[1], cached[2]
 
-    def _forget_fused_query_projection(self, grad):
+    def _forget_fused_query_projection(self, grad=None):
         self.__dict__.pop("_fused_qproj", None)      # the graph behind the cached tensors ends with this backward
         return None
+
+    # The cache is a derived tensor (and, in training, a live autograd edge): drop it whenever the parameters can
+    # have changed behind the version counters (``.data`` writes by EMA / manual updates are paired with a mode
+    # switch or a load in every training loop), and never let it travel with a pickle / deepcopy of the module.
+    def train(self, mode: bool = True):
+        self._forget_fused_query_projection()
+        return super().train(mode)
+
+    def _apply(self, fn, *args, **kwargs):
+        self._forget_fused_query_projection()
+        return super()._apply(fn, *args, **kwargs)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._forget_fused_query_projection()
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state.pop("_fused_qproj", None)
+        return state
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k != "_fused_qproj":
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
 
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
                 input_padding_mask=None):

@@ -22,7 +22,10 @@ def box_cxcywh_to_xyxy(boxes: torch.Tensor) -> torch.Tensor:
     4 x (mul, add/sub) + stack: 1 kernel instead of 9 forward (and 1 instead of ~14 backward), ~9 calls per frame
     in the launch-bound criterion / matcher.  Bit-identical to the elementwise form: every product is with 0, 1 or
     +-0.5 (exact) and each output has two non-zero terms, so there is a single rounding in either form."""
-    if not boxes.is_floating_point() or boxes.dtype in (torch.float16, torch.bfloat16):
+    reduced = boxes.dtype == torch.float32 and boxes.is_cuda and (
+        torch.backends.cuda.matmul.allow_tf32 or torch.get_float32_matmul_precision() != "highest")
+    if not boxes.is_floating_point() or boxes.dtype in (torch.float16, torch.bfloat16) or reduced:
+        # (fp32 GEMMs in a reduced internal precision would round the 0.5 * w products: keep the elementwise form)
         cx, cy, w, h = boxes.unbind(-1)
         return torch.stack((cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h), dim=-1)
     key = (boxes.device, boxes.dtype)

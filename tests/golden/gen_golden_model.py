@@ -400,15 +400,138 @@ def case_train_step():
     save("M6_train_step", weights=np_state(model), **arrs)
 
 
+def case_msdeform_module_d32():
+    """Fixture M7: the ``MSDeformAttn`` module at the MeMOTR head width (D = 32 channels per head -- the geometry the
+    specialised and the fused-prologue kernels take), both reference-point branches, with a padding mask, and the
+    gradients of every differentiable input (query, input_flatten, reference_points)."""
+    from models.ops.modules import MSDeformAttn
+    arrs = {}
+    for tag, (d_model, heads, levels, points, shapes_l, Lq, N) in {
+            "a": (64, 2, 4, 4, [(12, 16), (6, 8), (3, 4), (2, 2)], 23, 2),     # M = 2, L*P = 16
+            "b": (96, 3, 2, 3, [(9, 7), (4, 5)], 10, 1)}.items():             # M = 3, L*P = 6 (not a multiple of 8)
+        g = torch.Generator().manual_seed(70 + ord(tag))
+        mod = randomize(MSDeformAttn(d_model=d_model, n_levels=levels, n_heads=heads, n_points=points), 71 + ord(tag))
+        with torch.no_grad():     # offsets of a few pixels around the star, non-uniform attention
+            mod.sampling_offsets.weight.mul_(3.0)
+            mod.attention_weights.weight.mul_(4.0)
+        shapes = torch.tensor(shapes_l)
+        lsi = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
+        S = int(shapes.prod(1).sum())
+        mask = torch.zeros(N, S, dtype=torch.bool)
+        mask[-1, 5:19] = True
+        mask[-1, S - 7:] = True
+        arrs.update({f"{tag}_shapes": shapes, f"{tag}_level_start": lsi, f"{tag}_mask": mask,
+                     f"{tag}_dims": torch.tensor([d_model, heads, levels, points])})
+        arrs.update(np_state(mod, f"{tag}_w::"))
+        for rtag, nref in (("ref2", 2), ("ref4", 4)):
+            src = torch.randn(N, S, d_model, generator=g).requires_grad_(True)
+            query = torch.randn(N, Lq, d_model, generator=g).requires_grad_(True)
+            ref = torch.rand(N, Lq, levels, nref, generator=g)
+            if nref == 4:
+                ref[..., 2:] = ref[..., 2:] * 0.3 + 0.05
+            ref.requires_grad_(True)
+            out = mod(query, ref, src, shapes, lsi, mask)
+            grad_out = torch.randn(out.shape, generator=g)
+            gq, gs, gr = torch.autograd.grad(out, (query, src, ref), grad_out)
+            k = f"{tag}_{rtag}_"
+            arrs.update({k + "query": query, k + "src": src, k + "ref": ref, k + "out": out, k + "grad_out": grad_out,
+                         k + "grad_query": gq, k + "grad_src": gs, k + "grad_ref": gr})
+    save("M7_msdeform_module_d32", **arrs)
+
+
+def case_memotr_no_dab():
+    """Fixture M8: one training-mode frame with carried tracks of the Deformable-DETR variant (USE_DAB False, configs/*_deformable_detr.yaml): 2-d
+    decoder references, ``reference_points`` Linear, 2C query embeddings, 4-d inverse sigmoid at head level 0."""
+    import models.backbone as ref_backbone
+    from models.memotr import MeMOTR
+    from models.deformable_transformer import build as build_tr
+    from models.position_embedding import build as build_pe
+    from models.query_updater import build as build_qu
+    from structures.track_instances import TrackInstances
+    from utils.nested_tensor import NestedTensor, tensor_list_to_nested_tensor
+    cfg = small_config()
+    cfg.update(USE_DAB=False)
+
+    class TinyBackbone(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.backbone = TinyBody()
+            self.strides = [8, 16, 32]
+            self.num_channels = [8, 12, 16]
+
+        def forward(self, nt):
+            res = {}
+            for name, out in self.backbone(nt.tensors).items():
+                m = F.interpolate(nt.masks[None].float(), mode="nearest", size=out.shape[-2:]).to(nt.masks.dtype)[0]
+                res[name] = NestedTensor(out, m)
+            return res
+
+    torch.manual_seed(80)
+    model = MeMOTR(backbone=ref_backbone.BackboneWithPE(TinyBackbone(), build_pe(cfg)), transformer=build_tr(cfg),
+                   query_updater=build_qu(cfg), num_classes=1, n_det_queries=20, n_feature_levels=4, hidden_dim=64,
+                   ffn_dim=128, dropout=0.0, aux_loss=True, with_box_refine=True, use_checkpoint=False,
+                   checkpoint_level=2, use_dab=False, visualize=False)
+    randomize(model, 81)
+    with torch.no_grad():
+        for ce in model.class_embed:
+            ce.bias.zero_()
+    model.train()
+    g = torch.Generator().manual_seed(8)
+    frame = torch.rand(3, 120, 150, generator=g)
+    # hand-made carried tracks (the reference's RuntimeTracker hard-codes a 256-wide slice for this variant, so the
+    # tracks are built directly): 5 track queries with 2C embeddings and 4-d logit-space reference points
+    tr = TrackInstances(hidden_dim=64, num_classes=1, use_dab=False)
+    n = 5
+    tr.ref_pts = torch.randn(n, 4, generator=g)
+    tr.query_embed = torch.randn(n, 128, generator=g)
+    tr.ids = torch.arange(n)
+    tr.boxes = torch.rand(n, 4, generator=g)
+    tr.labels = torch.zeros(n, dtype=torch.long)
+    tr.logits = torch.randn(n, 1, generator=g)
+    tr.matched_idx = torch.arange(n)
+    tr.output_embed = torch.randn(n, 64, generator=g)
+    tr.disappear_time = torch.zeros(n, dtype=torch.long)
+    tr.scores = tr.logits.sigmoid()
+    tr.area = torch.rand(n, generator=g)
+    tr.iou = torch.rand(n, generator=g)
+    tr.last_output = torch.randn(n, 64, generator=g)
+    tr.long_memory = torch.randn(n, 64, generator=g)
+    tr.last_appear_boxes = torch.rand(n, 4, generator=g)
+    arrs = {"frame": frame}
+    arrs.update(track_arrays("in_", tr))
+    res = model(frame=tensor_list_to_nested_tensor([frame]), tracks=[tr])
+    for k in ("pred_logits", "pred_bboxes", "last_ref_pts", "init_ref_pts", "outputs"):
+        arrs[k] = res[k].detach().clone()
+    loss = res["pred_bboxes"].square().sum() + res["pred_logits"].sum()
+    for j, aux in enumerate(res["aux_outputs"]):
+        for k in ("pred_logits", "pred_bboxes"):
+            arrs[f"aux{j}_{k}"] = aux[k].detach().clone()
+        loss = loss + (aux["pred_bboxes"] * torch.linspace(0.5, 2.0, 4)).square().sum()
+    loss.backward()
+    arrs["loss"] = loss.detach()
+    for name, p in model.named_parameters():
+        if p.requires_grad and p.grad is not None:
+            arrs[f"g::{name}"] = p.grad.norm().double()
+    save("M8_memotr_no_dab", weights=np_state(model), **arrs)
+
+
 def main():
     install_stubs()
     torch.set_num_threads(1)
+    only = set(sys.argv[1:])          # e.g. `gen_golden_model.py M7 M8` regenerates just those fixtures
+    if only:
+        for tag, fn in (("M7", case_msdeform_module_d32), ("M8", case_memotr_no_dab)):
+            if tag in only:
+                fn()
+        return
     case_small_functions()
     case_msdeform_module()
     case_transformer()
     case_query_updater()
     case_memotr_two_frames()
     case_train_step()
+    case_msdeform_module_d32()
+    case_memotr_no_dab()
 
 
 if __name__ == "__main__":

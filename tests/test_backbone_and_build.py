@@ -127,3 +127,83 @@ def test_split_contraction_linear_matches_plain_linear():
             torch.testing.assert_close(a, c, rtol=1e-12, atol=1e-10)
     small = long_linear(torch.randn(4, 32, requires_grad=True), torch.randn(8, 32, requires_grad=True))
     assert "SplitK" not in small.grad_fn.__class__.__name__ and "View" not in small.grad_fn.__class__.__name__
+
+
+# ------------------------------------------------------------------ A8: independent restatement of ResNet-50
+def _resnet50_from_definition(x, sd):
+    """ResNet-50 v1.5 written functionally from its published definition (7x7/2 stem, 3x3/2 max-pool, bottleneck
+    stages [3, 4, 6, 3] of widths 64/128/256/512 x 4, stride on the 3x3 convolution, projection shortcut on the first
+    block of a stage) with UNFOLDED batch norm in inference mode (``F.batch_norm(training=False)``, eps 1e-5 =
+    the reference's FrozenBatchNorm2d, models/backbone.py:42-52).  ``sd``: name -> tensor, torchvision key names.
+    Independent of memotr_amd.models.resnet: shares no code with it."""
+    def unit(x, conv, bn, stride=1, padding=0, relu=True):
+        y = F.conv2d(x, sd[conv + ".weight"], None, stride, padding)
+        y = F.batch_norm(y, sd[bn + ".running_mean"], sd[bn + ".running_var"], sd[bn + ".weight"], sd[bn + ".bias"],
+                         training=False, eps=1e-5)
+        return F.relu(y) if relu else y
+
+    x = F.max_pool2d(unit(x, "conv1", "bn1", 2, 3), 3, 2, 1)
+    outs = {}
+    for stage, (blocks, stride) in enumerate([(3, 1), (4, 2), (6, 2), (3, 2)], start=1):
+        for b in range(blocks):
+            p = f"layer{stage}.{b}"
+            s = stride if b == 0 else 1
+            y = unit(x, p + ".conv1", p + ".bn1")
+            y = unit(y, p + ".conv2", p + ".bn2", s, 1)
+            y = unit(y, p + ".conv3", p + ".bn3", relu=False)
+            shortcut = unit(x, p + ".downsample.0", p + ".downsample.1", s, 0, relu=False) if b == 0 else x
+            x = F.relu(y + shortcut)
+        outs[stage] = x
+    return outs[2], outs[3], outs[4]
+
+
+def _randomised_backbone(seed):
+    from memotr_amd.models.backbone import Backbone, FrozenBatchNorm2d
+    torch.manual_seed(seed)
+    bb = Backbone("resnet50", train_backbone=True, return_interm_layers=True)
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for m in bb.modules():
+            if isinstance(m, FrozenBatchNorm2d):       # non-trivial frozen statistics and affine
+                m.weight.copy_(torch.rand(m.weight.shape, generator=g) * 0.6 + 0.3)
+                m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+                m.running_mean.copy_(torch.randn(m.bias.shape, generator=g) * 0.2)
+                m.running_var.copy_(torch.rand(m.bias.shape, generator=g) * 1.5 + 0.5)
+    return bb
+
+
+@pytest.mark.parametrize("device", ["cpu", pytest.param("cuda", marks=pytest.mark.gpu)])
+def test_folded_resnet50_equals_unfolded_definition(device):
+    """A8 as far as this container allows (torchvision itself is absent -> parity with its build stays UNPINNED):
+    the product's conv+folded-frozen-BN stack vs the from-definition network with separate inference-mode batch
+    norms on the same weights -- layer2/3/4 outputs and the gradients of the trainable (layer2-4) convolutions."""
+    from memotr_amd.utils.nested_tensor import tensor_list_to_nested_tensor
+    bb = _randomised_backbone(11).to(device)
+    x = torch.randn(2, 3, 64, 96, generator=torch.Generator().manual_seed(12)).to(device)
+    nt = tensor_list_to_nested_tensor(list(x))
+    got = bb(nt)
+    sd = {k[len("backbone."):]: v.detach().clone() for k, v in bb.state_dict().items()}
+    train_keys = [k for k in sd if k.endswith(".weight") and sd[k].dim() == 4 and k.split(".")[0] in
+                  ("layer2", "layer3", "layer4")]
+    for k in train_keys:
+        sd[k].requires_grad_(True)
+    want = _resnet50_from_definition(nt.tensors, sd)
+    seeds = [torch.randn(w.shape, generator=torch.Generator().manual_seed(20 + i)).to(device)
+             for i, w in enumerate(want)]
+    for i, name in enumerate(("0", "1", "2")):
+        a, b = got[name].tensors, want[i]
+        assert a.shape == b.shape
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 2e-5 * max(scale, 1.0), (name, float((a - b).abs().max()), scale)
+    sum((got[n].tensors * s).sum() for n, s in zip(("0", "1", "2"), seeds)).backward()
+    grads = torch.autograd.grad(sum((w * s).sum() for w, s in zip(want, seeds)), [sd[k] for k in train_keys])
+    params = dict(bb.backbone.named_parameters())
+    assert len(train_keys) == sum(1 for n, p in params.items() if p.requires_grad) > 40
+    for k, g_ref in zip(train_keys, grads):
+        g_got = params[k].grad
+        assert g_got is not None, k
+        rel = float((g_got - g_ref).norm()) / (float(g_ref.norm()) + 1e-12)
+        assert rel < 2e-4, (k, rel)
+    for n, p in params.items():                     # conv1 / layer1 stay frozen (models/backbone.py:72-74)
+        if n.split(".")[0] in ("conv1", "layer1"):
+            assert p.grad is None and not p.requires_grad

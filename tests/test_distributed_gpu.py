@@ -1,0 +1,84 @@
+"""GPU: the data-parallel train step on the RCCL (``nccl``) backend.
+
+  * world size 1 (any GPU box): the real model wrapped in DistributedDataParallel on ``nccl``, two clip steps
+    with the encode/decode split -- so the first multi-GPU run is not also the first NCCL run;
+  * world size 2 (only when two devices are visible): replicas stay bit-identical after two steps.
+Workers run in spawned processes (one per GPU, like ``torch.distributed.run`` launches bench.py).
+"""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from memotr_amd import _lib
+    from memotr_amd.configs import dancetrack_config
+    from memotr_amd.engine import (build_optimizer, clip_forward_backward, clip_to_device, make_synthetic_clip,
+                                   optimizer_step)
+    from memotr_amd.models import build_model
+    from memotr_amd.models.criterion import build as build_criterion
+    cfg = dancetrack_config(DEVICE="cuda", AVAILABLE_GPUS=str(rank), NUM_ENC_LAYERS=2, NUM_DEC_LAYERS=2, FFN_DIM=512)
+    torch.manual_seed(100 + rank)                    # DDP must broadcast rank 0's weights
+    model = build_model(cfg).train()
+    ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[rank], find_unused_parameters=False)
+    criterion = build_criterion(cfg)
+    opt = build_optimizer(cfg, ddp)
+    batch = clip_to_device(make_synthetic_clip(clip_len=3, height=256, width=320, n_gts=3 + rank, seed=7 + rank), dev)
+    losses = []
+    for _ in range(2):                               # a second step raises if a bucket was left unreduced
+        loss, _ = clip_forward_backward(ddp, criterion, batch, dev)
+        assert all(p.grad is not None for p in ddp.parameters() if p.requires_grad)
+        optimizer_step(ddp, opt, cfg["CLIP_MAX_NORM"])
+        losses.append(float(loss))
+    torch.cuda.synchronize()
+    flat = torch.cat([p.detach().reshape(-1) for p in ddp.parameters()]).cpu()
+    torch.save({"flat": flat, "losses": losses, "kernel": _lib.last_kernel(),
+                "backend": dist.get_backend(), "world": dist.get_world_size()}, f"{out_path}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(world, tmp_path):
+    port = _free_port()
+    out = str(tmp_path / "rank")
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    return [torch.load(f"{out}.{r}") for r in range(world)]
+
+
+def test_single_rank_nccl_ddp_two_clip_steps(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    (r0,) = _run(1, tmp_path)
+    assert r0["backend"] == "nccl" and r0["world"] == 1
+    assert all(l == l and abs(l) < 1e6 for l in r0["losses"])
+    assert torch.isfinite(r0["flat"]).all()
+    assert "msda" in r0["kernel"]
+
+
+def test_two_rank_nccl_replicas_stay_in_sync(tmp_path):
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    r0, r1 = _run(2, tmp_path)
+    assert r0["world"] == 2 and torch.equal(r0["flat"], r1["flat"]), "replicas diverged"
+    assert r0["losses"][0] != r1["losses"][0]

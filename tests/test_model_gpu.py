@@ -186,3 +186,78 @@ def test_bf16_autocast_module_tracks_fp32(hip_lib):
     (g16,) = torch.autograd.grad(out16.float().sum(), query)
     assert float((out16.float() - out32).abs().max()) < 0.06 * float(out32.abs().max()) + 0.02
     assert float((g16.float() - g32).norm()) < 0.15 * float(g32.norm()) + 1e-3     # bf16: ~3 significant digits through two GEMMs
+
+
+def _m6_setup(g):
+    from memotr_amd.models.criterion import build as build_criterion
+    cfg = small_config()
+    cfg.update(MATCH_COST_CLASS=2, MATCH_COST_BBOX=5, MATCH_COST_GIOU=2, LOSS_WEIGHT_FOCAL=2, LOSS_WEIGHT_L1=5,
+               LOSS_WEIGHT_GIOU=2, AUX_LOSS_WEIGHT=[1.0], SAMPLE_LENGTHS=[2, 3, 4, 5])
+    batch = {"imgs": [[t(g[f"img{i}"]).cuda() for i in range(3)]],
+             "infos": [[{"ids": t(g[f"gt{i}_ids"]).cuda(), "labels": torch.zeros(6, dtype=torch.long).cuda(),
+                         "boxes": t(g[f"gt{i}_boxes"]).cuda()} for i in range(3)]]}
+    return build_criterion(cfg), batch
+
+
+@pytest.mark.parametrize("level", [1, 2, 3])
+def test_train_step_with_activation_checkpointing_on_hip_operator(level):
+    """BASELINE config 4 (--use-checkpoint): the M6 train-step golden on the HIP operator with the reference's
+    checkpoint switches (memotr.py:102-103, deformable_transformer.py:223-226, deformable_decoder.py:104-118;
+    level 1 = encoder in groups of three layers, 2 = whole encoder, 3 = decoder layers only).  The recompute
+    re-launches the forward kernels inside backward: same loss, same per-parameter gradient norms."""
+    from memotr_amd.engine import clip_forward_backward
+    g = load_model_golden("M6_train_step")
+    model = build_memotr_cuda(g).train()
+    model.use_checkpoint, model.checkpoint_level = True, level
+    tr = model.transformer
+    tr.use_checkpoint, tr.checkpoint_level = True, level
+    tr.encoder.use_checkpoint = level == 1
+    tr.decoder.use_checkpoint = True
+    criterion, batch = _m6_setup(g)
+    loss, loss_dict = clip_forward_backward(model, criterion, batch, torch.device("cuda"))
+    np.testing.assert_allclose(float(loss), float(g["total_loss"]), rtol=5e-4)
+    for k, v in loss_dict.items():
+        np.testing.assert_allclose(float(v), float(g[f"loss::{k}"]), rtol=1e-3, err_msg=k)
+    worst = 0.0
+    for name, p in model.named_parameters():
+        if p.requires_grad:
+            want = float(g[f"g::{name}"])
+            worst = max(worst, abs(float(p.grad.norm()) - want) / max(want, 1e-4))
+    assert worst < 2e-2, worst
+
+
+def test_d32_model_with_checkpointing_equals_plain_step(hip_lib):
+    """The same switches at the MeMOTR head geometry (D = 32: specialised + fused-prologue kernels), HIP operator
+    both times: checkpointed and plain steps must agree (only atomics-order noise)."""
+    import memotr_amd.modules.ms_deform_attn as mod
+    from memotr_amd.structures.track_instances import TrackInstances
+    from memotr_amd.utils.nested_tensor import tensor_list_to_nested_tensor
+    frame = tensor_list_to_nested_tensor([torch.randn(3, 200, 300, generator=torch.Generator().manual_seed(4))]).to("cuda")
+
+    def run(level):
+        torch.manual_seed(0)
+        model = build_memotr_cuda(None, hidden=256, ffn=256, NUM_ENC_LAYERS=3, NUM_DEC_LAYERS=2).train()
+        with torch.no_grad():
+            for m in model.modules():
+                if isinstance(m, mod.MSDeformAttn):
+                    m.sampling_offsets.weight.normal_(0, 0.02)
+                    m.attention_weights.weight.normal_(0, 0.05)
+        if level:
+            model.use_checkpoint, model.checkpoint_level = True, level
+            tr = model.transformer
+            tr.use_checkpoint, tr.checkpoint_level = True, level
+            tr.encoder.use_checkpoint = level == 1
+            tr.decoder.use_checkpoint = True
+        tracks = [TrackInstances(hidden_dim=256, num_classes=1, use_dab=True).to("cuda")]
+        res = model(frame=frame, tracks=tracks)
+        loss = res["pred_bboxes"].square().sum() + res["pred_logits"].sum() + res["outputs"].mean()
+        loss.backward()
+        return float(loss), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    l0, g0 = run(0)
+    for level in (1, 2):
+        l1, g1 = run(level)
+        assert l1 == pytest.approx(l0, rel=1e-5)
+        assert g0.keys() == g1.keys()
+        for n in g0:
+            assert float((g1[n] - g0[n]).norm()) / (float(g0[n].norm()) + 1e-6) < 2e-3, (level, n)

@@ -1,0 +1,209 @@
+"""GPU parity at BASELINE.json's own shapes: the HIP kernels against the C oracle (not against each other).
+
+  * encoder call  S = Lq = 22323 (800x1333 pyramid), forward and all three gradients, for the encoder-like
+    sampling distribution (LDS-window path of the tiled backward) and for uniform locations (everything on the
+    global-atomic fallback path);
+  * decoder calls Lq in {300, 320, 400} on the full pyramid;
+  * the same on the BDD100K pyramid (736x1280: (92,160) (46,80) (23,40) (12,20), S = 19560);
+  * the fixed-point window accumulation of the tiled backward under a wide dynamic range of ``grad_out``
+    (per-channel scales, per-region scales, an outlier row, non-finite values).
+
+The oracle takes 0.2 s (forward) / 0.9 s (backward) per full-size call on the host.
+Tolerances are stated per assertion; north_star allows 1e-3 abs in fp32.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def msda(hip_lib):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from memotr_amd import MultiScaleDeformableAttention as MSDA
+    return MSDA
+
+
+@pytest.fixture(autouse=True)
+def _reset_options(hip_lib):
+    yield
+    for k in ("fwd_variant", "bwd_variant"):
+        hip_lib.set_option(k, 0)
+
+
+def _cpu(x):
+    return {k: v.detach().cpu().numpy() for k, v in x.items() if isinstance(v, torch.Tensor)}
+
+
+def _oracle(c):
+    from oracle import msda_oracle as oracle
+    out = oracle.forward(c["value"], c["shapes"], c["level_start"], c["loc"], c["attn"])
+    gv, gl, ga = oracle.backward(c["value"], c["shapes"], c["level_start"], c["loc"], c["attn"], c["grad_out"])
+    return out, gv, gl, ga
+
+
+def _hip(msda, x):
+    from memotr_amd.MultiScaleDeformableAttention import tag_host_shapes
+    tag_host_shapes(x["shapes"], x["shapes_list"])
+    args = (x["value"], x["shapes"], x["level_start"], x["loc"], x["attn"])
+    out = msda.ms_deform_attn_forward(*args, 64)
+    gv, gl, ga = msda.ms_deform_attn_backward(*args, x["grad_out"], 64)
+    return tuple(t.cpu().numpy() for t in (out, gv, gl, ga))
+
+
+def _check(got, want, what):
+    out, gv, gl, ga = got
+    rout, rgv, rgl, rga = want
+    # forward: 16 points x 4 corners of O(1) values -> |out| ~ 1; 2e-5 abs = 50x inside the 1e-3 bar
+    np.testing.assert_allclose(out, rout, rtol=1e-4, atol=2e-5, err_msg=what + " out")
+    # grad_value: float atomics (order-dependent) + 2^-21-relative fixed point; cells collect up to ~100 terms
+    np.testing.assert_allclose(gv, rgv, rtol=1e-4, atol=1e-4, err_msg=what + " grad_value")
+    # grad_loc carries the factor W or H (up to 168) on sums over 32 channels
+    np.testing.assert_allclose(gl, rgl, rtol=1e-4, atol=2e-3, err_msg=what + " grad_loc")
+    np.testing.assert_allclose(ga, rga, rtol=1e-4, atol=2e-4, err_msg=what + " grad_attn")
+
+
+PYRAMIDS = {"dancetrack_800x1333": (800, 1333), "bdd100k_720x1280": (720, 1280)}
+
+
+@pytest.mark.parametrize("pyr", list(PYRAMIDS))
+@pytest.mark.parametrize("dist", ["encoder_like", "uniform"])
+def test_encoder_shape_forward_and_backward_match_oracle(msda, hip_lib, pyr, dist):
+    from memotr_amd.synth import make_inputs
+    h, w = PYRAMIDS[pyr]
+    x = make_inputs(height=h, width=w, dist=dist, device="cuda", seed=11)
+    if pyr.startswith("bdd"):
+        assert x["shapes_list"] == [(92, 160), (46, 80), (23, 40), (12, 20)] and x["value"].shape[1] == 19560
+    else:
+        assert x["value"].shape[1] == 22323
+    got = _hip(msda, x)
+    kernel = hip_lib.last_kernel()
+    assert "tile" in kernel, kernel          # the default training kernel for pyramid self-attention
+    _check(got, _oracle(_cpu(x)), f"{pyr}/{dist}")
+
+
+@pytest.mark.parametrize("pyr", list(PYRAMIDS))
+@pytest.mark.parametrize("n_queries", [300, 320, 400])
+def test_decoder_shape_forward_and_backward_match_oracle(msda, hip_lib, pyr, n_queries):
+    from memotr_amd.synth import make_inputs
+    h, w = PYRAMIDS[pyr]
+    for dist in ("encoder_like", "uniform"):
+        x = make_inputs(height=h, width=w, n_queries=n_queries, dist=dist, device="cuda", seed=5 + n_queries)
+        got = _hip(msda, x)
+        _check(got, _oracle(_cpu(x)), f"{pyr}/dec{n_queries}/{dist}")
+
+
+@pytest.mark.parametrize("batch", [2, 5])
+def test_clip_batched_encoder_call_matches_oracle(msda, hip_lib, batch):
+    """N > 1: all frames of an encode group in one call (what the training loop issues), reduced pyramid."""
+    from memotr_amd.synth import make_inputs
+    x = make_inputs(height=400, width=667, batch=batch, dist="encoder_like", device="cuda", seed=21)
+    x["value"] = torch.randn_like(x["value"])
+    x["loc"] = (x["loc"] + 0.002 * torch.randn_like(x["loc"])).contiguous()     # frames differ
+    got = _hip(msda, x)
+    assert "tile" in hip_lib.last_kernel()
+    _check(got, _oracle(_cpu(x)), f"batch{batch}")
+
+
+# ----------------------------------------------------------------------------- fixed-point dynamic range
+def _small_pyramid_inputs(seed=31, height=320, width=448):
+    from memotr_amd.synth import make_inputs
+    return make_inputs(height=height, width=width, dist="encoder_like", device="cuda", seed=seed)
+
+
+def _abs_mass(c):
+    """Per-cell sum of |contribution| (the scale fp32 atomics are accurate against): oracle backward on |.|."""
+    from oracle import msda_oracle as oracle
+    gv, _, _ = oracle.backward(np.ones_like(c["value"]), c["shapes"], c["level_start"], c["loc"], np.abs(c["attn"]),
+                               np.abs(c["grad_out"]))
+    return gv
+
+
+def test_fixed_point_window_accumulation_per_channel_scales(msda, hip_lib):
+    """grad_out channels spanning 1e-4 .. 1e+3: the window scale is per channel (and per level), so every channel
+    keeps its own ~2^-21 relative quantum -- per channel, error / that channel's largest |grad_value| <= 1e-5."""
+    x = _small_pyramid_inputs()
+    g = torch.Generator().manual_seed(1)
+    scales = 10.0 ** (torch.rand(256, generator=g) * 7 - 4)
+    x["grad_out"] = (x["grad_out"] * scales.cuda()).contiguous()
+    got = _hip(msda, x)
+    assert "tile_q" in hip_lib.last_kernel()
+    want = _oracle(_cpu(x))
+    gv, rgv = got[1].reshape(-1, 256), want[1].reshape(-1, 256)
+    err = np.abs(gv - rgv).max(0) / np.abs(rgv).max(0)
+    assert err.max() < 1e-5, (err.max(), int(err.argmax()), float(scales[int(err.argmax())]))
+    np.testing.assert_allclose(got[2], want[2], rtol=1e-3, atol=2e-3 * float(scales.max()))   # grad_loc: float path
+
+
+def test_fixed_point_window_accumulation_per_region_scales(msda, hip_lib):
+    """Left half of the image 1e-4, right half 1e+3: scales are per workgroup (region), so both halves keep a
+    small error relative to their own magnitude."""
+    x = _small_pyramid_inputs(seed=32)
+    shapes = x["shapes_list"]
+    col_scale = []
+    for (h, w) in shapes:
+        s = torch.full((h, w), 1e-4)
+        s[:, w // 2:] = 1e3
+        col_scale.append(s.reshape(-1))
+    qs = torch.cat(col_scale).cuda()
+    x["grad_out"] = (x["grad_out"] * qs[None, :, None]).contiguous()
+    got = _hip(msda, x)
+    want = _oracle(_cpu(x))
+    gv, rgv = got[1][0], want[1][0]                         # (S, M, D)
+    # value pixels of level 0 well inside either half (sampling reaches a few pixels across the seam)
+    h0, w0 = shapes[0]
+    cols = np.arange(h0 * w0) % w0
+    left, right = cols < w0 // 2 - 12, cols >= w0 // 2 + 12
+    for name, sel, mag in (("left", left, 1e-4), ("right", right, 1e3)):
+        e = np.abs(gv[:h0 * w0][sel] - rgv[:h0 * w0][sel]).max()
+        ref = np.abs(rgv[:h0 * w0][sel]).max()
+        assert ref > 0.1 * mag and e < 2e-5 * ref, (name, e, ref)
+
+
+def test_fixed_point_window_accumulation_outlier_row_and_small_rows(msda, hip_lib):
+    """One query with a 1e4-times larger gradient inside a region must not wipe out its neighbours: rows far below
+    the region's bound bypass the fixed-point windows (float atomics), so every cell stays accurate relative to the
+    mass of contributions it actually receives, except cells the outlier itself writes to (bounded by ITS quantum)."""
+    x = _small_pyramid_inputs(seed=33)
+    S = x["value"].shape[1]
+    outliers = torch.arange(50, S, 997)
+    x["grad_out"][0, outliers] *= 1e4
+    x["grad_out"] = x["grad_out"].contiguous()
+    got = _hip(msda, x)
+    c = _cpu(x)
+    want = _oracle(c)
+    mass = _abs_mass(c)
+    # cells the outlier rows touch: mass computed with only those rows
+    c_out = dict(c)
+    go = np.zeros_like(c["grad_out"])
+    go[0, outliers.numpy()] = c["grad_out"][0, outliers.numpy()]
+    c_out["grad_out"] = go
+    mass_out = _abs_mass(c_out)
+    err = np.abs(got[1] - want[1])
+    clean = mass_out == 0
+    assert clean.mean() > 0.5
+    # float-atomic quality where no outlier lands: a few ulps of the cell's own mass
+    assert (err[clean] <= 2e-5 * mass[clean] + 1e-12).all(), float((err[clean] / (mass[clean] + 1e-30)).max())
+    # everywhere: the fixed-point quantum of the largest bound in play (2^-21 * max|grad_out| * max|attn|, x rows*P/2)
+    bound = float(np.abs(c["grad_out"]).max() * np.abs(c["attn"]).max())
+    assert err.max() <= 2.0 ** -12 * bound, (err.max(), bound)
+    np.testing.assert_allclose(got[3], want[3], rtol=1e-3, atol=1e-3 * 1e4)
+
+
+def test_non_finite_gradients_propagate_like_float_atomics(msda, hip_lib):
+    """An inf / nan in grad_out reaches grad_value exactly where the reference's float atomics would put a
+    non-finite value (the fixed-point conversion must not turn it into 0)."""
+    x = _small_pyramid_inputs(seed=34)
+    x["grad_out"][0, 1234, 7] = float("inf")
+    x["grad_out"][0, 4321, 130] = float("nan")
+    x["grad_out"] = x["grad_out"].contiguous()
+    got = _hip(msda, x)
+    want = _oracle(_cpu(x))
+    bad_ref = ~np.isfinite(want[1])
+    bad_got = ~np.isfinite(got[1])
+    assert bad_ref.sum() > 0
+    assert np.array_equal(bad_got, bad_ref)
+    ok = ~bad_ref
+    np.testing.assert_allclose(got[1][ok], want[1][ok], rtol=1e-4, atol=1e-4)

@@ -150,3 +150,17 @@ def test_box_conversion_as_matrix_product_is_bit_identical(device):
             assert torch.equal(ga, gb), shape
     sig = torch.rand((50, 4), generator=g).to(device)                    # sigmoid-range boxes, as in the criterion
     assert torch.equal(box_cxcywh_to_xyxy(sig), _xyxy_elementwise(sig))
+
+
+def test_ground_truth_ownership_takes_the_last_duplicate_id():
+    """reference criterion.py:166-170 builds ``gt_ids_to_idx`` with a dict comprehension: when a frame repeats an
+    id the LAST ground truth wins.  The tensor form must agree."""
+    ids_tr = torch.tensor([5, 9, 7, 3])
+    ids_gt = torch.tensor([7, 5, 7, 1, 5])
+    want = []
+    lut = {int(v): i for i, v in enumerate(ids_gt)}
+    for v in ids_tr.tolist():
+        want.append(lut.get(v, -1))
+    eq = ids_tr[:, None] == ids_gt[None, :]
+    got = (eq * torch.arange(1, len(ids_gt) + 1)).amax(1) - 1
+    assert got.tolist() == want == [4, -1, 2, -1]
