@@ -197,7 +197,7 @@ def test_non_finite_gradients_propagate_like_float_atomics(msda, hip_lib):
     non-finite value (the fixed-point conversion must not turn it into 0)."""
     x = _small_pyramid_inputs(seed=34)
     x["grad_out"][0, 1234, 7] = float("inf")
-    x["grad_out"][0, 4321, 130] = float("nan")
+    x["grad_out"][0, 2321, 130] = float("nan")
     x["grad_out"] = x["grad_out"].contiguous()
     got = _hip(msda, x)
     want = _oracle(_cpu(x))
