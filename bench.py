@@ -120,6 +120,38 @@ class MsdaCall:
         return algorithmic_bytes(self.N, self.S, self.Lq, self.M, self.D, self.L, self.P, 4, backward)
 
 
+class FusedCall(MsdaCall):
+    """The fused-prologue entry points (what the model issues): same sampling pattern as the plain call, given as
+    raw projection rows + reference points."""
+
+    def __init__(self, x):
+        super().__init__(x)
+        from memotr_amd.synth import to_fused_inputs
+        f = to_fused_inputs(x)
+        self.proj, self.ref = f["proj"], f["ref"]
+        self.gp = torch.empty_like(self.proj)
+
+    def fwd(self):
+        x = self.x
+        rc = self.lib.msda_fused_forward_f32(x["value"].data_ptr(), x["shapes"].data_ptr(), x["level_start"].data_ptr(),
+                                             self.proj.data_ptr(), self.proj.shape[2], self.ref.data_ptr(), 2, None,
+                                             self.N, self.S, self.M, self.D, self.L, self.Lq, self.P,
+                                             self.out.data_ptr(), self.hptr, torch.cuda.current_stream().cuda_stream)
+        if rc:
+            raise RuntimeError(self._lib.last_error())
+
+    def bwd(self):
+        x = self.x
+        rc = self.lib.msda_fused_backward_f32(x["value"].data_ptr(), x["shapes"].data_ptr(),
+                                              x["level_start"].data_ptr(), self.proj.data_ptr(), self.proj.shape[2],
+                                              self.ref.data_ptr(), 2, None, x["grad_out"].data_ptr(), self.N, self.S,
+                                              self.M, self.D, self.L, self.Lq, self.P, self.gv.data_ptr(),
+                                              self.gp.data_ptr(), None, 1, self.hptr,
+                                              torch.cuda.current_stream().cuda_stream)
+        if rc:
+            raise RuntimeError(self._lib.last_error())
+
+
 def time_kernel(fn, iters=200, warmup=20):
     """Average launch duration (ms) from HIP events on the launch stream."""
     for _ in range(warmup):
@@ -134,21 +166,41 @@ def time_kernel(fn, iters=200, warmup=20):
     return s.elapsed_time(e) / iters
 
 
-def read_traffic():
-    """HBM bytes per launch from the committed PMC pass (profiles/traffic.json), or None."""
+def read_traffic(kernel_label):
+    """HBM bytes per launch of the dominant kernel from the committed PMC pass (profiles/traffic.json: separate
+    --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 correction applied) -- only if that pass measured THIS kernel built from
+    THESE sources (label + source hash stamped by tools/prof_summary.py); otherwise null rather than a stale number."""
     p = os.path.join(ROOT, "profiles", "traffic.json")
     try:
+        from memotr_amd.build import source_hash
         with open(p) as f:
-            return json.load(f).get("msda_fwd_encoder_bytes_per_launch")
+            t = json.load(f)
+        if t.get("kernel_label") != kernel_label or t.get("source_sha16") != source_hash():
+            return None
+        return t.get("msda_fwd_encoder_bytes_per_launch")
     except Exception:
         return None
+
+
+def host_cpu_info():
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return model, os.cpu_count() or 1
 
 
 def cpu_baseline_msda(args, enc_shape_kwargs, dec_shape_kwargs):
     """Reference CPU fallback formulation on the host cores; bounded sample, scaled to frames/s."""
     from memotr_amd.synth import make_inputs
     from oracle import msda_oracle as oracle
-    cores = os.cpu_count() or 1
+    cpu_model, cpu_total = host_cpu_info()
+    cores = cpu_total
     if args.cpu_threads > 0:
         cores = args.cpu_threads
     else:
@@ -189,8 +241,10 @@ def cpu_baseline_msda(args, enc_shape_kwargs, dec_shape_kwargs):
     per_frame = 6 * min(t_enc) + 6 * min(t_dec)
     return {
         "value": 1.0 / per_frame, "unit": "frames/s", "cores": cores, "kind": "port",
+        "cpu_model": cpu_model, "host_cores": cpu_total,
         "sample": f"{reps} reps of one encoder-shape + one decoder-shape fwd+bwd "
-                  f"(torch-CPU grid_sample formulation, {cores} threads), best rep x6 calls each per frame",
+                  f"(torch-CPU grid_sample formulation; {cpu_model}, {cpu_total} host cores, {cores} threads = "
+                  f"best of a probe over {{all, 64, 32, 16}}), best rep x6 calls each per frame",
         "enc_fwd_bwd_s": min(t_enc), "dec_fwd_bwd_s": min(t_dec),
     }
 
@@ -200,8 +254,10 @@ def run_msda(args, rank, world):
     dev = torch.device("cuda", torch.cuda.current_device())
     enc_kw = dict(dist=args.dist, seed=3 + rank)
     dec_kw = dict(dist=args.dist, seed=103 + rank, n_queries=300 + args.n_track)
-    enc = MsdaCall(make_inputs(device=dev, **enc_kw))
-    dec = MsdaCall(make_inputs(device=dev, **dec_kw))
+    # the calls the model issues: fused-prologue entry points (raw projection rows + reference points in,
+    # softmax / location arithmetic in-kernel); same sampling pattern and algorithmic bytes as the plain operator
+    enc = FusedCall(make_inputs(device=dev, **enc_kw))
+    dec = FusedCall(make_inputs(device=dev, **dec_kw))
 
     def step():
         for _ in range(6):
@@ -243,7 +299,7 @@ def run_msda(args, rank, world):
                                    "800x1333 pyramid, M=8 D=32 L=4 P=4, bs=1/GPU" % (300 + args.n_track),
                        "loc_dist": args.dist, "parallelism": f"dp{world}"},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBPS, "traffic": read_traffic(), "kernel": kernel,
+                         "frac": ach / HBM_PEAK_GBPS, "traffic": read_traffic(kernel), "kernel": kernel,
                          "ms": ms_fwd, "algorithmic_bytes": enc.bytes()},
             "kernels": {
                 "enc_fwd_ms": ms_fwd, "enc_bwd_ms": ms_bwd, "dec_fwd_ms": ms_dec, "enc_bwd_kernel": kernel_bwd,
@@ -260,8 +316,8 @@ def run_msda_kernels_only(args):
     """Roofline numbers for the dominant kernel + a thunk for the CPU baseline (used by the train workload)."""
     from memotr_amd.synth import make_inputs
     dev = torch.device("cuda", torch.cuda.current_device())
-    enc = MsdaCall(make_inputs(device=dev, dist=args.dist, seed=3))
-    dec = MsdaCall(make_inputs(device=dev, dist=args.dist, seed=103, n_queries=300 + args.n_track))
+    enc = FusedCall(make_inputs(device=dev, dist=args.dist, seed=3))
+    dec = FusedCall(make_inputs(device=dev, dist=args.dist, seed=103, n_queries=300 + args.n_track))
     ms_fwd = time_kernel(enc.fwd)
     kernel = enc._lib.last_kernel()
     ms_bwd = time_kernel(enc.bwd, iters=50)
@@ -270,7 +326,7 @@ def run_msda_kernels_only(args):
     ach = enc.bytes() / (ms_fwd * 1e-3) / 1e9
     return {
         "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": ach / HBM_PEAK_GBPS, "traffic": read_traffic(), "kernel": kernel, "ms": ms_fwd,
+                     "frac": ach / HBM_PEAK_GBPS, "traffic": read_traffic(kernel), "kernel": kernel, "ms": ms_fwd,
                      "algorithmic_bytes": enc.bytes()},
         "kernels": {"enc_fwd_ms": ms_fwd, "enc_bwd_ms": ms_bwd, "dec_fwd_ms": ms_dec, "enc_bwd_kernel": kernel_bwd,
                     "enc_bwd_GBps": enc.bytes(True) / (ms_bwd * 1e-3) / 1e9},

@@ -105,18 +105,69 @@ int msda_backward_bf16(const uint16_t *value, const int64_t *shapes_dev, const i
                        float *grad_value, float *grad_loc, float *grad_attn,
                        int zero_grad_value, const int64_t *shapes_host, void *stream);
 
-/* ---- parity hook: the integer side of the sampling arithmetic ----
- * For every (n,q,m,l,p): h_low = floor(loc_y*H_l - 0.5), w_low = floor(loc_x*W_l - 0.5)
- * and gate = (-1 < h < H_l && -1 < w < W_l) as computed by the device function the
- * kernels use (.cuh:285-288, :38-39).  Outputs are (N,Lq,M,L,P) int32/int32/uint8. */
+/* ---- fused prologue: replaces the elementwise chain of the reference MODULE between its query projections
+ * and the operator (models/ops/modules/ms_deform_attn.py:104-123) ----
+ * Instead of materialised sampling locations and attention weights the kernels take
+ *     proj      (N*Lq, proj_stride) fp32   one row per query: [offsets (M,L,P,2) | logits (M,L,P)], i.e. the raw
+ *                                          outputs of `sampling_offsets` and `attention_weights` side by side
+ *                                          (proj_stride >= 3*M*L*P elements)
+ *     ref       (N*Lq, L, ref_dim) fp32    reference points, ref_dim = 2 (x, y) or 4 (x, y, w, h)
+ *     pad_mask  (N, S) uint8 or NULL       non-zero = padded pixel: its `value` row reads as zero and receives no
+ *                                          gradient (= value.masked_fill(mask, 0) of ms_deform_attn.py:107-108)
+ * and compute in-kernel, per (query, head): attention weights = softmax over the L*P logits (:111), locations =
+ * ref + off / (W_l, H_l) for ref_dim 2 (:114-117) or ref_xy + off / P * ref_wh * 0.5 for ref_dim 4 (:118-120), each
+ * step an IEEE fp32 operation in the reference's order -- the index arithmetic downstream sees the bits torch would
+ * have produced (msda_fused_points_f32 exposes them).  L*P <= 64.
+ * Backward: grad_value as msda_backward_*; grad_proj (N*Lq, proj_stride) receives d/d offsets and d/d logits (softmax
+ * and location Jacobians applied; the 3*M*L*P used columns of every row are overwritten); grad_ref_part, when not
+ * NULL, receives (N, Lq, M, L, ref_dim) per-head partial sums of d/d reference points (the caller sums over M).
+ * Returns MSDA_ENOTSUP for L*P > 64. */
+int msda_fused_forward_f32(const float *value, const int64_t *shapes_dev, const int64_t *lstart_dev,
+                           const float *proj, int proj_stride, const float *ref, int ref_dim,
+                           const uint8_t *pad_mask,
+                           int N, int S, int M, int D, int L, int Lq, int P,
+                           float *out, const int64_t *shapes_host, void *stream);
+
+int msda_fused_forward_bf16(const uint16_t *value, const int64_t *shapes_dev, const int64_t *lstart_dev,
+                            const float *proj, int proj_stride, const float *ref, int ref_dim,
+                            const uint8_t *pad_mask,
+                            int N, int S, int M, int D, int L, int Lq, int P,
+                            uint16_t *out, const int64_t *shapes_host, void *stream);
+
+int msda_fused_backward_f32(const float *value, const int64_t *shapes_dev, const int64_t *lstart_dev,
+                            const float *proj, int proj_stride, const float *ref, int ref_dim,
+                            const uint8_t *pad_mask, const float *grad_out,
+                            int N, int S, int M, int D, int L, int Lq, int P,
+                            float *grad_value, float *grad_proj, float *grad_ref_part,
+                            int zero_grad_value, const int64_t *shapes_host, void *stream);
+
+int msda_fused_backward_bf16(const uint16_t *value, const int64_t *shapes_dev, const int64_t *lstart_dev,
+                             const float *proj, int proj_stride, const float *ref, int ref_dim,
+                             const uint8_t *pad_mask, const uint16_t *grad_out,
+                             int N, int S, int M, int D, int L, int Lq, int P,
+                             float *grad_value, float *grad_proj, float *grad_ref_part,
+                             int zero_grad_value, const int64_t *shapes_host, void *stream);
+
+/* ---- parity hooks ----
+ * msda_sample_indices_f32: the integer side of the sampling arithmetic.  For every (n,q,m,l,p):
+ * h_low = floor(loc_y*H_l - 0.5), w_low = floor(loc_x*W_l - 0.5) and gate = (-1 < h < H_l && -1 < w < W_l) as computed
+ * by the device function the kernels use (.cuh:285-288, :38-39).  Outputs are (N,Lq,M,L,P) int32/int32/uint8.
+ * msda_fused_points_f32: the fused prologue on its own -- loc_out (N,Lq,M,L,P,2) and attn_out (N,Lq,M,L,P) exactly as
+ * the fused kernels compute them from proj / ref. */
 int msda_sample_indices_f32(const int64_t *shapes_dev, const float *loc,
                             int N, int M, int L, int Lq, int P,
                             int32_t *h_low, int32_t *w_low, uint8_t *gate, void *stream);
 
+int msda_fused_points_f32(const int64_t *shapes_dev, const float *proj, int proj_stride, const float *ref,
+                          int ref_dim, int N, int M, int L, int Lq, int P,
+                          float *loc_out, float *attn_out, void *stream);
+
 /* ---- tuning knobs (benchmarks / tests only; defaults pick the fastest correct path) ----
  * key: "fwd_variant" | "bwd_variant" (0 = auto, 1 = generic one-thread-per-output
  *       kernels, >=2 = specialised kernels), "fwd_block" | "bwd_block"
- *       (threads per block, multiple of 64), "fwd_grid_mult" | "bwd_grid_mult" (blocks per CU).
+ *       (threads per block, multiple of 64), "fwd_grid_mult" | "bwd_grid_mult" (blocks per CU),
+ *       "fwd_tile_margin" | "bwd_tile_margin" (LDS window margin in pixels), "fwd_tile_l0" (first pyramid level the
+ *       hybrid forward serves from LDS).
  * Returns MSDA_OK or MSDA_EINVAL for an unknown key / bad value. */
 int msda_set_option(const char *key, int value);
 int msda_get_option(const char *key, int *value);

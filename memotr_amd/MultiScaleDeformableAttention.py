@@ -112,7 +112,7 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
         output = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
         if output.numel() == 0:  # a frame without queries: nothing to launch (empty tensors have no storage)
             return output
-        keep, hptr = _host_ptr(spatial_shapes, suf == "f32" and D == 32 and Lq == S and L <= 4)
+        keep, hptr = _host_ptr(spatial_shapes, suf in ("f32", "bf16") and D == 32 and Lq == S and L <= 4)
         rc = getattr(_lib.lib, f"msda_forward_{suf}")(
             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
             attn_weight.data_ptr(), N, S, M, D, L, Lq, P, output.data_ptr(), hptr, _stream(value.device))
@@ -139,7 +139,7 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
         grad_attn = torch.empty_like(attn_weight)
         if grad_output.numel() == 0:
             return [grad_value.to(value.dtype), grad_loc, grad_attn]
-        keep, hptr = _host_ptr(spatial_shapes, suf == "f32" and D == 32 and Lq == S and L <= 4)
+        keep, hptr = _host_ptr(spatial_shapes, suf in ("f32", "bf16") and D == 32 and Lq == S and L <= 4)
         rc = getattr(_lib.lib, f"msda_backward_{suf}")(
             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
             attn_weight.data_ptr(), grad_output.data_ptr(), N, S, M, D, L, Lq, P, grad_value.data_ptr(),
@@ -150,6 +150,132 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     if grad_value.dtype != value.dtype:
         grad_value = grad_value.to(value.dtype)
     return [grad_value, grad_loc, grad_attn]
+
+
+# ----------------------------------------------------------------------------------------------------------
+# Fused prologue (no reference counterpart at the extension level: it replaces the elementwise chain of the
+# reference MODULE, models/ops/modules/ms_deform_attn.py:104-123).  C ABI: msda_fused_* in include/msda_hip.h.
+# ----------------------------------------------------------------------------------------------------------
+FUSED_MAX_POINTS = 64       # L * P limit of the fused kernels
+
+
+def _fused_dims(value, spatial_shapes, level_start_index, proj, ref, pad_mask, n_heads, n_points):
+    if value.dim() != 4 or proj.dim() != 3 or ref.dim() != 4:
+        raise RuntimeError("expected value (N,S,M,D), proj (N,Lq,>=3*M*L*P), reference_points (N,Lq,L,2|4)")
+    N, S, M, D = value.shape
+    L = spatial_shapes.shape[0]
+    Lq, P = proj.shape[1], int(n_points)
+    if M != n_heads or proj.shape[0] != N or proj.shape[2] < 3 * M * L * P:
+        raise RuntimeError("proj does not match value / n_heads / n_points")
+    if tuple(ref.shape[:3]) != (N, Lq, L) or ref.shape[3] not in (2, 4):
+        raise RuntimeError("reference_points must be (N, Lq, L, 2|4)")
+    if proj.dtype != torch.float32 or ref.dtype != torch.float32:
+        raise RuntimeError("proj / reference_points must be float32")
+    if pad_mask is not None and (pad_mask.dtype != torch.bool or tuple(pad_mask.shape) != (N, S)):
+        raise RuntimeError("padding mask must be a bool (N, S) tensor")
+    if tuple(spatial_shapes.shape) != (L, 2) or tuple(level_start_index.shape) != (L,):
+        raise RuntimeError("spatial_shapes must be (L,2) and level_start_index (L,)")
+    if spatial_shapes.dtype != torch.int64 or level_start_index.dtype != torch.int64:
+        raise RuntimeError("spatial_shapes and level_start_index must be int64 tensors")
+    if L * P > FUSED_MAX_POINTS:
+        raise RuntimeError(f"fused prologue supports at most {FUSED_MAX_POINTS} sampling points per head")
+    return N, S, M, D, L, Lq, P
+
+
+def _fused_suffix(value):
+    suf = {torch.float32: "f32", torch.bfloat16: "bf16"}.get(value.dtype)
+    if suf is None:
+        raise RuntimeError(f"fused ms_deform_attn: unsupported value dtype {value.dtype}")
+    return suf
+
+
+def fused_supported(value_dtype, head_dim: int, n_levels: int, n_points: int) -> bool:
+    """Shapes / dtypes the fused entry points take (everything else keeps the reference-compatible operator)."""
+    return value_dtype in (torch.float32, torch.bfloat16) and n_levels * n_points <= FUSED_MAX_POINTS
+
+
+def ms_deform_attn_fused_forward(value, spatial_shapes, level_start_index, proj, reference_points, pad_mask,
+                                 n_heads, n_points):
+    """-> output (N, Lq, M*D) from the raw query projection [offsets | logits], the reference points and the
+    padding mask of ``value`` (softmax, location arithmetic and mask fill in-kernel)."""
+    named = [("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
+             ("proj", proj), ("reference_points", reference_points)]
+    if pad_mask is not None:
+        named.append(("padding_mask", pad_mask))
+    _check_inputs(named)
+    N, S, M, D, L, Lq, P = _fused_dims(value, spatial_shapes, level_start_index, proj, reference_points, pad_mask,
+                                       n_heads, n_points)
+    suf = _fused_suffix(value)
+    with torch.cuda.device(value.device):
+        output = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
+        if output.numel() == 0:
+            return output
+        keep, hptr = _host_ptr(spatial_shapes, D == 32 and Lq == S and L <= 4)
+        rc = getattr(_lib.lib, f"msda_fused_forward_{suf}")(
+            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), proj.data_ptr(),
+            proj.shape[2], reference_points.data_ptr(), reference_points.shape[3],
+            pad_mask.data_ptr() if pad_mask is not None else None, N, S, M, D, L, Lq, P, output.data_ptr(), hptr,
+            _stream(value.device))
+        del keep
+    if rc != 0:
+        _raise(rc, "ms_deform_attn_fused_forward")
+    return output
+
+
+def ms_deform_attn_fused_backward(value, spatial_shapes, level_start_index, proj, reference_points, pad_mask,
+                                  grad_output, n_heads, n_points, need_ref_grad=False):
+    """-> [grad_value, grad_proj, grad_reference_points | None]."""
+    named = [("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
+             ("proj", proj), ("reference_points", reference_points), ("grad_output", grad_output)]
+    if pad_mask is not None:
+        named.append(("padding_mask", pad_mask))
+    _check_inputs(named)
+    N, S, M, D, L, Lq, P = _fused_dims(value, spatial_shapes, level_start_index, proj, reference_points, pad_mask,
+                                       n_heads, n_points)
+    suf = _fused_suffix(value)
+    if grad_output.dtype != value.dtype or grad_output.numel() != N * Lq * M * D:
+        raise RuntimeError("grad_output must match the forward output (N, Lq, M*D) and value's dtype")
+    with torch.cuda.device(value.device):
+        grad_value = torch.zeros(value.shape, dtype=torch.float32, device=value.device)
+        used = 3 * M * L * P
+        grad_proj = (torch.empty_like(proj) if proj.shape[2] == used else torch.zeros_like(proj))
+        ref_part = None
+        if need_ref_grad:
+            ref_part = torch.empty((N, Lq, M, L, reference_points.shape[3]), dtype=torch.float32, device=value.device)
+        if grad_output.numel() == 0:
+            gref = ref_part.sum(2) if ref_part is not None else None
+            return [grad_value.to(value.dtype), grad_proj, gref]
+        keep, hptr = _host_ptr(spatial_shapes, D == 32 and Lq == S and L <= 4 and not need_ref_grad)
+        rc = getattr(_lib.lib, f"msda_fused_backward_{suf}")(
+            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), proj.data_ptr(),
+            proj.shape[2], reference_points.data_ptr(), reference_points.shape[3],
+            pad_mask.data_ptr() if pad_mask is not None else None, grad_output.data_ptr(), N, S, M, D, L, Lq, P,
+            grad_value.data_ptr(), grad_proj.data_ptr(), ref_part.data_ptr() if ref_part is not None else None, 0,
+            hptr, _stream(value.device))
+        del keep
+    if rc != 0:
+        _raise(rc, "ms_deform_attn_fused_backward")
+    if grad_value.dtype != value.dtype:
+        grad_value = grad_value.to(value.dtype)
+    return [grad_value, grad_proj, ref_part.sum(2) if ref_part is not None else None]
+
+
+def fused_points(spatial_shapes, proj, reference_points, n_heads, n_points):
+    """Parity hook: (sampling locations (N,Lq,M,L,P,2), attention weights (N,Lq,M,L,P)) as the fused kernels
+    compute them from the raw projection and the reference points."""
+    if not (proj.is_cuda and proj.dtype == torch.float32 and proj.is_contiguous() and reference_points.is_contiguous()):
+        raise RuntimeError("fused_points expects contiguous float32 CUDA tensors")
+    N, Lq = proj.shape[0], proj.shape[1]
+    L, M, P = spatial_shapes.shape[0], int(n_heads), int(n_points)
+    with torch.cuda.device(proj.device):
+        loc = torch.empty((N, Lq, M, L, P, 2), dtype=torch.float32, device=proj.device)
+        attn = torch.empty((N, Lq, M, L, P), dtype=torch.float32, device=proj.device)
+        rc = _lib.lib.msda_fused_points_f32(spatial_shapes.data_ptr(), proj.data_ptr(), proj.shape[2],
+                                            reference_points.data_ptr(), reference_points.shape[3], N, M, L, Lq, P,
+                                            loc.data_ptr(), attn.data_ptr(), _stream(proj.device))
+    if rc != 0:
+        _raise(rc, "msda_fused_points_f32")
+    return loc, attn
 
 
 def sample_indices(spatial_shapes, sampling_loc):

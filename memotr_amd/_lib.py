@@ -11,13 +11,17 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmsda_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_int = ctypes.c_int
 c_void_p = ctypes.c_void_p
 
 _FWD_ARGS = [c_void_p] * 5 + [c_int] * 7 + [c_void_p, c_void_p, c_void_p]
 _BWD_ARGS = [c_void_p] * 6 + [c_int] * 7 + [c_void_p] * 3 + [c_int, c_void_p, c_void_p]
+# fused prologue: value, shapes, lstart, proj, proj_stride, ref, ref_dim, pad_mask, [grad_out,] N..P, outputs...
+_FUSED_FWD_ARGS = [c_void_p] * 4 + [c_int, c_void_p, c_int, c_void_p] + [c_int] * 7 + [c_void_p, c_void_p, c_void_p]
+_FUSED_BWD_ARGS = ([c_void_p] * 4 + [c_int, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p] * 3 +
+                   [c_int, c_void_p, c_void_p])
 
 SYMBOLS = {
     "msda_abi_version": ([], c_int),
@@ -29,7 +33,12 @@ SYMBOLS = {
     "msda_backward_f32": (_BWD_ARGS, c_int),
     "msda_backward_f64": (_BWD_ARGS, c_int),
     "msda_backward_bf16": (_BWD_ARGS, c_int),
+    "msda_fused_forward_f32": (_FUSED_FWD_ARGS, c_int),
+    "msda_fused_forward_bf16": (_FUSED_FWD_ARGS, c_int),
+    "msda_fused_backward_f32": (_FUSED_BWD_ARGS, c_int),
+    "msda_fused_backward_bf16": (_FUSED_BWD_ARGS, c_int),
     "msda_sample_indices_f32": ([c_void_p, c_void_p] + [c_int] * 5 + [c_void_p] * 4, c_int),
+    "msda_fused_points_f32": ([c_void_p, c_void_p, c_int, c_void_p, c_int] + [c_int] * 5 + [c_void_p] * 3, c_int),
     "msda_set_option": ([ctypes.c_char_p, c_int], c_int),
     "msda_get_option": ([ctypes.c_char_p, ctypes.POINTER(c_int)], c_int),
 }

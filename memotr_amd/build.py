@@ -8,6 +8,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(_HERE, "csrc", "msda_hip.hip")
 HDR = os.path.join(os.path.dirname(_HERE), "include", "msda_hip.h")
+COMMON = os.path.join(_HERE, "csrc", "msda_common.h")
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libmsda_hip.so")
 
@@ -24,11 +25,22 @@ def hipcc_path() -> str:
     raise RuntimeError("hipcc not found (ROCm toolchain required to build libmsda_hip.so)")
 
 
+def source_hash() -> str:
+    """sha256 (first 16 hex digits) of the kernel sources: stamps measurements (profiles/traffic.json) so that a
+    number taken on other kernels is recognised as stale."""
+    import hashlib
+    h = hashlib.sha256()
+    for p in (SRC, COMMON):
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(p) > t for p in (SRC, HDR))
+    return any(os.path.getmtime(p) > t for p in (SRC, HDR, COMMON))
 
 
 def build_lib(force: bool = False, verbose: bool = False) -> str:

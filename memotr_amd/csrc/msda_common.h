@@ -1,0 +1,243 @@
+// msda_common.h -- shared device helpers of the gfx950 multi-scale deformable attention kernels.
+//
+// Everything here is device-side arithmetic shared by the kernel families in msda_hip.hip:
+//   * the sampling arithmetic with the reference's rounding points (ms_deform_im2col_cuda.cuh:285-288, :38-39),
+//   * the fused prologue: softmax over the L*P attention logits of a (query, head) row and the sampling
+//     locations from raw offsets + reference points, in the operation order of the reference module
+//     (models/ops/modules/ms_deform_attn.py:104-123), so that the index arithmetic downstream sees the same
+//     float32 bits torch would have produced,
+//   * buffer-resource loads with hardware zero padding, DPP reductions over the lanes that own one row.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace msda {
+
+constexpr int kWave = 64;
+constexpr int kMaxLevels = 16;                // level table kept in LDS by the specialised kernels
+constexpr unsigned kOobOffset = 0x80000000u;  // >= any legal byte offset (tensors < 2 GiB)
+constexpr int kNumCU = 256;
+constexpr int kMaxFusedLP = 64;               // fused prologue: L*P points per row kept in one wavefront / LDS row
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// ----------------------------------------------------------------------------------------
+// storage <-> compute conversions
+// ----------------------------------------------------------------------------------------
+struct bf16_t {
+    uint16_t bits;
+};
+
+__device__ __forceinline__ float to_compute(float x) { return x; }
+__device__ __forceinline__ double to_compute(double x) { return x; }
+__device__ __forceinline__ float to_compute(bf16_t x) { return __uint_as_float(((unsigned)x.bits) << 16); }
+
+__device__ __forceinline__ unsigned bf16_bits_rne(float x) {
+    unsigned u = __float_as_uint(x);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x0040u;   // NaN: keep it quiet
+    u += 0x7fffu + ((u >> 16) & 1u);                                     // round to nearest even
+    return u >> 16;
+}
+
+template <typename TS, typename TC>
+__device__ __forceinline__ TS to_storage(TC x);
+template <>
+__device__ __forceinline__ float to_storage<float, float>(float x) { return x; }
+template <>
+__device__ __forceinline__ double to_storage<double, double>(double x) { return x; }
+template <>
+__device__ __forceinline__ bf16_t to_storage<bf16_t, float>(float x) {
+    bf16_t r;
+    r.bits = (uint16_t)bf16_bits_rne(x);
+    return r;
+}
+
+// ----------------------------------------------------------------------------------------
+// The sampling arithmetic shared by every kernel.  Rounding points are the reference's:
+// the product loc*size is rounded to T first, then 0.5 is subtracted (no FMA contraction),
+// so floor() and the gate see exactly the reference's h_im / w_im (.cuh:285-288).
+// ----------------------------------------------------------------------------------------
+template <typename T>
+struct Sample {
+    bool gate;
+    int h_low, w_low;
+    T lh, lw;
+};
+
+template <typename T>
+__device__ __forceinline__ Sample<T> sample_setup(T loc_w, T loc_h, int H, int W) {
+#pragma clang fp contract(off)
+    Sample<T> s;
+    const T hf = (T)H, wf = (T)W;
+    const T ph = loc_h * hf;
+    const T pw = loc_w * wf;
+    const T h_im = ph - (T)0.5;
+    const T w_im = pw - (T)0.5;
+    s.gate = (h_im > (T)-1) && (w_im > (T)-1) && (h_im < hf) && (w_im < wf);
+    const T fh = floor(h_im), fw = floor(w_im);
+    s.h_low = (int)fh;
+    s.w_low = (int)fw;
+    s.lh = h_im - fh;
+    s.lw = w_im - fw;
+    return s;
+}
+
+// ----------------------------------------------------------------------------------------
+// Where the sampling locations / attention weights of a (query, head) row come from.
+//   plain : the reference operator's own inputs (loc, attn)
+//   fused : the raw query projection [offsets (M,L,P,2) | logits (M,L,P)] of the module, the reference points
+//           and (optionally) the padding mask of `value`; softmax, location arithmetic and mask fill happen in
+//           the kernel (models/ops/modules/ms_deform_attn.py:104-123), loc / attn never exist in HBM
+// ----------------------------------------------------------------------------------------
+struct PointSrc {
+    const float *loc;            // plain (N, Lq, M, L, P, 2)
+    const float *attn;           // plain (N, Lq, M, L, P)
+    const float *proj;           // fused (N*Lq, proj_stride)
+    const float *ref;            // fused (N*Lq, L, ref_dim)
+    const unsigned char *mask;   // fused, may be null: (N, S), non-zero = padded pixel (its value row reads as 0)
+    int proj_stride, n_off, ref_dim;
+};
+
+// sampling location of point t (level l) of head m of query row `qrow` = b*Lq + q, in the reference module's
+// operation order: 2-d  ref + off / (W, H)              (ms_deform_attn.py:114-117)
+//                  4-d  ref_xy + off / P * ref_wh * 0.5 (:118-120)
+// Every step is an IEEE float32 operation (no contraction), i.e. the bits torch computes.
+__device__ __forceinline__ f32x2 fused_location(const PointSrc &s, long qrow, int m, int L, int P, int t, int l,
+                                                int H, int W) {
+#pragma clang fp contract(off)
+    const float *off = s.proj + qrow * s.proj_stride + ((long)m * (L * P) + t) * 2;
+    const float *r = s.ref + (qrow * L + l) * s.ref_dim;
+    const float ox = off[0], oy = off[1];
+    f32x2 xy;
+    if (s.ref_dim == 2) {
+        const float dx = ox / (float)W, dy = oy / (float)H;
+        xy.x = r[0] + dx;
+        xy.y = r[1] + dy;
+    } else {
+        const float px = ox / (float)P, py = oy / (float)P;
+        const float qx = px * r[2], qy = py * r[3];
+        const float hx = qx * 0.5f, hy = qy * 0.5f;
+        xy.x = r[0] + hx;
+        xy.y = r[1] + hy;
+    }
+    return xy;
+}
+
+__device__ __forceinline__ const float *fused_logits(const PointSrc &s, long qrow, int m, int LP) {
+    return s.proj + qrow * s.proj_stride + s.n_off + (long)m * LP;
+}
+
+// (x, y) of point t of row pm = qrow*M + m (qrow = b*Lq + q) from either source
+template <bool FUSED>
+__device__ __forceinline__ f32x2 point_location(const PointSrc &s, long pm, long qrow, int m, int L, int P, int t,
+                                                int l, int H, int W) {
+    if (FUSED) return fused_location(s, qrow, m, L, P, t, l, H, W);
+    return *reinterpret_cast<const f32x2 *>(s.loc + (pm * (L * P) + t) * 2);
+}
+
+// ----------------------------------------------------------------------------------------
+// buffer resources: reads past `bytes` return 0, atomics / stores past it are dropped
+// ----------------------------------------------------------------------------------------
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+
+__device__ __forceinline__ u32x4 buf_load_u4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+}
+
+__device__ __forceinline__ f32x4 buf_load_f4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
+}
+
+__device__ __forceinline__ u32x2 buf_load_u2(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0);
+}
+
+// four consecutive channels of a row as floats: fp32 rows (16 bytes) or bf16 rows (8 bytes)
+template <typename TV>
+__device__ __forceinline__ f32x4 buf_load_ch4(__amdgpu_buffer_rsrc_t r, unsigned off);
+template <>
+__device__ __forceinline__ f32x4 buf_load_ch4<float>(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return buf_load_f4(r, off);
+}
+template <>
+__device__ __forceinline__ f32x4 buf_load_ch4<bf16_t>(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    const u32x2 p = buf_load_u2(r, off);
+    f32x4 v;
+    v.x = __uint_as_float(p.x << 16);
+    v.y = __uint_as_float(p.x & 0xffff0000u);
+    v.z = __uint_as_float(p.y << 16);
+    v.w = __uint_as_float(p.y & 0xffff0000u);
+    return v;
+}
+
+// ----------------------------------------------------------------------------------------
+// reductions over the lanes that own one row (8 lanes: fp32 rows; 4 lanes: bf16 rows), DPP only
+// ----------------------------------------------------------------------------------------
+#define MSDA_DPP(x, ctrl) \
+    __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (x)), (ctrl), 0xF, 0xF, true))
+
+template <int LANES>
+__device__ __forceinline__ float row_sum(float x) {
+    x += MSDA_DPP(x, 0xB1);                      // quad_perm [1,0,3,2]
+    x += MSDA_DPP(x, 0x4E);                      // quad_perm [2,3,0,1]
+    if (LANES == 8) x += MSDA_DPP(x, 0x141);     // row_half_mirror
+    return x;
+}
+
+template <int LANES>
+__device__ __forceinline__ float row_max(float x) {
+    x = fmaxf(x, MSDA_DPP(x, 0xB1));
+    x = fmaxf(x, MSDA_DPP(x, 0x4E));
+    if (LANES == 8) x = fmaxf(x, MSDA_DPP(x, 0x141));
+    return x;
+}
+
+__device__ __forceinline__ float sum8(float x) { return row_sum<8>(x); }
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, kWave);
+    return x;
+}
+
+// softmax statistics (max, 1/sum handled by the caller as a division) of the row's LP logits, computed by the
+// LANES lanes that own the row: lane `sub` takes logits sub, sub+LANES, ...
+template <int LANES>
+__device__ __forceinline__ void row_softmax_stats(const float *logits, int LP, int sub, float &mx, float &sum) {
+    float m = -INFINITY;
+    for (int t = sub; t < LP; t += LANES) m = fmaxf(m, logits[t]);
+    m = row_max<LANES>(m);
+    float s = 0.f;
+    for (int t = sub; t < LP; t += LANES) s += expf(logits[t] - m);
+    mx = m;
+    sum = row_sum<LANES>(s);
+}
+
+// XCD-aware task walk: hardware places block b on XCD b % 8 (observed; speed only).  Give each
+// XCD one contiguous eighth of the (raster-ordered) rows so the level slabs it touches stay in
+// its private 4 MiB L2.
+struct TaskWalk {
+    long begin, end, step;
+};
+__device__ __forceinline__ TaskWalk xcd_walk(long n_tasks, int waves_per_block) {
+    TaskWalk w;
+    const int xcd = blockIdx.x & 7;
+    const int blk_in_xcd = blockIdx.x >> 3;
+    const int blks_per_xcd = (gridDim.x + 7 - xcd) >> 3;  // blocks with this residue
+    const long per = (n_tasks + 7) >> 3;
+    const long lo = per * xcd;
+    long hi = lo + per;
+    if (hi > n_tasks) hi = n_tasks;
+    w.begin = lo + (long)blk_in_xcd * waves_per_block + (threadIdx.x >> 6);
+    w.end = hi;
+    w.step = (long)blks_per_xcd * waves_per_block;
+    return w;
+}
+
+}  // namespace msda

@@ -37,3 +37,35 @@ class MSDeformAttnFunction(Function):
             value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights,
             grad_output.contiguous(), ctx.im2col_step)
         return grad_value, None, None, grad_sampling_loc, grad_attn_weight, None
+
+
+class MSDeformAttnFusedFunction(Function):
+    """The operator with the module's prologue folded in (no reference counterpart):
+    ``apply(value, spatial_shapes, level_start_index, proj, reference_points, padding_mask, n_heads, n_points)``
+    where ``proj`` is the raw output of the two query projections, ``[offsets (M,L,P,2) | logits (M,L,P)]`` per
+    query.  Softmax over the L*P logits, the location arithmetic of ``models/ops/modules/ms_deform_attn.py:113-122``
+    and the padding-mask fill of ``value`` (:107-108) happen inside the HIP kernels, forward and backward:
+    sampling locations and attention weights are never written to memory.  Gradients: value, proj and -- when it
+    requires one -- reference_points."""
+
+    @staticmethod
+    def forward(ctx, value, value_spatial_shapes, value_level_start_index, proj, reference_points, padding_mask,
+                n_heads, n_points):
+        ctx.n_heads, ctx.n_points = int(n_heads), int(n_points)
+        ctx.shapes_host = getattr(value_spatial_shapes, "_msda_host", None)
+        output = MSDA.ms_deform_attn_fused_forward(value, value_spatial_shapes, value_level_start_index, proj,
+                                                   reference_points, padding_mask, ctx.n_heads, ctx.n_points)
+        ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, proj, reference_points,
+                              padding_mask)
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        value, shapes, level_start, proj, reference_points, padding_mask = ctx.saved_tensors
+        if ctx.shapes_host is not None and getattr(shapes, "_msda_host", None) is None:
+            shapes._msda_host = (ctx.shapes_host[0], shapes._version)
+        grad_value, grad_proj, grad_ref = MSDA.ms_deform_attn_fused_backward(
+            value, shapes, level_start, proj, reference_points, padding_mask, grad_output.contiguous(), ctx.n_heads,
+            ctx.n_points, need_ref_grad=ctx.needs_input_grad[4])
+        return grad_value, None, None, grad_proj, grad_ref, None, None, None

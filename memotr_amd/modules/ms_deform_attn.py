@@ -10,6 +10,7 @@ kernels behind ``MSDeformAttnFunction``.
 from __future__ import annotations
 
 import math
+import os
 import warnings
 
 import torch
@@ -17,8 +18,13 @@ import torch.nn.functional as F
 from torch import nn
 from torch.nn.init import constant_, xavier_uniform_
 
-from ..functions import MSDeformAttnFunction
+from .. import MultiScaleDeformableAttention as MSDA
+from ..functions import MSDeformAttnFunction, MSDeformAttnFusedFunction
 from .linear import long_linear
+
+# Fused prologue (softmax + location arithmetic + mask fill inside the HIP kernels).  On by default
+# for CUDA tensors; MEMOTR_FUSED_PROLOGUE=0 (or setting this attribute) keeps the reference-shaped operator boundary.
+FUSED_PROLOGUE = os.environ.get("MEMOTR_FUSED_PROLOGUE", "1") != "0"
 
 
 def _is_power_of_2(n) -> bool:
@@ -142,9 +148,6 @@ class MSDeformAttn(nn.Module):
         M, L, P = self.n_heads, self.n_levels, self.n_points
 
         value = long_linear(input_flatten, self.value_proj.weight, self.value_proj.bias)
-        if input_padding_mask is not None:
-            value = value.masked_fill(input_padding_mask[..., None], 0.0)
-        value = value.view(N, S, M, self.d_model // M)
 
         # one GEMM for both query projections
         n_off = M * L * P * 2
@@ -155,6 +158,25 @@ class MSDeformAttn(nn.Module):
             # sampling locations / attention weights / index arithmetic stay fp32
             proj = proj.float()
             reference_points = reference_points.float()
+        if reference_points.shape[-1] not in (2, 4):
+            raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead.".format(
+                reference_points.shape[-1]))
+
+        if (FUSED_PROLOGUE and value.is_cuda and not self.sigmoid_attn and proj.dtype == torch.float32
+                and reference_points.dtype == torch.float32
+                and MSDA.fused_supported(value.dtype, self.d_model // M, L, P)):
+            # softmax over L*P, ref + off / (W, H) (or the box-scaled form) and the padding-mask fill run inside the
+            # kernels, forward and backward: loc / attn / the masked copy of value never reach HBM
+            out = MSDeformAttnFusedFunction.apply(value.view(N, S, M, self.d_model // M), input_spatial_shapes,
+                                                  input_level_start_index, proj.contiguous(),
+                                                  reference_points.contiguous(),
+                                                  None if input_padding_mask is None else input_padding_mask.contiguous(),
+                                                  M, P)
+            return long_linear(out, self.output_proj.weight, self.output_proj.bias)
+
+        if input_padding_mask is not None:
+            value = value.masked_fill(input_padding_mask[..., None], 0.0)
+        value = value.view(N, S, M, self.d_model // M)
         # views (only the last dim is split), not reshape copies: the ops below write contiguous results anyway
         offsets = proj[..., :n_off].unflatten(-1, (M, L, P, 2))
         logits = proj[..., n_off:].unflatten(-1, (M, L * P))
@@ -167,7 +189,7 @@ class MSDeformAttn(nn.Module):
         if reference_points.shape[-1] == 2:
             wh = _level_sizes(input_spatial_shapes, offsets.dtype)  # (L, 2) as (W, H), cached per pyramid tensor
             loc = reference_points[:, :, None, :, None, :] + offsets / wh[None, None, None, :, None, :]
-        elif reference_points.shape[-1] == 4:
+        else:
             if P & (P - 1) == 0:
                 # offsets / P * wh * 0.5 with P a power of two: scaling by powers of two commutes with rounding,
                 # so folding 0.5 / P into the (small) reference tensor gives the same bits with two fewer kernels
@@ -176,9 +198,6 @@ class MSDeformAttn(nn.Module):
             else:
                 loc = reference_points[:, :, None, :, None, :2] \
                     + offsets / P * reference_points[:, :, None, :, None, 2:] * 0.5
-        else:
-            raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead.".format(
-                reference_points.shape[-1]))
 
         out = MSDeformAttnFunction.apply(value.contiguous(), input_spatial_shapes, input_level_start_index,
                                          loc.contiguous(), attn.contiguous(), self.im2col_step)

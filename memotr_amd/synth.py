@@ -130,6 +130,20 @@ def make_inputs(height: int = 800, width: int = 1333, n_queries: int | None = No
     return out
 
 
+def to_fused_inputs(x: dict) -> dict:
+    """The same sampling pattern as ``x`` (a ``make_inputs`` result) expressed as the fused entry points' inputs:
+    reference points = mean location per (query, level), offsets = (loc - ref) * (W, H), logits = log(attn), packed
+    as projection rows [offsets (M,L,P,2) | logits (M,L,P)].  Returns dict(proj, ref)."""
+    loc, attn = x["loc"].float(), x["attn"].float()
+    N, Lq, M, L, P, _ = loc.shape
+    wh = torch.tensor([[w, h] for h, w in x["shapes_list"]], dtype=torch.float32, device=loc.device)
+    ref = loc.mean(dim=(2, 4))                                                   # (N, Lq, L, 2)
+    off = (loc - ref[:, :, None, :, None, :]) * wh[None, None, None, :, None, :]
+    logits = attn.clamp_min(1e-30).log()
+    proj = torch.cat((off.reshape(N, Lq, M * L * P * 2), logits.reshape(N, Lq, M * L * P)), -1).contiguous()
+    return dict(proj=proj, ref=ref.contiguous())
+
+
 def algorithmic_bytes(batch: int, S: int, Lq: int, M: int, D: int, L: int, P: int, value_size: int = 4,
                       backward: bool = False) -> int:
     """bytes one call must move.  The gather cannot read more of ``value``

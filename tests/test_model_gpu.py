@@ -117,10 +117,17 @@ def test_d32_model_hip_operator_vs_oracle_operator(monkeypatch, hip_lib):
         grads = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
         return res["pred_bboxes"].detach().clone(), res["outputs"].detach().clone(), grads
 
-    box_h, out_h, g_h = run()
-    assert "d32" in hip_lib.last_kernel() or "generic" in hip_lib.last_kernel()
+    box_h, out_h, g_h = run()            # fused-prologue kernels (default)
+    assert "fused" in hip_lib.last_kernel()
+    monkeypatch.setattr(mod, "FUSED_PROLOGUE", False)
+    box_u, out_u, g_u = run()            # reference-shaped operator boundary, HIP kernels
+    assert "fused" not in hip_lib.last_kernel() and "msda" in hip_lib.last_kernel()
     monkeypatch.setattr(mod, "MSDeformAttnFunction", OracleMSDeformAttnFunction)
-    box_o, out_o, g_o = run()
+    box_o, out_o, g_o = run()            # the oracle's torch statement of the operator
+    torch.testing.assert_close(box_u, box_o, rtol=1e-4, atol=1e-5)
+    for n in g_u:
+        denom = float(g_o[n].norm()) + 1e-6
+        assert float((g_u[n] - g_o[n]).norm()) / denom < 5e-3, ("unfused", n)
     torch.testing.assert_close(box_h, box_o, rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(out_h, out_o, rtol=1e-3, atol=1e-4)
     assert g_h.keys() == g_o.keys()
@@ -182,7 +189,7 @@ def test_bf16_autocast_module_tracks_fp32(hip_lib):
     (g32,) = torch.autograd.grad(out32.sum(), query)
     with torch.autocast("cuda", dtype=torch.bfloat16):
         out16 = mod(query, ref, src, shapes, lsi)
-    assert out16.dtype == torch.bfloat16 and "generic" in hip_lib.last_kernel()
+    assert out16.dtype == torch.bfloat16 and "bf16" in hip_lib.last_kernel(), hip_lib.last_kernel()
     (g16,) = torch.autograd.grad(out16.float().sum(), query)
     assert float((out16.float() - out32).abs().max()) < 0.06 * float(out32.abs().max()) + 0.02
     assert float((g16.float() - g32).norm()) < 0.15 * float(g32.norm()) + 1e-3     # bf16: ~3 significant digits through two GEMMs

@@ -163,18 +163,20 @@ def test_fixed_point_window_accumulation_per_region_scales(msda, hip_lib):
 
 
 def test_fixed_point_window_accumulation_outlier_row_and_small_rows(msda, hip_lib):
-    """One query with a 1e4-times larger gradient inside a region must not wipe out its neighbours: rows far below
-    the region's bound bypass the fixed-point windows (float atomics), so every cell stays accurate relative to the
-    mass of contributions it actually receives, except cells the outlier itself writes to (bounded by ITS quantum)."""
+    """Queries with a 1e4-times larger gradient must not wipe out their neighbours.  A region whose rows differ by
+    more than 2^5 is "wide": there every lane whose channels sit more than 7 bits under their (outlier-set) bounds
+    sends its contributions as float atomics.  Guarantee checked here: cells no outlier writes to keep an error of at
+    most a few 2^-14 of the ORDINARY rows' magnitude (the round-1 kernel quantised them at the outlier's step: 80x
+    worse), and no cell is off by more than the outlier's own fixed-point step."""
     x = _small_pyramid_inputs(seed=33)
     S = x["value"].shape[1]
     outliers = torch.arange(50, S, 997)
+    g_normal = float(x["grad_out"].abs().max())
     x["grad_out"][0, outliers] *= 1e4
     x["grad_out"] = x["grad_out"].contiguous()
     got = _hip(msda, x)
     c = _cpu(x)
     want = _oracle(c)
-    mass = _abs_mass(c)
     # cells the outlier rows touch: mass computed with only those rows
     c_out = dict(c)
     go = np.zeros_like(c["grad_out"])
@@ -184,10 +186,11 @@ def test_fixed_point_window_accumulation_outlier_row_and_small_rows(msda, hip_li
     err = np.abs(got[1] - want[1])
     clean = mass_out == 0
     assert clean.mean() > 0.5
-    # float-atomic quality where no outlier lands: a few ulps of the cell's own mass
-    assert (err[clean] <= 2e-5 * mass[clean] + 1e-12).all(), float((err[clean] / (mass[clean] + 1e-30)).max())
-    # everywhere: the fixed-point quantum of the largest bound in play (2^-21 * max|grad_out| * max|attn|, x rows*P/2)
-    bound = float(np.abs(c["grad_out"]).max() * np.abs(c["attn"]).max())
+    a_max = float(np.abs(c["attn"]).max())
+    assert err[clean].max() <= 2.5e-3 * g_normal * a_max, (err[clean].max(), g_normal, a_max)
+    assert np.sqrt((err[clean] ** 2).mean()) <= 1e-4 * g_normal * a_max
+    # everywhere: the fixed-point step of the largest bound in play (2^-21 of max|grad_out| * max|attn|, x rows*P/2)
+    bound = float(np.abs(c["grad_out"]).max() * a_max)
     assert err.max() <= 2.0 ** -12 * bound, (err.max(), bound)
     np.testing.assert_allclose(got[3], want[3], rtol=1e-3, atol=1e-3 * 1e4)
 

@@ -17,7 +17,7 @@ from conftest import golden_cases, load_golden
 pytestmark = pytest.mark.gpu
 
 FWD_VARIANTS = [0, 1, 2, 3, 4]
-BWD_VARIANTS = [0, 1, 2, 3]
+BWD_VARIANTS = [0, 1, 8, 9]
 
 
 @pytest.fixture(scope="module")
@@ -35,6 +35,7 @@ def _reset_options(hip_lib):
         hip_lib.set_option(k, 0)
     hip_lib.set_option("fwd_block", 256)
     hip_lib.set_option("bwd_block", 256)
+    hip_lib.set_option("fwd_tile_l0", 1)
 
 
 def dev(a):
@@ -217,22 +218,19 @@ def test_region_tiled_kernels_match_oracle(msda, hip_lib, case, margin):
     g = pyramid_case(seed, shapes, N, M, P, mode)
     ref_out = oracle.forward(g["value"], g["shapes"], g["level_start"], g["loc"], g["attn"])
     rgv, rgl, rga = oracle.backward(g["value"], g["shapes"], g["level_start"], g["loc"], g["attn"], g["grad_out"])
-    hip_lib.set_option("fwd_variant", 5)
     hip_lib.set_option("fwd_tile_margin", margin)
     hip_lib.set_option("bwd_tile_margin", margin)
     try:
-        out = run_fwd(msda, g)
-        assert hip_lib.last_kernel() == "msda_fwd_d32_tile"
-        np.testing.assert_allclose(out, ref_out, **tol(np.float32, 2))
-        for variant in (6, 7):                     # gather with the coarsest level resident in LDS
-            hip_lib.set_option("fwd_variant", variant)
-            out = run_fwd(msda, g)
-            rows = g["loc"].shape[0] * g["loc"].shape[1] * g["loc"].shape[2]
-            if rows >= 1024 and len(shapes) >= 2:
-                assert "gather_lds" in hip_lib.last_kernel()
-            np.testing.assert_allclose(out, ref_out, **tol(np.float32, 2))
-        # 5: float LDS atomics; 6/7: fixed-point window accumulation (4 / 8 points in flight)
-        for variant, kernel in ((5, "msda_bwd_d32_tile"), (6, "msda_bwd_d32_tile_q<4>"), (7, "msda_bwd_d32_tile_q<8>")):
+        # hybrid forward: levels >= l0 from LDS windows, the rest through the vector L1 (l0 = 0: all LDS; L: none)
+        for variant, pts in ((8, 4), (9, 2)):
+            for l0 in (0, 1, 2, len(shapes)):
+                hip_lib.set_option("fwd_variant", variant)
+                hip_lib.set_option("fwd_tile_l0", l0)
+                out = run_fwd(msda, g)
+                assert hip_lib.last_kernel() == f"msda_fwd_d32_hybrid<{pts}>", hip_lib.last_kernel()
+                np.testing.assert_allclose(out, ref_out, err_msg=f"hybrid<{pts}> l0={l0}", **tol(np.float32, 2))
+        # fixed-point window accumulation, 64-bit packed LDS atomics (2 / 4 points in flight)
+        for variant, kernel in ((8, "msda_bwd_d32_tile_q2<2>"), (9, "msda_bwd_d32_tile_q2<4>")):
             hip_lib.set_option("bwd_variant", variant)
             gv, gl, ga = run_bwd(msda, g)
             assert hip_lib.last_kernel() == kernel
@@ -242,11 +240,12 @@ def test_region_tiled_kernels_match_oracle(msda, hip_lib, case, margin):
     finally:
         hip_lib.set_option("fwd_tile_margin", 3)
         hip_lib.set_option("bwd_tile_margin", 3)
+        hip_lib.set_option("fwd_tile_l0", 1)
 
 
 def test_tiled_variant_falls_back_when_queries_are_not_the_pyramid(msda, hip_lib):
     g = seeded_case(47, 1, 8, 32, 300, 4, 4, [(25, 42), (13, 21), (7, 11), (4, 6)], np.float32)
-    hip_lib.set_option("fwd_variant", 5)
+    hip_lib.set_option("fwd_variant", 8)
     out = run_fwd(msda, g)
     assert "gather" in hip_lib.last_kernel()
     from oracle import msda_oracle as oracle
@@ -267,18 +266,18 @@ def test_full_size_specialised_equals_generic(msda, hip_lib, full_inputs):
     args = (x["value"], x["shapes"], x["level_start"], x["loc"], x["attn"])
     hip_lib.set_option("fwd_variant", 1)
     ref = msda.ms_deform_attn_forward(*args, 64)
-    for v in (2, 3, 4, 5, 6, 7):
+    for v in (2, 3, 4, 8, 9):
         hip_lib.set_option("fwd_variant", v)
         out = msda.ms_deform_attn_forward(*args, 64)
         assert "d32" in hip_lib.last_kernel()
-        assert (v == 5) == ("tile" in hip_lib.last_kernel()) and (v >= 6) == ("gather_lds" in hip_lib.last_kernel())
+        assert (v >= 8) == ("hybrid" in hip_lib.last_kernel())
         torch.testing.assert_close(out, ref, rtol=1e-4, atol=2e-5)
     hip_lib.set_option("bwd_variant", 1)
     ref_g = msda.ms_deform_attn_backward(*args, x["grad_out"], 64)
-    for v in (2, 3, 5, 6, 7):
+    for v in (8, 9):
         hip_lib.set_option("bwd_variant", v)
         got = msda.ms_deform_attn_backward(*args, x["grad_out"], 64)
-        assert (v >= 5) == ("tile" in hip_lib.last_kernel())
+        assert "tile_q2" in hip_lib.last_kernel()
         torch.testing.assert_close(got[0], ref_g[0], rtol=1e-3, atol=2e-4)   # atomics: order-dependent sums
         torch.testing.assert_close(got[1], ref_g[1], rtol=1e-3, atol=5e-3)
         torch.testing.assert_close(got[2], ref_g[2], rtol=1e-3, atol=5e-4)
@@ -342,7 +341,7 @@ def test_out_of_range_and_empty_inputs(msda):
     assert e.shape == (1, 0, 256)
 
 
-def test_autograd_function_and_bf16_extension(msda):
+def test_autograd_function_and_bf16_extension(msda, hip_lib):
     from memotr_amd.functions import MSDeformAttnFunction
     from oracle import msda_oracle as oracle
     g = seeded_case(31, 2, 8, 32, 50, 4, 4, [(12, 20), (6, 10), (3, 5), (2, 3)], np.float32)
@@ -358,5 +357,42 @@ def test_autograd_function_and_bf16_extension(msda):
     # bf16 storage (no reference counterpart): compare with the fp32 oracle on bf16-rounded inputs
     vb = dev(g["value"]).bfloat16()
     ob = msda.ms_deform_attn_forward(vb, dev(g["shapes"]), dev(g["level_start"]), dev(g["loc"]), dev(g["attn"]), 64)
+    assert hip_lib_kernel_is_bf16_d32()
     ref = oracle.forward(vb.float().cpu().numpy(), g["shapes"], g["level_start"], g["loc"], g["attn"])
     np.testing.assert_allclose(ob.float().cpu().numpy(), ref, rtol=1e-2, atol=1e-2)
+    gob = dev(g["grad_out"]).bfloat16()
+    gvb, glb, gab = msda.ms_deform_attn_backward(vb, dev(g["shapes"]), dev(g["level_start"]), dev(g["loc"]),
+                                                 dev(g["attn"]), gob, 64)
+    rgv, rgl, rga = oracle.backward(vb.float().cpu().numpy(), g["shapes"], g["level_start"], g["loc"], g["attn"],
+                                    gob.float().cpu().numpy())
+    np.testing.assert_allclose(gvb.float().cpu().numpy(), rgv, rtol=1e-2, atol=2e-2)     # rounded to bf16 at the end
+    np.testing.assert_allclose(glb.cpu().numpy(), rgl, **tol(np.float32, 60))
+    np.testing.assert_allclose(gab.cpu().numpy(), rga, **tol(np.float32, 20))
+
+
+def hip_lib_kernel_is_bf16_d32():
+    from memotr_amd import _lib
+    return "d32" in _lib.last_kernel() and "bf16" in _lib.last_kernel()
+
+
+def test_bf16_pyramid_self_attention_takes_the_tiled_backward(msda, hip_lib):
+    """bf16 value / grad_out on the pyramid: specialised gather forward (4 lanes x 8 channels per 64-byte row) and
+    the fixed-point tiled backward, against the fp32 oracle on the bf16-rounded inputs."""
+    from memotr_amd.MultiScaleDeformableAttention import tag_host_shapes
+    from oracle import msda_oracle as oracle
+    shapes = [(20, 28), (10, 14), (5, 7), (3, 4)]
+    g = pyramid_case(51, shapes, 2, 8, 4, "local")
+    vb, gob = dev(g["value"]).bfloat16(), dev(g["grad_out"]).bfloat16()
+    sh = tag_host_shapes(dev(g["shapes"]), shapes)
+    args = (vb, sh, dev(g["level_start"]), dev(g["loc"]), dev(g["attn"]))
+    out = msda.ms_deform_attn_forward(*args, 64)
+    assert hip_lib.last_kernel() == "msda_fwd_d32_gather<4,bf16>", hip_lib.last_kernel()
+    gv, gl, ga = msda.ms_deform_attn_backward(*args, gob, 64)
+    assert hip_lib.last_kernel() == "msda_bwd_d32_tile_q2<2,bf16>", hip_lib.last_kernel()
+    v32, go32 = vb.float().cpu().numpy(), gob.float().cpu().numpy()
+    ref = oracle.forward(v32, g["shapes"], g["level_start"], g["loc"], g["attn"])
+    rgv, rgl, rga = oracle.backward(v32, g["shapes"], g["level_start"], g["loc"], g["attn"], go32)
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref, rtol=1e-2, atol=1e-2)
+    np.testing.assert_allclose(gv.float().cpu().numpy(), rgv, rtol=1e-2, atol=3e-2)
+    np.testing.assert_allclose(gl.cpu().numpy(), rgl, **tol(np.float32, 100))
+    np.testing.assert_allclose(ga.cpu().numpy(), rga, **tol(np.float32, 40))

@@ -3,13 +3,11 @@
 
     python tools/kbench.py [--quick] [--out gpurun_out/kbench.json]
 
-For the BASELINE shapes (encoder Lq=S=22323; decoder Lq=300/320/400) and both location
-distributions it times every forward/backward variant x block size x grid multiplier with HIP
-events on the launch stream, checks each specialised variant against the generic kernel, and
-prints achieved GB/s on the algorithmic bytes of SURVEY.md 8(d).
+For the BASELINE shapes (encoder Lq=S=22323; decoder Lq=320) and both location distributions it times the
+forward / backward variants (plain operator and fused prologue) with HIP events on the launch stream, checks each
+against the generic kernel, and prints achieved GB/s on the algorithmic bytes of SURVEY.md 8(d).
 """
 import argparse
-import itertools
 import json
 import os
 import sys
@@ -17,75 +15,83 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from bench import MsdaCall, time_kernel  # noqa: E402
+from bench import FusedCall, MsdaCall, time_kernel  # noqa: E402
 from memotr_amd import _lib  # noqa: E402
 from memotr_amd.synth import make_inputs  # noqa: E402
+
+
+def reset():
+    for k, v in (("fwd_variant", 0), ("bwd_variant", 0), ("fwd_tile_margin", 3), ("bwd_tile_margin", 3),
+                 ("fwd_tile_l0", 1), ("fwd_block", 256), ("fwd_grid_mult", 32)):
+        _lib.set_option(k, v)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--out", default="gpurun_out/kbench.json")
-    ap.add_argument("--fwd-variants", default="1,2,3,4,5")
-    ap.add_argument("--bwd-variants", default="1,2,3,90,5,6,7")
-    ap.add_argument("--blocks", default="64,256")
-    ap.add_argument("--margins", default="1,2,3,4,5")
-    ap.add_argument("--grid-mults", default="8,16,32")
+    ap.add_argument("--dists", default="encoder_like,uniform")
     args = ap.parse_args()
-    fv = [int(x) for x in args.fwd_variants.split(",")]
-    bv = [int(x) for x in args.bwd_variants.split(",")]
-    blocks = [int(x) for x in args.blocks.split(",")]
-    gms = [int(x) for x in args.grid_mults.split(",")]
-    margins = [int(x) for x in args.margins.split(",")]
-    if args.quick:
-        blocks, gms, margins = [256], [16], [2, 3]
     rows = []
-    shapes = [("enc", None), ("dec320", 320)] if args.quick else [("enc", None), ("dec300", 300), ("dec400", 400)]
-    for dist in ("encoder_like", "uniform"):
-        for sname, nq in shapes:
+
+    def record(**kw):
+        rows.append(kw)
+        err = kw.get("err")
+        errs = " ".join(f"{e:.1e}" for e in err) if isinstance(err, (list, tuple)) else f"{err:.1e}"
+        print(f"{kw['op']:9s} {kw['dist']:12s} {kw['shape']:6s} {kw['cfg']:28s} {kw['ms']*1e3:9.1f} us "
+              f"{kw['GBps']:8.1f} GB/s ({kw['GBps']/80:5.1f}%)  err {errs}  {kw['kernel']}", flush=True)
+
+    for dist in args.dists.split(","):
+        for sname, nq in (("enc", None), ("dec320", 320)):
             x = make_inputs(dist=dist, n_queries=nq, device="cuda")
-            call = MsdaCall(x)
-            # reference results from the generic kernels
+            call, fcall = MsdaCall(x), FusedCall(x)
+            reset()
             _lib.set_option("fwd_variant", 1)
             _lib.set_option("bwd_variant", 1)
             call.fwd(); call.bwd(); torch.cuda.synchronize()
             ref = (call.out.clone(), call.gv.clone(), call.gl.clone(), call.ga.clone())
-            for v in fv:
-                combos = [(256, 8)] if v == 1 else itertools.product(blocks, gms)
-                if v == 5:
-                    if nq is not None:
-                        continue
-                    combos = [(256, mg) for mg in margins]
-                for blk, gm in combos:
-                    _lib.set_option("fwd_variant", v); _lib.set_option("fwd_block", blk)
-                    _lib.set_option("fwd_tile_margin" if v == 5 else "fwd_grid_mult", gm)
-                    call.out.zero_(); call.fwd(); torch.cuda.synchronize()
-                    err = float((call.out - ref[0]).abs().max())
-                    ms = time_kernel(call.fwd, iters=30 if nq is None else 100)
-                    gbps = call.bytes() / (ms * 1e-3) / 1e9
-                    rows.append(dict(op="fwd", dist=dist, shape=sname, variant=v, block=blk, grid_mult=gm, ms=ms,
-                                     GBps=gbps, frac=gbps / 8000, err=err, kernel=_lib.last_kernel()))
-                    print(f"fwd {dist:12s} {sname:6s} v{v} blk{blk:4d} gm{gm:2d}  {ms*1e3:9.1f} us  {gbps:8.1f} GB/s "
-                          f"({gbps/80:5.1f}%)  err {err:.1e}  {_lib.last_kernel()}", flush=True)
-            for v in bv:
-                combos = [(256, 8)] if v == 1 else itertools.product(blocks, gms)
-                if v in (5, 6, 7):
-                    if nq is not None:
-                        continue
-                    combos = [(256, mg) for mg in margins]
-                for blk, gm in combos:
-                    _lib.set_option("bwd_variant", v); _lib.set_option("bwd_block", blk)
-                    _lib.set_option("bwd_tile_margin" if v in (5, 6, 7) else "bwd_grid_mult", gm)
-                    call.bwd(); torch.cuda.synchronize()
-                    errs = [float((a - b).abs().max()) for a, b in zip((call.gv, call.gl, call.ga), ref[1:])]
-                    ms = time_kernel(call.bwd, iters=10 if nq is None else 50)
-                    gbps = call.bytes(True) / (ms * 1e-3) / 1e9
-                    rows.append(dict(op="bwd", dist=dist, shape=sname, variant=v, block=blk, grid_mult=gm, ms=ms,
-                                     GBps=gbps, frac=gbps / 8000, err=errs, kernel=_lib.last_kernel()))
-                    print(f"bwd {dist:12s} {sname:6s} v{v} blk{blk:4d} gm{gm:2d}  {ms*1e3:9.1f} us  {gbps:8.1f} GB/s "
-                          f"({gbps/80:5.1f}%)  err {errs[0]:.1e} {errs[1]:.1e} {errs[2]:.1e}  {_lib.last_kernel()}",
-                          flush=True)
-            _lib.set_option("fwd_variant", 0); _lib.set_option("bwd_variant", 0)
+            fcall.fwd(); fcall.bwd(); torch.cuda.synchronize()
+            fref = (fcall.out.clone(), fcall.gv.clone(), fcall.gp.clone())
+            enc = nq is None
+            fwd_cfgs = [("v1 generic", dict(fwd_variant=1)), ("v3 gather<4>", dict(fwd_variant=3)),
+                        ("v2 gather<2>", dict(fwd_variant=2))]
+            if enc:
+                for v in (8, 9):
+                    for l0 in (1, 2, 4):
+                        for mg in ((2, 3) if (l0 == 1 and not args.quick) else (3,)):
+                            fwd_cfgs.append((f"v{v} hybrid l0={l0} m{mg}", dict(fwd_variant=v, fwd_tile_l0=l0,
+                                                                                 fwd_tile_margin=mg)))
+            for name, opts in fwd_cfgs:
+                for c, r, tag in ((call, ref[0], "fwd"), (fcall, fref[0], "fwd_fused")):
+                    reset()
+                    for k, v in opts.items():
+                        _lib.set_option(k, v)
+                    c.out.zero_(); c.fwd(); torch.cuda.synchronize()
+                    err = float((c.out - r).abs().max())
+                    ms = time_kernel(c.fwd, iters=50 if enc else 100)
+                    gbps = c.bytes() / (ms * 1e-3) / 1e9
+                    record(op=tag, dist=dist, shape=sname, cfg=name, ms=ms, GBps=gbps, err=err,
+                           kernel=_lib.last_kernel())
+            bwd_cfgs = [("v1 generic", dict(bwd_variant=1))]
+            if enc:
+                for v in (8, 9):
+                    for mg in ((2, 3, 4) if not args.quick else (3,)):
+                        bwd_cfgs.append((f"v{v} tile_q2 m{mg}", dict(bwd_variant=v, bwd_tile_margin=mg)))
+            for name, opts in bwd_cfgs:
+                for c, tag in ((call, "bwd"), (fcall, "bwd_fused")):
+                    reset()
+                    for k, v in opts.items():
+                        _lib.set_option(k, v)
+                    c.bwd(); torch.cuda.synchronize()
+                    if tag == "bwd":
+                        errs = [float((a - b).abs().max()) for a, b in zip((c.gv, c.gl, c.ga), ref[1:])]
+                    else:
+                        errs = [float((a - b).abs().max()) for a, b in zip((c.gv, c.gp), fref[1:])]
+                    ms = time_kernel(c.bwd, iters=20 if enc else 50)
+                    gbps = c.bytes(True) / (ms * 1e-3) / 1e9
+                    record(op=tag, dist=dist, shape=sname, cfg=name, ms=ms, GBps=gbps, err=errs,
+                           kernel=_lib.last_kernel())
+            reset()
     # memset + copy baselines for context (same bytes as value)
     v = torch.empty(22323 * 8 * 32, device="cuda")
     w = torch.empty_like(v)

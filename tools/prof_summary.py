@@ -101,8 +101,21 @@ def main():
         key = max(fwd, key=lambda k: int(k.split("@grid")[-1]) if k.split("@grid")[-1].isdigit() else 0)
         fe = fwd[key]["mean"]
         wr = traffic.get("write", {}).get(key, {}).get("mean", 0.0)
+        # stamp: the label bench.py prints for this kernel (msda_last_kernel) and the hash of the kernel sources,
+        # so bench.py can refuse the number once the dominant kernel or its source has changed
+        label, sha = None, None
+        try:
+            sys.path.insert(0, repo)
+            from memotr_amd.build import source_hash
+            sha = source_hash()
+            for ln in open(os.path.join(root, "stats.log")):
+                if ln.startswith("{") and '"roofline"' in ln:
+                    label = json.loads(ln)["roofline"].get("kernel")
+        except Exception as exc:  # noqa: BLE001
+            print("traffic stamp incomplete:", exc)
         with open(os.path.join(out_dir, "traffic.json"), "w") as f:
             json.dump({"msda_fwd_encoder_bytes_per_launch": int((2 * fe + wr) * 1024), "kernel": key,
+                       "kernel_label": label, "source_sha16": sha,
                        "fetch_size_KiB": fe, "write_size_KiB": wr,
                        "note": "FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B); separate --pmc passes"},
                       f, indent=1)
