@@ -526,6 +526,7 @@ struct TilePlan {
     int RY, RX;
     int rows;                      // queries per region
     int l0;                        // first level that has an LDS window (forward hybrid); 0 = all levels
+    int wide_log2;                 // tiled backward: rows of a region differing by >= 2^wide_log2 make it "wide" (0 = never)
     int ablate;                    // profiling only (msda_set_option "bwd_ablate"): 1 no flush, 2 no scatter, 4 no value loads
     int H[kTileMaxL], W[kTileMaxL];
     int qstart[kTileMaxL];         // first query of level l (cumulative H*W)
@@ -1062,10 +1063,13 @@ __global__ __launch_bounds__(kTileThreads, PTS <= 2 ? 4 : 2) void msda_bwd_d32_t
     // 64 contiguous bytes per ds_add_u64; the pair order alternates with the row slot to spread the LDS banks
     const int rot = grp & 1;
     const int cpair[2] = {2 * sub + 16 * rot, 2 * sub + 16 * (rot ^ 1)};
-    // A region whose rows differ by more than 2^5 in magnitude ("wide": an outlier query, a masked-out neighbourhood)
-    // would quantise its small rows at the large rows' step.  There, every lane whose own channels sit more than 7 bits
-    // under their bounds sends its contributions through the float path instead; ordinary regions never take that test.
-    const bool wide = (int)(s_rowrange[1] >> 23) - (int)(s_rowrange[0] >> 23) >= 5 && s_rowrange[1] != 0u;
+    // A region whose rows differ by >= 2^wide_log2 in magnitude ("wide": an outlier query, a dead neighbourhood) would
+    // quantise its small rows at the large rows' step.  There, every lane whose own channels sit more than 7 bits
+    // under their bounds sends its contributions through the float path instead; ordinary regions never take that test
+    // (measured on the DanceTrack train step: with the threshold at 2^5 most regions of a real gradient qualify and the
+    // kernel runs 9x slower; at the default 2^12 none do).
+    const bool wide = pl.wide_log2 > 0 && s_rowrange[1] != 0u &&
+                      (int)(s_rowrange[1] >> 23) - (int)(s_rowrange[0] >> 23) >= pl.wide_log2;
     const float lane_limit = wide ? ldexpf(1.f, K - 7) : 0.f;
     float cs[4], ci[4];
 #pragma unroll
@@ -1282,6 +1286,7 @@ std::atomic<int> opt_fwd_block{256}, opt_bwd_block{256};
 std::atomic<int> opt_fwd_grid_mult{32}, opt_bwd_grid_mult{16};
 std::atomic<int> opt_fwd_tile_margin{3}, opt_bwd_tile_margin{3};
 std::atomic<int> opt_fwd_tile_l0{1};      // hybrid forward: first level served from LDS windows
+std::atomic<int> opt_bwd_wide_log2{12};   // tiled backward: row-magnitude range (log2) that makes a region "wide"; 0 = off
 std::atomic<int> opt_bwd_ablate{0};       // profiling only: drop parts of the tiled backward (results are then wrong)
 
 int fail(int code, const char *msg) {
@@ -1560,6 +1565,7 @@ int backward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart,
                 const int grid = (pl.n_blocks + 7) & ~7;
                 const PointSrc src = make_src(loc, attn, fa, M, L, P);
                 pl.ablate = opt_bwd_ablate.load();
+                pl.wide_log2 = opt_bwd_wide_log2.load();
 #define MSDA_LAUNCH_TQ(PTS, FU, NAME)                                                                                \
     do {                                                                                                             \
         rc = allow_big_lds(msda_bwd_d32_tile_q2<PTS, TV, FU>, lds);                                                  \
@@ -1756,6 +1762,7 @@ static std::atomic<int> *find_opt(const char *key) {
     if (!strcmp(key, "bwd_tile_margin")) return &opt_bwd_tile_margin;
     if (!strcmp(key, "fwd_tile_l0")) return &opt_fwd_tile_l0;
     if (!strcmp(key, "bwd_ablate")) return &opt_bwd_ablate;
+    if (!strcmp(key, "bwd_wide_log2")) return &opt_bwd_wide_log2;
     return nullptr;
 }
 
