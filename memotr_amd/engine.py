@@ -150,12 +150,13 @@ def clip_forward_backward(model: nn.Module, criterion, batch: dict, device, use_
         lo, n = starts[ci], chunks[ci]
         enc = model(frame=frames(lo, lo + n), stage="encode")
         if n == 1:
-            encoded[lo] = enc
+            encoded[lo] = dict(enc, frame_slot=lo)        # the frame's slot for the decoder's hipGraphs
             return
         per_frame = {k: (v.split(n_clips, dim=0) if k in ("memory", "valid_ratios", "mask_flatten") else None)
                      for k, v in enc.items()}
         for j in range(n):
             encoded[lo + j] = {k: (per_frame[k][j] if per_frame[k] is not None else v) for k, v in enc.items()}
+            encoded[lo + j]["frame_slot"] = lo + j
 
     def set_up():
         tr = TrackInstances.init_tracks(batch=batch, hidden_dim=core.hidden_dim, num_classes=core.num_classes,

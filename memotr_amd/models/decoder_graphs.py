@@ -1,0 +1,135 @@
+"""hipGraph capture of the decoder loop (forward AND backward), one graph per (layer, frame slot, query bucket).
+
+Why: the decoder / box-refinement chain of one frame is ~150 tiny kernels per layer forward and ~2x that backward,
+each costing the host 13-27 us to issue; with the encoder batched per clip the train step is bound by that launch
+rate.  A captured graph replays the whole per-layer chain with one launch.
+
+What is captured: one iteration of ``DeformableDecoder.forward``'s loop as a tensor-in / tensor-out module
+(``DecoderStep``): anchors -> sine embedding -> ``ref_point_head`` (x ``query_scale``) -> the decoder layer
+(self-attention over the queries, MSDeformAttn cross-attention through the fused HIP kernels, FFN) -> box head ->
+refined reference.  ``torch.cuda.make_graphed_callables`` records its forward and its backward as two graphs.
+
+Constraints handled here:
+  * static shapes: the query count (300 detect + n track queries) is padded to a multiple of ``BUCKET`` with masked
+    slots (padded keys are excluded from the self-attention softmax exactly; padded queries are sliced away, so
+    their rows receive zero gradient);
+  * a graphed callable owns its activations: it cannot run twice before its backward.  A clip holds T frames of
+    activations at once, so every (layer, frame index) gets its own capture ("slot");
+  * the pyramid geometry is part of the key (multi-scale training re-captures per geometry, LRU-bounded);
+  * parameters are shared by all slots: each graph returns its own parameter gradients and autograd adds them up,
+    so DistributedDataParallel's hooks fire once per parameter as usual.
+Anything that cannot be captured (CPU tensors, checkpointing, no grad mode mismatch, a capture error) takes the eager
+path -- same arithmetic, kernel by kernel.
+"""
+from __future__ import annotations
+
+import os
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from ..utils.utils import inverse_sigmoid
+from .utils import pos_to_pos_embed
+
+BUCKET = 32
+MAX_GRAPHS = 96          # (layers x frame slots x geometries x buckets) kept alive; least recently used go first
+
+
+class DecoderStep(nn.Module):
+    """One iteration of the DAB decoder loop (reference models/deformable_decoder.py:70-140) on tensors only.
+    Holds references to modules owned by the decoder; it is never attached to the model tree."""
+
+    def __init__(self, decoder, lid: int, spatial_shapes, level_start_index):
+        super().__init__()
+        self.layer = decoder.layers[lid]
+        self.ref_point_head = decoder.ref_point_head
+        self.query_scale = decoder.query_scale
+        self.bbox_embed = decoder.bbox_embed[lid]
+        self.lid = lid
+        self.merge = lid >= decoder.merge_det_track_layer
+        self.nd = decoder.n_det_queries
+        self.d_model = decoder.d_model
+        # constants of the geometry: closed over, not graph inputs (the operator plans from their host tag)
+        self._shapes = spatial_shapes
+        self._lsi = level_start_index
+
+    def forward(self, output, reference_points, src, ratios4, query_mask, src_padding_mask):
+        ref_in = reference_points[:, :, None] * ratios4
+        anchor = pos_to_pos_embed(ref_in[:, :, 0, :], num_pos_feats=self.d_model // 2)
+        raw_pos = self.ref_point_head(anchor)
+        query_pos = raw_pos if self.lid == 0 else self.query_scale(output) * raw_pos
+        out = self.layer(output, query_pos, ref_in, src, self._shapes, self._lsi, query_mask, src_padding_mask,
+                         self.merge)
+        new_ref = (self.bbox_embed(out) + inverse_sigmoid(reference_points)).sigmoid()
+        return out, new_ref
+
+
+def enabled() -> bool:
+    return os.environ.get("MEMOTR_DECODER_GRAPHS", "1") != "0"
+
+
+class DecoderGraphs:
+    """Cache of captured decoder steps, owned by a ``DeformableDecoder``."""
+
+    def __init__(self, decoder):
+        self.decoder = decoder
+        self.slots: "OrderedDict[tuple, object]" = OrderedDict()
+        self.failed = False
+        self.captures = 0
+
+    def usable(self, output, src) -> bool:
+        d = self.decoder
+        return (enabled() and not self.failed and output.is_cuda and d.use_dab and d.bbox_embed is not None
+                and not d.use_checkpoint and torch.is_grad_enabled() and src.requires_grad
+                and not torch.is_autocast_enabled() and output.dtype == torch.float32)
+
+    @staticmethod
+    def bucket(n_queries: int, n_det: int) -> int:
+        # the TOTAL is rounded up to a multiple of BUCKET (the fused attention kernels want aligned key counts) with
+        # at least one (masked) track slot: a zero-sized track part would put empty copy nodes into the capture
+        n = max(n_queries, n_det + 1)
+        return (n + BUCKET - 1) // BUCKET * BUCKET
+
+    def step(self, lid: int, frame_slot: int, args, shapes, lsi):
+        """Run decoder iteration ``lid`` of frame ``frame_slot`` through its graph (captured on first use)."""
+        key = (lid, frame_slot, tuple(a.shape for a in args), tuple(bool(a.requires_grad) for a in args), id(shapes))
+        slot = self.slots.get(key)
+        if slot is None:
+            slot = self._capture(lid, args, shapes, lsi)
+            if slot is None:
+                return None
+            self.slots[key] = slot
+            while len(self.slots) > MAX_GRAPHS:
+                self.slots.popitem(last=False)
+        else:
+            self.slots.move_to_end(key)
+        fn, params = slot
+        return fn(*args, *params)
+
+    def _capture(self, lid, args, shapes, lsi):
+        """Capture ``DecoderStep(lid)`` as a function of (inputs..., parameters...).
+
+        The parameters travel as ordinary tensor ARGUMENTS (``torch.func.functional_call`` substitutes them): the
+        captured backward then differentiates with respect to fresh leaf tensors only.  Capturing with respect to the
+        live ``nn.Parameter`` objects instead makes autograd reuse their gradient-accumulator nodes, which remember the
+        stream they were created on -- any earlier use of a decoder parameter on the default stream (an eager step, a
+        kept-alive graph) then drags the legacy stream into the capture and hipStreamEndCapture faults."""
+        step = DecoderStep(self.decoder, lid, shapes, lsi)
+        names, params = zip(*step.named_parameters())
+        n_user = len(args)
+
+        def run(*flat):
+            return torch.func.functional_call(step, dict(zip(names, flat[n_user:])), tuple(flat[:n_user]))
+
+        sample = tuple(a.detach().clone().requires_grad_(a.requires_grad) for a in args) + \
+            tuple(p.detach().clone().requires_grad_(p.requires_grad) for p in params)
+        try:
+            fn = torch.cuda.make_graphed_callables(run, sample, num_warmup_iters=2, allow_unused_input=True)
+        except Exception as exc:  # noqa: BLE001 -- capture is an optimisation; eager stays valid
+            import warnings
+            warnings.warn(f"decoder graph capture failed ({type(exc).__name__}: {exc}); running eager")
+            self.failed = True
+            return None
+        self.captures += 1
+        return fn, params

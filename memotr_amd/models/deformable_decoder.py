@@ -9,6 +9,7 @@ from torch.utils.checkpoint import checkpoint
 from ..modules import MSDeformAttn
 from ..modules.attention import self_attention
 from ..utils.utils import inverse_sigmoid
+from .decoder_graphs import DecoderGraphs
 from .mlp import MLP
 from .utils import get_activation_layer, get_clones, pos_to_pos_embed
 
@@ -33,13 +34,60 @@ class DeformableDecoder(nn.Module):
             self.query_scale = MLP(d_model, d_model, d_model, 2)
             self.ref_point_head = MLP(d_model * 2, d_model, d_model, 2)
 
+    def graphs(self) -> DecoderGraphs:
+        g = self.__dict__.get("_decoder_graphs")
+        if g is None:
+            g = self.__dict__["_decoder_graphs"] = DecoderGraphs(self)
+        return g
+
+    def _forward_graphed(self, tgt, reference_points, src, spatial_shapes, level_start_index, valid_ratios, query_mask,
+                         src_padding_mask, frame_slot):
+        """The loop below with every iteration replayed from a hipGraph (models/decoder_graphs.py).  Returns None
+        when a capture fails; the caller then runs the eager loop."""
+        graphs = self.graphs()
+        nd = self.n_det_queries
+        B, nq, C = tgt.shape
+        nb = graphs.bucket(nq, nd)
+        if nb > nq:      # static shapes: pad the track part with masked slots (excluded as keys, sliced away below)
+            pad = nb - nq
+            tgt = torch.cat((tgt, tgt.new_zeros(B, pad, C)), 1)
+            reference_points = torch.cat((reference_points, reference_points.new_full((B, pad, 4), 0.5)), 1)
+            query_mask = torch.cat((query_mask, query_mask.new_ones(B, pad)), 1)
+        ratios4 = torch.cat([valid_ratios, valid_ratios], -1)[:, None].contiguous()
+        query_mask = query_mask.contiguous()
+        output = tgt
+        outs, refs, layer_inputs, boxes = [], [], [], []
+        for lid in range(self.num_layers):
+            res = graphs.step(lid, frame_slot, (output.contiguous(), reference_points.contiguous(), src, ratios4,
+                                                query_mask, src_padding_mask), spatial_shapes, level_start_index)
+            if res is None:
+                return None
+            layer_inputs.append(output[:, :nq])
+            output, new_ref = res
+            boxes.append(new_ref[:, :nq])
+            if lid >= self.merge_det_track_layer:
+                reference_points = new_ref.detach()
+            else:   # track queries did not go through the layer: keep their anchors
+                reference_points = torch.cat((new_ref[:, :nd].detach(), reference_points[:, nd:]), dim=1)
+            outs.append(output[:, :nq])
+            refs.append(reference_points[:, :nq])
+        return torch.stack(outs), torch.stack(refs), torch.stack(layer_inputs), torch.stack(boxes)
+
     def forward(self, tgt, reference_points, src, src_spatial_shapes, src_level_start_index, src_valid_ratios,
-                query_pos, query_mask, src_padding_mask):
+                query_pos, query_mask, src_padding_mask, frame_slot=None):
         """tgt (B,Nq,C); reference_points (B,Nq,4) in [0,1]; src (B,S,C).
         Returns stacks over layers: outputs (n,B,Nq,C), refined references (n,B,Nq,4), layer inputs (n,B,Nq,C),
-        refined boxes with their graph (n,B,Nq,4) or None without box refinement."""
+        refined boxes with their graph (n,B,Nq,4) or None without box refinement.
+        ``frame_slot`` (the frame's index inside its clip, given by the training loop) selects the hipGraph slot the
+        loop is replayed from; without it -- inference, the reference's frame order -- the loop runs eagerly."""
         if not self.return_intermediate:
             raise NotImplementedError("Not Support for no Inter Outputs.")
+        if (frame_slot is not None and reference_points.shape[-1] == 4 and src_padding_mask is not None
+                and self.graphs().usable(tgt, src)):
+            res = self._forward_graphed(tgt, reference_points, src, src_spatial_shapes, src_level_start_index,
+                                        src_valid_ratios, query_mask, src_padding_mask, frame_slot)
+            if res is not None:
+                return res
         nd = self.n_det_queries
         output = tgt
         outs, refs, layer_inputs, boxes = [], [], [], []

@@ -91,6 +91,10 @@ class MSDeformAttn(nn.Module):
         concatenations are made once per step: the cached tensors (and the autograd edge to the four parameters)
         are reused until a parameter changes or a backward pass has flowed through them."""
         so, aw = self.sampling_offsets, self.attention_weights
+        if so.weight.is_cuda and torch.cuda.is_current_stream_capturing():
+            # inside a hipGraph capture the concatenation must be part of the graph (a cached tensor would freeze the
+            # weights of the first capture into every replay)
+            return torch.cat((so.weight, aw.weight), 0), torch.cat((so.bias, aw.bias), 0)
         key = (id(so.weight), id(aw.weight), so.weight._version, aw.weight._version, so.bias._version,
                aw.bias._version, so.weight.device, so.weight.dtype, torch.is_grad_enabled())
         cached = self.__dict__.get("_fused_qproj")
