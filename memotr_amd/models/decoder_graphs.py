@@ -1,20 +1,20 @@
-"""hipGraph capture of the decoder loop (forward AND backward), one graph per (layer, frame slot, query bucket).
+"""hipGraph capture of the decoder loop (forward AND backward), one graph pair per (frame slot, query bucket).
 
 Why: the decoder / box-refinement chain of one frame is ~150 tiny kernels per layer forward and ~2x that backward,
 each costing the host 13-27 us to issue; with the encoder batched per clip the train step is bound by that launch
 rate.  A captured graph replays the whole per-layer chain with one launch.
 
-What is captured: one iteration of ``DeformableDecoder.forward``'s loop as a tensor-in / tensor-out module
-(``DecoderStep``): anchors -> sine embedding -> ``ref_point_head`` (x ``query_scale``) -> the decoder layer
+What is captured: ``DeformableDecoder.forward``'s loop as a tensor-in / tensor-out module (``DecoderLoop``): per layer anchors -> sine embedding -> ``ref_point_head`` (x ``query_scale``) -> the decoder layer
 (self-attention over the queries, MSDeformAttn cross-attention through the fused HIP kernels, FFN) -> box head ->
-refined reference.  ``torch.cuda.make_graphed_callables`` records its forward and its backward as two graphs.
+refined reference (detached for the next layer).  ``torch.cuda.make_graphed_callables`` records its forward and its
+backward as two graphs.
 
 Constraints handled here:
   * static shapes: the query count (300 detect + n track queries) is padded to a multiple of ``BUCKET`` with masked
     slots (padded keys are excluded from the self-attention softmax exactly; padded queries are sliced away, so
     their rows receive zero gradient);
   * a graphed callable owns its activations: it cannot run twice before its backward.  A clip holds T frames of
-    activations at once, so every (layer, frame index) gets its own capture ("slot");
+    activations at once, so every frame index gets its own capture ("slot");
   * the pyramid geometry is part of the key (multi-scale training re-captures per geometry, LRU-bounded);
   * parameters are shared by all slots: each graph returns its own parameter gradients and autograd adds them up,
     so DistributedDataParallel's hooks fire once per parameter as usual.
@@ -33,36 +33,51 @@ from ..utils.utils import inverse_sigmoid
 from .utils import pos_to_pos_embed
 
 BUCKET = 32
-MAX_GRAPHS = 96          # (layers x frame slots x geometries x buckets) kept alive; least recently used go first
+MAX_GRAPHS = 24          # (frame slots x geometries x buckets) kept alive; least recently used go first
 
 
-class DecoderStep(nn.Module):
-    """One iteration of the DAB decoder loop (reference models/deformable_decoder.py:70-140) on tensors only.
-    Holds references to modules owned by the decoder; it is never attached to the model tree."""
+class DecoderLoop(nn.Module):
+    """All iterations of the decoder loop of one frame (what ``DeformableDecoder.forward`` does with DAB anchors and
+    box refinement, reference models/deformable_decoder.py:70-140), tensors in -> four stacks out.  One capture per
+    frame slot: `src` and the parameters enter the graph once per frame.
 
-    def __init__(self, decoder, lid: int, spatial_shapes, level_start_index):
+    Holds references to modules owned by the decoder and is never attached to the model tree.  Every module appears
+    exactly ONCE in this tree: ``torch.func.functional_call`` does not restore parameters of a module that is
+    reachable under two names (it leaves the substituted tensors behind -- observed with torch 2.10), so the heads
+    shared by all layers (``ref_point_head``, ``query_scale``) live at this level, not inside per-layer children."""
+
+    def __init__(self, decoder, spatial_shapes, level_start_index):
         super().__init__()
-        self.layer = decoder.layers[lid]
+        self.layers = nn.ModuleList(decoder.layers)
+        self.bbox_embed = nn.ModuleList(decoder.bbox_embed)
         self.ref_point_head = decoder.ref_point_head
         self.query_scale = decoder.query_scale
-        self.bbox_embed = decoder.bbox_embed[lid]
-        self.lid = lid
-        self.merge = lid >= decoder.merge_det_track_layer
         self.nd = decoder.n_det_queries
+        self.merge_from = decoder.merge_det_track_layer
         self.d_model = decoder.d_model
         # constants of the geometry: closed over, not graph inputs (the operator plans from their host tag)
         self._shapes = spatial_shapes
         self._lsi = level_start_index
 
     def forward(self, output, reference_points, src, ratios4, query_mask, src_padding_mask):
-        ref_in = reference_points[:, :, None] * ratios4
-        anchor = pos_to_pos_embed(ref_in[:, :, 0, :], num_pos_feats=self.d_model // 2)
-        raw_pos = self.ref_point_head(anchor)
-        query_pos = raw_pos if self.lid == 0 else self.query_scale(output) * raw_pos
-        out = self.layer(output, query_pos, ref_in, src, self._shapes, self._lsi, query_mask, src_padding_mask,
-                         self.merge)
-        new_ref = (self.bbox_embed(out) + inverse_sigmoid(reference_points)).sigmoid()
-        return out, new_ref
+        outs, refs, layer_inputs, boxes = [], [], [], []
+        for lid, layer in enumerate(self.layers):
+            layer_inputs.append(output)
+            ref_in = reference_points[:, :, None] * ratios4
+            anchor = pos_to_pos_embed(ref_in[:, :, 0, :], num_pos_feats=self.d_model // 2)
+            raw_pos = self.ref_point_head(anchor)
+            query_pos = raw_pos if lid == 0 else self.query_scale(output) * raw_pos
+            merge = lid >= self.merge_from
+            output = layer(output, query_pos, ref_in, src, self._shapes, self._lsi, query_mask, src_padding_mask, merge)
+            new_ref = (self.bbox_embed[lid](output) + inverse_sigmoid(reference_points)).sigmoid()
+            boxes.append(new_ref)
+            if merge:
+                reference_points = new_ref.detach()
+            else:   # track queries did not go through the layer: keep their anchors
+                reference_points = torch.cat((new_ref[:, :self.nd].detach(), reference_points[:, self.nd:]), dim=1)
+            outs.append(output)
+            refs.append(reference_points)
+        return torch.stack(outs), torch.stack(refs), torch.stack(layer_inputs), torch.stack(boxes)
 
 
 def enabled() -> bool:
@@ -91,12 +106,12 @@ class DecoderGraphs:
         n = max(n_queries, n_det + 1)
         return (n + BUCKET - 1) // BUCKET * BUCKET
 
-    def step(self, lid: int, frame_slot: int, args, shapes, lsi):
-        """Run decoder iteration ``lid`` of frame ``frame_slot`` through its graph (captured on first use)."""
-        key = (lid, frame_slot, tuple(a.shape for a in args), tuple(bool(a.requires_grad) for a in args), id(shapes))
+    def run(self, frame_slot: int, args, shapes, lsi):
+        """The decoder loop of frame ``frame_slot`` through its graph (captured on first use); None if capture failed."""
+        key = (frame_slot, tuple(a.shape for a in args), tuple(bool(a.requires_grad) for a in args), id(shapes))
         slot = self.slots.get(key)
         if slot is None:
-            slot = self._capture(lid, args, shapes, lsi)
+            slot = self._capture(args, shapes, lsi)
             if slot is None:
                 return None
             self.slots[key] = slot
@@ -107,23 +122,28 @@ class DecoderGraphs:
         fn, params = slot
         return fn(*args, *params)
 
-    def _capture(self, lid, args, shapes, lsi):
-        """Capture ``DecoderStep(lid)`` as a function of (inputs..., parameters...).
+    def _capture(self, args, shapes, lsi):
+        """Capture ``DecoderLoop`` as a function of (inputs..., parameters...).
 
         The parameters travel as ordinary tensor ARGUMENTS (``torch.func.functional_call`` substitutes them): the
         captured backward then differentiates with respect to fresh leaf tensors only.  Capturing with respect to the
         live ``nn.Parameter`` objects instead makes autograd reuse their gradient-accumulator nodes, which remember the
         stream they were created on -- any earlier use of a decoder parameter on the default stream (an eager step, a
-        kept-alive graph) then drags the legacy stream into the capture and hipStreamEndCapture faults."""
-        step = DecoderStep(self.decoder, lid, shapes, lsi)
-        names, params = zip(*step.named_parameters())
+        kept-alive graph) then drags the legacy stream into the capture and hipStreamEndCapture faults.
+        The sample parameters ALIAS the real ones (``p.detach()`` shares storage), so a replay reads the live weights
+        in place: make_graphed_callables skips the refresh copy of an argument whose address equals its placeholder's."""
+        loop = DecoderLoop(self.decoder, shapes, lsi)
+        names, params = zip(*loop.named_parameters())
+        if len(names) != sum(1 for _ in loop.named_parameters(remove_duplicate=False)):
+            self.failed = True      # a module shared between layers (no box refinement clones): see DecoderLoop
+            return None
         n_user = len(args)
 
         def run(*flat):
-            return torch.func.functional_call(step, dict(zip(names, flat[n_user:])), tuple(flat[:n_user]))
+            return torch.func.functional_call(loop, dict(zip(names, flat[n_user:])), tuple(flat[:n_user]))
 
         sample = tuple(a.detach().clone().requires_grad_(a.requires_grad) for a in args) + \
-            tuple(p.detach().clone().requires_grad_(p.requires_grad) for p in params)
+            tuple(p.detach().requires_grad_(p.requires_grad) for p in params)
         try:
             fn = torch.cuda.make_graphed_callables(run, sample, num_warmup_iters=2, allow_unused_input=True)
         except Exception as exc:  # noqa: BLE001 -- capture is an optimisation; eager stays valid
@@ -131,5 +151,8 @@ class DecoderGraphs:
             warnings.warn(f"decoder graph capture failed ({type(exc).__name__}: {exc}); running eager")
             self.failed = True
             return None
+        # functional_call must have put every nn.Parameter back (see DecoderLoop)
+        assert all(isinstance(p, nn.Parameter) for p in loop.parameters()) and \
+            [id(p) for p in loop.parameters()] == [id(p) for p in params], "decoder parameters were replaced"
         self.captures += 1
         return fn, params

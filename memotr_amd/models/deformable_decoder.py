@@ -55,23 +55,14 @@ class DeformableDecoder(nn.Module):
             query_mask = torch.cat((query_mask, query_mask.new_ones(B, pad)), 1)
         ratios4 = torch.cat([valid_ratios, valid_ratios], -1)[:, None].contiguous()
         query_mask = query_mask.contiguous()
-        output = tgt
-        outs, refs, layer_inputs, boxes = [], [], [], []
-        for lid in range(self.num_layers):
-            res = graphs.step(lid, frame_slot, (output.contiguous(), reference_points.contiguous(), src, ratios4,
-                                                query_mask, src_padding_mask), spatial_shapes, level_start_index)
-            if res is None:
-                return None
-            layer_inputs.append(output[:, :nq])
-            output, new_ref = res
-            boxes.append(new_ref[:, :nq])
-            if lid >= self.merge_det_track_layer:
-                reference_points = new_ref.detach()
-            else:   # track queries did not go through the layer: keep their anchors
-                reference_points = torch.cat((new_ref[:, :nd].detach(), reference_points[:, nd:]), dim=1)
-            outs.append(output[:, :nq])
-            refs.append(reference_points[:, :nq])
-        return torch.stack(outs), torch.stack(refs), torch.stack(layer_inputs), torch.stack(boxes)
+        res = graphs.run(frame_slot, (tgt.contiguous(), reference_points.contiguous(), src, ratios4, query_mask,
+                                      src_padding_mask), spatial_shapes, level_start_index)
+        if res is None:
+            return None
+        outs, refs, layer_inputs, boxes = res
+        if nb > nq:
+            outs, refs, layer_inputs, boxes = (x[:, :, :nq] for x in (outs, refs, layer_inputs, boxes))
+        return outs, refs, layer_inputs, boxes
 
     def forward(self, tgt, reference_points, src, src_spatial_shapes, src_level_start_index, src_valid_ratios,
                 query_pos, query_mask, src_padding_mask, frame_slot=None):

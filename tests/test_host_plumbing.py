@@ -156,3 +156,35 @@ def test_query_mask_tag_drops_an_all_false_mask():
     mask._no_padding = True
     torch.testing.assert_close(self_attention(mha, x, x, mask), mha(x, x, x, need_weights=False)[0], rtol=1e-5,
                                atol=1e-6)
+
+
+def test_decoder_loop_module_equals_the_eager_decoder_and_leaves_parameters_alone(monkeypatch):
+    """models/decoder_graphs.DecoderLoop is what gets captured in hipGraphs on the GPU: on the CPU it must reproduce
+    DeformableDecoder.forward exactly, give every parameter a gradient through torch.func.functional_call, and leave
+    the model's nn.Parameter objects in place (functional_call does not restore modules reachable under two names)."""
+    import torch
+    from model_helpers import build_small_memotr, patch_operator
+    from memotr_amd.models.decoder_graphs import DecoderGraphs, DecoderLoop
+    patch_operator(monkeypatch)
+    torch.manual_seed(0)
+    model = build_small_memotr().train()
+    dec = model.transformer.decoder
+    before = {n: id(p) for n, p in model.named_parameters()}
+    shapes, lsi, S, nq = torch.tensor([[6, 8], [3, 4], [2, 2], [1, 1]]), torch.tensor([0, 48, 60, 64]), 65, 32
+    loop = DecoderLoop(dec, shapes, lsi)
+    names, params = zip(*loop.named_parameters())
+    assert len(names) == sum(1 for _ in loop.named_parameters(remove_duplicate=False))
+    mask = torch.zeros(1, nq, dtype=torch.bool)
+    mask[:, 26:] = True
+    args = (torch.randn(1, nq, 64).requires_grad_(True), torch.rand(1, nq, 4).requires_grad_(True),
+            torch.randn(1, S, 64).requires_grad_(True), torch.ones(1, 1, 4, 4), mask, torch.zeros(1, S, dtype=torch.bool))
+    flat = tuple(p.detach().requires_grad_(True) for p in params)
+    outs = torch.func.functional_call(loop, dict(zip(names, flat)), args)
+    grads = torch.autograd.grad(sum(o.sum() for o in outs if o.requires_grad), flat, allow_unused=True)
+    assert all(g is not None for g in grads)
+    assert {n: id(p) for n, p in model.named_parameters()} == before
+    eager = dec(args[0], args[1], args[2], shapes, lsi, torch.ones(1, 4, 2), None, mask, args[5])
+    for a, b in zip(outs, eager):
+        assert torch.equal(a, b)
+    assert DecoderGraphs.bucket(300, 300) == 320 and DecoderGraphs.bucket(311, 300) == 320
+    assert DecoderGraphs.bucket(321, 300) == 352 and DecoderGraphs.bucket(20, 20) == 32
