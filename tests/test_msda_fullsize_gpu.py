@@ -26,8 +26,10 @@ def msda(hip_lib):
     return MSDA
 
 
-@pytest.fixture(autouse=True)
-def _reset_options(hip_lib):
+@pytest.fixture(autouse=True, params=[0, 8, 10], ids=["bwd_default", "bwd_tile_q2", "bwd_tile_lv"])
+def _bwd_family(request, hip_lib):
+    """Every test of this file runs with the default backward and with each region-tiled family forced."""
+    hip_lib.set_option("bwd_variant", request.param)
     yield
     for k in ("fwd_variant", "bwd_variant"):
         hip_lib.set_option(k, 0)
@@ -80,7 +82,7 @@ def test_encoder_shape_forward_and_backward_match_oracle(msda, hip_lib, pyr, dis
         assert x["value"].shape[1] == 22323
     got = _hip(msda, x)
     kernel = hip_lib.last_kernel()
-    assert "tile" in kernel, kernel          # the default training kernel for pyramid self-attention
+    assert "tile" in kernel, kernel          # the training kernels for pyramid self-attention
     _check(got, _oracle(_cpu(x)), f"{pyr}/{dist}")
 
 
@@ -129,7 +131,7 @@ def test_fixed_point_window_accumulation_per_channel_scales(msda, hip_lib):
     scales = 10.0 ** (torch.rand(256, generator=g) * 7 - 4)
     x["grad_out"] = (x["grad_out"] * scales.cuda()).contiguous()
     got = _hip(msda, x)
-    assert "tile_q" in hip_lib.last_kernel()
+    assert "tile_" in hip_lib.last_kernel()
     want = _oracle(_cpu(x))
     gv, rgv = got[1].reshape(-1, 256), want[1].reshape(-1, 256)
     err = np.abs(gv - rgv).max(0) / np.abs(rgv).max(0)

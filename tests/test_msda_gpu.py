@@ -17,7 +17,7 @@ from conftest import golden_cases, load_golden
 pytestmark = pytest.mark.gpu
 
 FWD_VARIANTS = [0, 1, 2, 3, 4]
-BWD_VARIANTS = [0, 1, 8, 9]
+BWD_VARIANTS = [0, 1, 8, 9, 10]
 
 
 @pytest.fixture(scope="module")
@@ -230,7 +230,9 @@ def test_region_tiled_kernels_match_oracle(msda, hip_lib, case, margin):
                 assert hip_lib.last_kernel() == f"msda_fwd_d32_hybrid<{pts}>", hip_lib.last_kernel()
                 np.testing.assert_allclose(out, ref_out, err_msg=f"hybrid<{pts}> l0={l0}", **tol(np.float32, 2))
         # fixed-point window accumulation, 64-bit packed LDS atomics (2 / 4 points in flight)
-        for variant, kernel in ((8, "msda_bwd_d32_tile_q2<2>"), (9, "msda_bwd_d32_tile_q2<4>")):
+        # 10 / 11: the same scheme with one pyramid level per workgroup and every input loaded once
+        for variant, kernel in ((8, "msda_bwd_d32_tile_q2<2>"), (9, "msda_bwd_d32_tile_q2<4>"),
+                                (10, "msda_bwd_d32_tile_lv<2>"), (11, "msda_bwd_d32_tile_lv<4>")):
             hip_lib.set_option("bwd_variant", variant)
             gv, gl, ga = run_bwd(msda, g)
             assert hip_lib.last_kernel() == kernel
@@ -274,10 +276,10 @@ def test_full_size_specialised_equals_generic(msda, hip_lib, full_inputs):
         torch.testing.assert_close(out, ref, rtol=1e-4, atol=2e-5)
     hip_lib.set_option("bwd_variant", 1)
     ref_g = msda.ms_deform_attn_backward(*args, x["grad_out"], 64)
-    for v in (8, 9):
+    for v in (8, 9, 10, 11):
         hip_lib.set_option("bwd_variant", v)
         got = msda.ms_deform_attn_backward(*args, x["grad_out"], 64)
-        assert "tile_q2" in hip_lib.last_kernel()
+        assert ("tile_q2" if v < 10 else "tile_lv") in hip_lib.last_kernel()
         torch.testing.assert_close(got[0], ref_g[0], rtol=1e-3, atol=2e-4)   # atomics: order-dependent sums
         torch.testing.assert_close(got[1], ref_g[1], rtol=1e-3, atol=5e-3)
         torch.testing.assert_close(got[2], ref_g[2], rtol=1e-3, atol=5e-4)
@@ -388,7 +390,7 @@ def test_bf16_pyramid_self_attention_takes_the_tiled_backward(msda, hip_lib):
     out = msda.ms_deform_attn_forward(*args, 64)
     assert hip_lib.last_kernel() == "msda_fwd_d32_gather<4,bf16>", hip_lib.last_kernel()
     gv, gl, ga = msda.ms_deform_attn_backward(*args, gob, 64)
-    assert hip_lib.last_kernel() == "msda_bwd_d32_tile_q2<2,bf16>", hip_lib.last_kernel()
+    assert hip_lib.last_kernel() == "msda_bwd_d32_tile_lv<2,bf16>", hip_lib.last_kernel()
     v32, go32 = vb.float().cpu().numpy(), gob.float().cpu().numpy()
     ref = oracle.forward(v32, g["shapes"], g["level_start"], g["loc"], g["attn"])
     rgv, rgl, rga = oracle.backward(v32, g["shapes"], g["level_start"], g["loc"], g["attn"], go32)

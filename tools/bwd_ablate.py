@@ -7,7 +7,7 @@ from memotr_amd import _lib
 from memotr_amd.synth import make_inputs
 x = make_inputs(dist="encoder_like", device="cuda")
 call = MsdaCall(x)
-for pts in (8, 9):
+for pts in (8, 10, 11):
     _lib.set_option("bwd_variant", pts)
     for ab in (0, 1, 2, 3, 4, 5, 6, 7):
         _lib.set_option("bwd_ablate", ab)

@@ -74,9 +74,10 @@ def main():
                            kernel=_lib.last_kernel())
             bwd_cfgs = [("v1 generic", dict(bwd_variant=1))]
             if enc:
-                for v in (8, 9):
+                for v in (8, 9, 10, 11):
                     for mg in ((2, 3, 4) if not args.quick else (3,)):
-                        bwd_cfgs.append((f"v{v} tile_q2 m{mg}", dict(bwd_variant=v, bwd_tile_margin=mg)))
+                        bwd_cfgs.append((f"v{v} {'tile_q2' if v < 10 else 'tile_lv'} m{mg}",
+                                         dict(bwd_variant=v, bwd_tile_margin=mg)))
             for name, opts in bwd_cfgs:
                 for c, tag in ((call, "bwd"), (fcall, "bwd_fused")):
                     reset()
