@@ -380,15 +380,25 @@ __device__ __forceinline__ void stage_records_fwd(u32x4 *rec, const PointSrc &sr
     const float *lg = nullptr;
     const long qrow = pmc / M;
     const int m = (int)(pmc - qrow * M);
+    float e0 = 0.f, e1 = 0.f;            // exp(logit - max) of this lane's first two points (all of them when LP <= 2 LANES)
+    const bool two = LP <= 2 * LANES;
     if (FUSED) {
         lg = fused_logits(src, qrow, m, LP);
-        row_softmax_stats<LANES>(lg, LP, sub, mx, sum);
+        if (two) {
+            const float l0 = sub < LP ? lg[sub] : -INFINITY, l1 = sub + LANES < LP ? lg[sub + LANES] : -INFINITY;
+            mx = row_max<LANES>(fmaxf(l0, l1));
+            e0 = expf(l0 - mx);
+            e1 = expf(l1 - mx);
+            sum = row_sum<LANES>(e0 + e1);
+        } else {
+            row_softmax_stats<LANES>(lg, LP, sub, mx, sum);
+        }
     }
     for (int t = sub; t < LP; t += LANES) {
         const int l = t / P;
         const int H = s_H[l], W = s_W[l];
         const f32x2 xy = point_location<FUSED>(src, pmc, qrow, m, L, P, t, l, H, W);
-        const float a_in = FUSED ? expf(lg[t] - mx) / sum : src.attn[pmc * LP + t];
+        const float a_in = FUSED ? (two ? (t == sub ? e0 : e1) : expf(lg[t] - mx)) / sum : src.attn[pmc * LP + t];
         Sample<float> s = sample_setup<float>(xy.x, xy.y, H, W);
         const bool live = s.gate && row_ok;
         // a gated-off point contributes nothing (the reference skips it): no NaN * 0 from non-finite locations
@@ -1438,10 +1448,11 @@ __global__ __launch_bounds__(kTileThreads, PTS <= 2 ? 4 : 2) void msda_bwd_d32_t
             if (ok[p] && sub < P) {
                 const unsigned u = __float_as_uint(pa[p]) & 0x7fffffffu;
                 amax = u > amax ? u : amax;
-                const Sample<float> s = sample_setup<float>(px_[p], py_[p], H, W);
-                if (s.gate) {
-                    sx += (float)s.w_low + s.lw;
-                    sy += (float)s.h_low + s.lh;
+                // (w_low + lw, h_low + lh) of sample_setup = the un-floored pixel position; same gate
+                const float w_im = px_[p] * (float)W - 0.5f, h_im = py_[p] * (float)H - 0.5f;
+                if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+                    sx += w_im;
+                    sy += h_im;
                     cnt += 1.f;
                 }
             }
@@ -1644,18 +1655,16 @@ __global__ __launch_bounds__(kTileThreads, PTS <= 2 ? 4 : 2) void msda_bwd_d32_t
             for (int i = sub; i < 2 * P; i += 8) {
                 const int t = i >> 1, comp = i & 1;
                 const float size = (float)(comp ? H : W);
-                const float gl = res[8 * t + 1 + comp] * size;
+                const float r_ = res[8 * t + 1 + comp];       // d/d(pixel position); grad_loc = r_ * size
                 if (FUSED) {
-                    float go;
-                    if (src.ref_dim == 2) {
-                        go = gl / size;
-                    } else {
+                    float go = r_;                            // 2-d: (r_ * size) / size
+                    if (src.ref_dim != 2) {
                         const float *rp = src.ref + (qrow * L + l) * 4;
-                        go = gl * (rp[2 + comp] * (0.5f / (float)P));
+                        go = (r_ * size) * (rp[2 + comp] * (0.5f / (float)P));
                     }
                     grad_proj[qrow * src.proj_stride + m * 2 * LP + l * P * 2 + i] = go;
                 } else {
-                    grad_loc[pm * LP * 2 + l * P * 2 + i] = gl;
+                    grad_loc[pm * LP * 2 + l * P * 2 + i] = r_ * size;
                 }
             }
             if (sub < P) {

@@ -93,6 +93,40 @@ def main():
                     record(op=tag, dist=dist, shape=sname, cfg=name, ms=ms, GBps=gbps, err=errs,
                            kernel=_lib.last_kernel())
             reset()
+    # bf16 storage (BASELINE config 5 extension): value / out / grad_out bf16, everything else fp32
+    for dist in args.dists.split(","):
+        x = make_inputs(dist=dist, device="cuda")
+        call = MsdaCall(x)
+        vb, gob = x["value"].bfloat16().contiguous(), x["grad_out"].bfloat16().contiguous()
+        outb = torch.empty(call.N, call.Lq, call.M * call.D, device="cuda", dtype=torch.bfloat16)
+        st = lambda: torch.cuda.current_stream().cuda_stream
+
+        def fwd16():
+            rc = _lib.lib.msda_forward_bf16(vb.data_ptr(), x["shapes"].data_ptr(), x["level_start"].data_ptr(),
+                                            x["loc"].data_ptr(), x["attn"].data_ptr(), call.N, call.S, call.M, call.D,
+                                            call.L, call.Lq, call.P, outb.data_ptr(), call.hptr, st())
+            assert rc == 0, _lib.last_error()
+
+        def bwd16():
+            rc = _lib.lib.msda_backward_bf16(vb.data_ptr(), x["shapes"].data_ptr(), x["level_start"].data_ptr(),
+                                             x["loc"].data_ptr(), x["attn"].data_ptr(), gob.data_ptr(), call.N, call.S,
+                                             call.M, call.D, call.L, call.Lq, call.P, call.gv.data_ptr(),
+                                             call.gl.data_ptr(), call.ga.data_ptr(), 1, call.hptr, st())
+            assert rc == 0, _lib.last_error()
+
+        reset()
+        call.fwd(); torch.cuda.synchronize()
+        fwd16(); torch.cuda.synchronize()
+        err = float((outb.float() - call.out).abs().max())
+        ms = time_kernel(fwd16, iters=50)
+        from memotr_amd.synth import algorithmic_bytes
+        by = algorithmic_bytes(call.N, call.S, call.Lq, call.M, call.D, call.L, call.P, 2)
+        record(op="fwd_bf16", dist=dist, shape="enc", cfg="default", ms=ms, GBps=by / (ms * 1e-3) / 1e9, err=err,
+               kernel=_lib.last_kernel())
+        ms = time_kernel(bwd16, iters=20)
+        by = algorithmic_bytes(call.N, call.S, call.Lq, call.M, call.D, call.L, call.P, 2, True)
+        record(op="bwd_bf16", dist=dist, shape="enc", cfg="default", ms=ms, GBps=by / (ms * 1e-3) / 1e9, err=0.0,
+               kernel=_lib.last_kernel())
     # memset + copy baselines for context (same bytes as value)
     v = torch.empty(22323 * 8 * 32, device="cuda")
     w = torch.empty_like(v)

@@ -18,7 +18,7 @@ root = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "msda" in r["Kernel_Name"]:
+        if "msda" in r["Kernel_Name"] and "jacobian" not in r["Kernel_Name"]:
             k = r["Kernel_Name"].split("::")[-1].split("(")[0]
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in agg.items():
