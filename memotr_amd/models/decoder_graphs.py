@@ -23,6 +23,7 @@ path -- same arithmetic, kernel by kernel.
 """
 from __future__ import annotations
 
+import contextlib
 import os
 from collections import OrderedDict
 
@@ -78,6 +79,26 @@ class DecoderLoop(nn.Module):
             outs.append(output)
             refs.append(reference_points)
         return torch.stack(outs), torch.stack(refs), torch.stack(layer_inputs), torch.stack(boxes)
+
+
+@contextlib.contextmanager
+def _thread_local_capture():
+    """``make_graphed_callables`` captures in the "global" error mode: ANY thread that touches the runtime while a
+    capture is open (the RCCL watchdog polling its events under DistributedDataParallel, a data-loader thread pinning
+    memory) invalidates it.  The decoder capture only needs the capturing threads themselves to behave, so the graph
+    context is switched to "thread_local" for its duration."""
+    orig = torch.cuda.graph
+
+    class _Graph(orig):
+        def __init__(self, *args, **kwargs):
+            kwargs.setdefault("capture_error_mode", "thread_local")
+            super().__init__(*args, **kwargs)
+
+    torch.cuda.graph = _Graph
+    try:
+        yield
+    finally:
+        torch.cuda.graph = orig
 
 
 def enabled() -> bool:
@@ -145,7 +166,8 @@ class DecoderGraphs:
         sample = tuple(a.detach().clone().requires_grad_(a.requires_grad) for a in args) + \
             tuple(p.detach().requires_grad_(p.requires_grad) for p in params)
         try:
-            fn = torch.cuda.make_graphed_callables(run, sample, num_warmup_iters=2, allow_unused_input=True)
+            with _thread_local_capture():
+                fn = torch.cuda.make_graphed_callables(run, sample, num_warmup_iters=2, allow_unused_input=True)
         except Exception as exc:  # noqa: BLE001 -- capture is an optimisation; eager stays valid
             import warnings
             warnings.warn(f"decoder graph capture failed ({type(exc).__name__}: {exc}); running eager")

@@ -92,8 +92,15 @@ def run_train(args, rank: int, world: int, clip_len: int = None, height: int = 8
     barrier()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    per_rank = [dt / args.steps * 1e3]
+    backend = None
     if world > 1:
+        # every rank's own step time (the reported number is the slowest rank's) and what the process group saw
+        every = [torch.zeros_like(t) for _ in range(world)]
+        torch.distributed.all_gather(every, t)
+        per_rank = [float(x.item()) / args.steps * 1e3 for x in every]
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        backend = f"{torch.distributed.get_backend()} world_size={torch.distributed.get_world_size()}"
     dt = float(t.item())
     if rank != 0:
         return None
@@ -109,4 +116,6 @@ def run_train(args, rank: int, world: int, clip_len: int = None, height: int = 8
                    "parallelism": f"dp{world}", "trainable_params": n_params, "tuned_gemms": n_tuned,
                    "frames_per_gpu_per_sec": clip_len * args.steps / dt, "final_loss": float(loss.detach())},
         "max_memory_MB": torch.cuda.max_memory_allocated() // (1024 ** 2),
+        "per_rank_ms_per_step": per_rank, "process_group": backend,
+        "decoder_graphs": getattr(getattr(getattr(model, "module", model).transformer.decoder, "graphs")(), "captures", 0),
     }

@@ -105,6 +105,40 @@ __global__ __launch_bounds__(256) void k_l1_rows(const float* buf, float* out, u
     if (acc.x + acc.y + acc.z + acc.w == 12345.f) out[0] = 1;
 }
 
+// "Ideal" forward of the encoder call (178,584 rows x 16 points x 4 corner rows of 128 B + 16 FMAs per lane and point):
+// the corner rows come from a 32 KB LDS pool (mode 0: no global traffic at all -- the LDS-side ceiling of any tiled
+// design) or from a 32 KB global slab that stays in the vector L1 (mode 1: the L1 request-rate ceiling with perfect
+// locality).  Row order is random per (row, point); no records, no index arithmetic, no output: only the gather + FMA.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_ideal_fwd(const float* buf, float* out, long n_tasks, unsigned bytes) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, sub = lane & 7;
+    for (int i = tid; i < 8192; i += 256) lds[i] = (float)i;           // 256 rows of 128 B
+    __syncthreads();
+    const f4* lds4 = reinterpret_cast<const f4*>(lds);
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)buf, 0, (int)bytes, 0x00020000);
+    const long wave = ((long)blockIdx.x * 256 + tid) >> 6, n_waves = ((long)gridDim.x * 256) >> 6;
+    f4 total = {0, 0, 0, 0};
+    for (long task = wave; task < n_tasks; task += n_waves) {
+        unsigned x = (unsigned)(task * 8 + (lane >> 3)) * 2654435761u;     // same for the 8 lanes of a row
+        f4 acc = {0, 0, 0, 0};
+        for (int t = 0; t < 16; t += 4) {
+            f4 v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                x = x * 1664525u + 1013904223u;
+                const unsigned row = (x >> 8) & 255;
+                v[j] = MODE == 0 ? lds4[row * 8 + sub]
+                                 : __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, row * 128 + sub * 16, 0, 0));
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc += 0.25f * v[j];
+        }
+        total += acc;
+    }
+    if (total.x + total.y + total.z + total.w == 12345.f) out[0] = 1;
+}
+
 template <typename F>
 float time_ms(F f, int reps = 5) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -156,5 +190,14 @@ int main() {
             double bytes = (double)blocks * 256 * iters * 16;
             printf("row gather over %8u rows (%7.1f KB) local=%d: %.3f ms  %.2f TB/s  (%.1f B/clk/CU)\n", rows, rows * 128 / 1024.0, local, ms, bytes / ms / 1e9, bytes / ms / 1e6 / 256 / 2.4);
         }
+    printf("== ideal encoder-call forward: 22323 tasks x 8 rows x 16 points x 4 corner rows + FMAs ==\n");
+    for (int mode = 0; mode < 2; ++mode) {
+        const long n_tasks = 22323;
+        float ms = mode == 0 ? time_ms([&] { hipLaunchKernelGGL(k_ideal_fwd<0>, dim3(256 * 8), dim3(256), 32768, 0, buf, out, n_tasks, (unsigned)((size_t)n_rows * 128)); }, 20)
+                             : time_ms([&] { hipLaunchKernelGGL(k_ideal_fwd<1>, dim3(256 * 8), dim3(256), 32768, 0, buf, out, n_tasks, (unsigned)((size_t)n_rows * 128)); }, 20);
+        double bytes = (double)n_tasks * 8 * 16 * 4 * 128;
+        printf("ideal forward, corner rows from %s: %.1f us  (%.2f TB/s of row reads, %.1f B/clk/CU; 80.0 MB algorithmic -> %.1f %% of 8 TB/s)\n",
+               mode == 0 ? "LDS      " : "L1 (32 KB)", ms * 1e3, bytes / ms / 1e9, bytes / ms / 1e6 / 256 / 2.4, 80.0057 / ms / 8.0 * 100 / 1e3 * 1e3 / 1e3);
+    }
     return 0;
 }
