@@ -782,11 +782,17 @@ __device__ __forceinline__ void hybrid_lds_chunk(const u32x4 *rec, int t0, unsig
     }
 }
 
+// Round-2 structure (the one that fixed the backward, section 4.2 of DESIGN.md): every global input of the
+// workgroup -- the locations / weights (or offsets, logits, reference points) of all its rows -- is loaded ONCE, up
+// front, for the three 32-row passes and kept in registers (2 points per lane and pass: L*P <= 16); the window
+// placement is computed from those registers, the windows are filled, and the passes then stage their records from
+// registers: 5 dependent global round trips per workgroup instead of 13.
 template <int PTS, bool FUSED>
-__global__ __launch_bounds__(kTileThreads) void msda_fwd_d32_hybrid(
+__global__ __launch_bounds__(kTileThreads, 4) void msda_fwd_d32_hybrid(
     const float *__restrict__ value, const int64_t *__restrict__ lstart, const PointSrc src,
     float *__restrict__ out, const TilePlan pl) {
     constexpr int D = 32;
+    constexpr int NP = (kTileMaxRows + 31) / 32;
     __shared__ TileTables tb;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     int b, ry, rx, m;
@@ -795,19 +801,101 @@ __global__ __launch_bounds__(kTileThreads) void msda_fwd_d32_hybrid(
     if (!live) return;
     tile_load_tables(tb, pl, lstart);
     __syncthreads();
-    tile_place_windows<FUSED>(tb, pl, src, b, ry, rx, m);
 
     const int L = pl.L, P = pl.P, LP = L * P, l0 = pl.l0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane >> 3, sub = lane & 7;
     const __amdgpu_buffer_rsrc_t vr = make_rsrc(value, pl.value_bytes);
+
+    // ---- phase A: all locations / weights of the workgroup's rows, once ----
+    bool ok[NP];
+    long pmr[NP];
+    float lx[NP][2], ly[NP][2], la[NP][2];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const TileRow row = tile_row(tb, L, pl.rows, p * 32 + wave * 8 + grp, b, ry, rx, m, pl.M, pl.Lq);
+        ok[p] = row.ok;
+        pmr[p] = row.pm;
+        const long qrow = (long)b * pl.Lq + row.q;
+        float mx = 0.f, sum = 1.f, e[2] = {0.f, 0.f};
+        if (FUSED) {     // softmax of the row's (<= 16) logits: two per lane, DPP reductions over the row's 8 lanes
+            const float *lg = fused_logits(src, qrow, m, LP);
+            const float g0 = sub < LP ? lg[sub] : -INFINITY, g1 = sub + 8 < LP ? lg[sub + 8] : -INFINITY;
+            mx = row_max<8>(fmaxf(g0, g1));
+            e[0] = expf(g0 - mx);
+            e[1] = expf(g1 - mx);
+            sum = row_sum<8>(e[0] + e[1]);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int t = sub + 8 * j;
+            lx[p][j] = ly[p][j] = la[p][j] = 0.f;
+            if (row.ok && t < LP) {
+                const int l = t / P;
+                const f32x2 xy = point_location<FUSED>(src, row.pm, qrow, m, L, P, t, l, tb.H[l], tb.W[l]);
+                lx[p][j] = xy.x;
+                ly[p][j] = xy.y;
+                la[p][j] = FUSED ? e[j] / sum : src.attn[row.pm * LP + t];
+            }
+        }
+    }
+
+    // ---- phase B: mean sampling position of every windowed level, from registers ----
+    {
+        float sx[kTileMaxL] = {0.f, 0.f, 0.f, 0.f}, sy[kTileMaxL] = {0.f, 0.f, 0.f, 0.f}, sc[kTileMaxL] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int t = sub + 8 * j;
+                if (ok[p] && t < LP) {
+                    const int l = t / P;
+                    const float Hf = (float)tb.H[l], Wf = (float)tb.W[l];
+                    const float w_im = lx[p][j] * Wf - 0.5f, h_im = ly[p][j] * Hf - 0.5f;
+                    const bool gate = h_im > -1.f && w_im > -1.f && h_im < Hf && w_im < Wf;
+#pragma unroll
+                    for (int k = 0; k < kTileMaxL; ++k)
+                        if (gate && k == l) { sx[k] += w_im; sy[k] += h_im; sc[k] += 1.f; }
+                }
+            }
+        for (int l = l0; l < L; ++l) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < kTileMaxL; ++k)
+                if (k == l) { a0 = sx[k]; a1 = sy[k]; a2 = sc[k]; }
+            a0 = wave_sum(a0);
+            a1 = wave_sum(a1);
+            a2 = wave_sum(a2);
+            if (lane == 0) {
+                atomicAdd(&tb.sum[l][0], a0);
+                atomicAdd(&tb.sum[l][1], a1);
+                atomicAdd(&tb.sum[l][2], a2);
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x >= l0 && threadIdx.x < L) {
+        const int l = threadIdx.x, win = tb.win[l], sh = tb.shift[l];
+        const float cnt = tb.sum[l][2];
+        const float cx = cnt > 0.f ? tb.sum[l][0] / cnt : (float)((rx << sh) + (1 << sh) / 2);
+        const float cy = cnt > 0.f ? tb.sum[l][1] / cnt : (float)((ry << sh) + (1 << sh) / 2);
+        int ox = (int)floorf(cx - 0.5f * (float)(win - 1) + 0.5f);
+        int oy = (int)floorf(cy - 0.5f * (float)(win - 1) + 0.5f);
+        const int max_x = tb.W[l] - win, max_y = tb.H[l] - win;
+        ox = ox > max_x ? max_x : ox;
+        oy = oy > max_y ? max_y : oy;
+        tb.ox[l] = ox < 0 ? 0 : ox;
+        tb.oy[l] = oy < 0 ? 0 : oy;
+    }
+    __syncthreads();
+
     f32x4 *win_f4 = reinterpret_cast<f32x4 *>(s_dyn);
     const int win_px = tb.base[kTileMaxL];
     const unsigned zero_row = (unsigned)win_px * 128u;   // one all-zero pixel row after the windows
     const int rec_stride = LP + 1;                       // 16-byte units; +1 staggers the 8 rows over the banks
     u32x4 *rec = reinterpret_cast<u32x4 *>(s_dyn + (size_t)(win_px + 1) * 128) + (size_t)(wave * 8 + grp) * rec_stride;
 
-    // ---- fill the windows (coalesced 128-byte rows; out-of-level cells read as zero) ----
+    // ---- fill the windows (coalesced 128-byte rows; out-of-level / padded cells read as zero) ----
     if (threadIdx.x < 8) win_f4[win_px * 8 + threadIdx.x] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int l = l0; l < L; ++l) {
         const int win = tb.win[l], magic = tb.magic[l], base = tb.base[l];
@@ -820,50 +908,47 @@ __global__ __launch_bounds__(kTileThreads) void msda_fwd_d32_hybrid(
             const int wy = (pix * magic) >> 16, wx = pix - wy * win;
             const int gy = oy + wy, gx = ox + wx;
             bool inside = gy < H && gx < W;
-            if (mk != nullptr && inside) inside = !mk[gy * W + gx];       // padded pixels read as zero
+            if (mk != nullptr && inside) inside = !mk[gy * W + gx];
             const unsigned off = inside ? tile_pixel_off(tb, pl, b, l, gy, gx, m) + (unsigned)s8 * 16u : kOobOffset;
             win_f4[(base + pix) * 8 + s8] = buf_load_f4(vr, off);
         }
     }
     __syncthreads();
 
+    // ---- phase C: the passes; records come from registers ----
     const unsigned lane_off = (unsigned)sub * 16u;
     const unsigned ps = (unsigned)pl.M * 128u;
-    for (int r0 = 0; r0 < pl.rows; r0 += 32) {
-        const TileRow row = tile_row(tb, L, pl.rows, r0 + wave * 8 + grp, b, ry, rx, m, pl.M, pl.Lq);
-        const long qrow = (long)b * pl.Lq + row.q;
-        float mx = 0.f, sum = 1.f;
-        const float *lg = nullptr;
-        if (FUSED) {
-            lg = fused_logits(src, qrow, m, LP);
-            row_softmax_stats<8>(lg, LP, sub, mx, sum);
-        }
-        for (int t = sub; t < LP; t += 8) {
-            const int l = t / P;
-            const int H = tb.H[l], W = tb.W[l];
-            const f32x2 xy = point_location<FUSED>(src, row.pm, qrow, m, L, P, t, l, H, W);
-            const float a_in = FUSED ? expf(lg[t] - mx) / sum : src.attn[row.pm * LP + t];
-            Sample<float> s = sample_setup<float>(xy.x, xy.y, H, W);
-            const float a = (s.gate && row.ok) ? a_in : 0.f;   // gated-off points contribute nothing (no NaN * 0)
-            if (!s.gate) s.lh = s.lw = 0.f;
-            const Corners c = tile_corners<FUSED>(s, row.ok, H, W, src, (long)b * pl.S + tb.lstart[l]);
-            const unsigned valid = (unsigned)c.v00 | ((unsigned)c.v01 << 1) | ((unsigned)c.v10 << 2) | ((unsigned)c.v11 << 3);
-            unsigned word0 = tile_pixel_off(tb, pl, b, l, s.h_low, s.w_low, m) | valid;
-            if (l >= l0) {
-                const int win = tb.win[l];
-                const int wy0 = s.h_low - tb.oy[l], wx0 = s.w_low - tb.ox[l];
-                const bool iy0 = (unsigned)wy0 < (unsigned)win, iy1 = (unsigned)(wy0 + 1) < (unsigned)win;
-                const bool ix0 = (unsigned)wx0 < (unsigned)win, ix1 = (unsigned)(wx0 + 1) < (unsigned)win;
-                const bool all_in = (!c.v00 || (iy0 && ix0)) && (!c.v01 || (iy0 && ix1)) &&
-                                    (!c.v10 || (iy1 && ix0)) && (!c.v11 || (iy1 && ix1));
-                if (all_in) word0 = ((unsigned)(tb.base[l] + wy0 * win + wx0) * 128u) | valid | kRecLds;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        if (p * 32 >= pl.rows) break;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int t = sub + 8 * j;
+            if (t < LP) {
+                const int l = t / P;
+                const int H = tb.H[l], W = tb.W[l];
+                Sample<float> s = sample_setup<float>(lx[p][j], ly[p][j], H, W);
+                const float a = (s.gate && ok[p]) ? la[p][j] : 0.f;   // gated-off points contribute nothing
+                if (!s.gate) s.lh = s.lw = 0.f;
+                const Corners c = tile_corners<FUSED>(s, ok[p], H, W, src, (long)b * pl.S + tb.lstart[l]);
+                const unsigned valid = (unsigned)c.v00 | ((unsigned)c.v01 << 1) | ((unsigned)c.v10 << 2) | ((unsigned)c.v11 << 3);
+                unsigned word0 = tile_pixel_off(tb, pl, b, l, s.h_low, s.w_low, m) | valid;
+                if (l >= l0) {
+                    const int win = tb.win[l];
+                    const int wy0 = s.h_low - tb.oy[l], wx0 = s.w_low - tb.ox[l];
+                    const bool iy0 = (unsigned)wy0 < (unsigned)win, iy1 = (unsigned)(wy0 + 1) < (unsigned)win;
+                    const bool ix0 = (unsigned)wx0 < (unsigned)win, ix1 = (unsigned)(wx0 + 1) < (unsigned)win;
+                    const bool all_in = (!c.v00 || (iy0 && ix0)) && (!c.v01 || (iy0 && ix1)) &&
+                                        (!c.v10 || (iy1 && ix0)) && (!c.v11 || (iy1 && ix1));
+                    if (all_in) word0 = ((unsigned)(tb.base[l] + wy0 * win + wx0) * 128u) | valid | kRecLds;
+                }
+                u32x4 r;
+                r.x = word0;
+                r.y = __float_as_uint(s.lh);
+                r.z = __float_as_uint(s.lw);
+                r.w = __float_as_uint(a);
+                rec[t] = r;
             }
-            u32x4 r;
-            r.x = word0;
-            r.y = __float_as_uint(s.lh);
-            r.z = __float_as_uint(s.lw);
-            r.w = __float_as_uint(a);
-            rec[t] = r;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -871,20 +956,20 @@ __global__ __launch_bounds__(kTileThreads) void msda_fwd_d32_hybrid(
         // ---- levels read through the vector L1 ----
         for (int l = 0; l < l0; ++l) {
             const unsigned wps = (unsigned)__builtin_amdgcn_readfirstlane(tb.W[l]) * ps;
-            int p = 0;
-            for (; p + PTS <= P; p += PTS) hybrid_global_chunk<PTS>(rec, l * P + p, ps, wps, vr, lane_off, acc);
-            for (; p < P; ++p) hybrid_global_chunk<1>(rec, l * P + p, ps, wps, vr, lane_off, acc);
+            int q = 0;
+            for (; q + PTS <= P; q += PTS) hybrid_global_chunk<PTS>(rec, l * P + q, ps, wps, vr, lane_off, acc);
+            for (; q < P; ++q) hybrid_global_chunk<1>(rec, l * P + q, ps, wps, vr, lane_off, acc);
         }
         // ---- levels read from the LDS windows ----
         for (int l = l0; l < L; ++l) {
             const unsigned wrow = (unsigned)__builtin_amdgcn_readfirstlane(tb.win[l]) * 128u;
             const unsigned wps = (unsigned)__builtin_amdgcn_readfirstlane(tb.W[l]) * ps;
-            int p = 0;
-            for (; p + PTS <= P; p += PTS)
-                hybrid_lds_chunk<PTS>(rec, l * P + p, wrow, ps, wps, zero_row, vr, lane_off, s_dyn, acc);
-            for (; p < P; ++p) hybrid_lds_chunk<1>(rec, l * P + p, wrow, ps, wps, zero_row, vr, lane_off, s_dyn, acc);
+            int q = 0;
+            for (; q + PTS <= P; q += PTS)
+                hybrid_lds_chunk<PTS>(rec, l * P + q, wrow, ps, wps, zero_row, vr, lane_off, s_dyn, acc);
+            for (; q < P; ++q) hybrid_lds_chunk<1>(rec, l * P + q, wrow, ps, wps, zero_row, vr, lane_off, s_dyn, acc);
         }
-        if (row.ok) *reinterpret_cast<f32x4 *>(out + row.pm * D + sub * 4) = acc;
+        if (ok[p]) *reinterpret_cast<f32x4 *>(out + pmr[p] * D + sub * 4) = acc;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
@@ -1910,7 +1995,8 @@ int forward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart, 
                 TilePlan pl;
                 size_t lds = 0;
                 const size_t rec_bytes = (size_t)32 * (L * P + 1) * 16;
-                if (make_tile_plan(pl, shapes_host, N, S, M, D, L, Lq, P, value_bytes, opt_fwd_tile_margin.load(),
+                if (L * P <= 16 &&
+                    make_tile_plan(pl, shapes_host, N, S, M, D, L, Lq, P, value_bytes, opt_fwd_tile_margin.load(),
                                    opt_fwd_tile_l0.load(), 1, rec_bytes, lds)) {
                     const int grid = (pl.n_blocks + 7) & ~7;
 #define MSDA_LAUNCH_HY(PTS, FU, NAME)                                                                                \

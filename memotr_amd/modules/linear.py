@@ -67,16 +67,30 @@ def _pick_chunks(rows: int) -> int:
     return TARGET_CHUNKS
 
 
+# bias + ReLU in the GEMM epilogue (hipBLASLt RELU_BIAS) for the encoder FFN's first linear: the activation is 8x the
+# model width, and a separate in-place ReLU re-reads and re-writes it (22,323 x 2048 x frames floats per layer).
+FUSE_RELU_EPILOGUE = os.environ.get("MEMOTR_FUSE_RELU", "1") != "0"
+
+
 class _SplitKLinear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias):
-        ctx.save_for_backward(x, weight)
+    def forward(ctx, x, weight, bias, relu=False):
         ctx.has_bias = bias is not None
+        ctx.relu = bool(relu)
+        if ctx.relu:
+            y = torch._addmm_activation(bias, x, weight.t(), use_gelu=False)      # relu(x W^T + b), one kernel
+            ctx.save_for_backward(x, weight, y)
+            return y
+        ctx.save_for_backward(x, weight)
         return F.linear(x, weight, bias)
 
     @staticmethod
     def backward(ctx, grad_out):
-        x, weight = ctx.saved_tensors
+        if ctx.relu:
+            x, weight, y = ctx.saved_tensors
+            grad_out = torch.ops.aten.threshold_backward(grad_out, y, 0.0)         # the ReLU mask, one pass
+        else:
+            x, weight = ctx.saved_tensors
         gx = gw = gb = None
         K, N = weight.shape[1], weight.shape[0]
         g2 = grad_out.reshape(-1, N)
@@ -99,7 +113,7 @@ class _SplitKLinear(torch.autograd.Function):
             gw = gw.to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = g2.sum(0).to(weight.dtype)
-        return gx, gw, gb
+        return gx, gw, gb, None
 
 
 def long_linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor = None, min_rows: int = None,
@@ -113,8 +127,10 @@ def long_linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor = None
             and x.dtype == weight.dtype and not torch.is_autocast_enabled()):   # mixed precision keeps the library path
         # 2-d in, 2-d out: the Function's output is then a fresh tensor (an N-d F.linear returns a view, and a
         # view made inside a custom Function may not be modified in place -- the FFN applies ReLU in place)
-        y = _SplitKLinear.apply(x.reshape(rows, x.shape[-1]), weight, bias)
-        if activation is not None:
+        fuse = (FUSE_RELU_EPILOGUE and isinstance(activation, torch.nn.ReLU) and bias is not None and x.is_cuda
+                and x.dtype == torch.float32)
+        y = _SplitKLinear.apply(x.reshape(rows, x.shape[-1]), weight, bias, fuse)
+        if activation is not None and not fuse:
             y = activation(y)
         return y.view(*x.shape[:-1], weight.shape[0])
     y = F.linear(x, weight, bias)

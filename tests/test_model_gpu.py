@@ -268,3 +268,25 @@ def test_d32_model_with_checkpointing_equals_plain_step(hip_lib):
         assert g0.keys() == g1.keys()
         for n in g0:
             assert float((g1[n] - g0[n]).norm()) / (float(g0[n].norm()) + 1e-6) < 2e-3, (level, n)
+
+
+def test_fused_bias_relu_epilogue_is_bit_identical():
+    """long_linear(..., activation=ReLU) with the ReLU in the GEMM epilogue (encoder FFN) vs linear + in-place ReLU:
+    same bits forward, same gradients."""
+    import memotr_amd.modules.linear as lin
+    torch.manual_seed(0)
+    x = torch.randn(9000, 256, device="cuda", requires_grad=True)
+    w = (torch.randn(512, 256, device="cuda") * 0.05).requires_grad_(True)
+    b = torch.randn(512, device="cuda", requires_grad=True)
+    seed = torch.randn(9000, 512, device="cuda")
+    res = []
+    for flag in (True, False):
+        lin.FUSE_RELU_EPILOGUE = flag
+        try:
+            y = lin.long_linear(x, w, b, activation=torch.nn.ReLU(True))
+            res.append((y.detach().clone(),) + torch.autograd.grad(y, (x, w, b), seed))
+        finally:
+            lin.FUSE_RELU_EPILOGUE = True
+    assert torch.equal(res[0][0], res[1][0]) and float(res[0][0].min()) == 0.0
+    for a, c in zip(res[0][1:], res[1][1:]):
+        torch.testing.assert_close(a, c, rtol=1e-5, atol=1e-5)
