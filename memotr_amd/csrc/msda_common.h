@@ -105,11 +105,14 @@ struct PointSrc {
 // operation order: 2-d  ref + off / (W, H)              (ms_deform_attn.py:114-117)
 //                  4-d  ref_xy + off / P * ref_wh * 0.5 (:118-120)
 // Every step is an IEEE float32 operation (no contraction), i.e. the bits torch computes.
-__device__ __forceinline__ f32x2 fused_location(const PointSrc &s, long qrow, int m, int L, int P, int t, int l,
+// IDX is the integer type of the row arithmetic: `long` in general, `unsigned` in kernels whose launch envelope
+// (check_dims: every tensor < 2^31 elements, so qrow * proj_stride < 1.5 * 2^31) lets them index in 32 bits.
+template <typename IDX>
+__device__ __forceinline__ f32x2 fused_location(const PointSrc &s, IDX qrow, int m, int L, int P, int t, int l,
                                                 int H, int W) {
 #pragma clang fp contract(off)
-    const float *off = s.proj + qrow * s.proj_stride + ((long)m * (L * P) + t) * 2;
-    const float *r = s.ref + (qrow * L + l) * s.ref_dim;
+    const float *off = s.proj + (qrow * (IDX)s.proj_stride + (IDX)((m * (L * P) + t) * 2));
+    const float *r = s.ref + (qrow * (IDX)L + (IDX)l) * (IDX)s.ref_dim;
     const float ox = off[0], oy = off[1];
     f32x2 xy;
     if (s.ref_dim == 2) {
@@ -126,16 +129,17 @@ __device__ __forceinline__ f32x2 fused_location(const PointSrc &s, long qrow, in
     return xy;
 }
 
-__device__ __forceinline__ const float *fused_logits(const PointSrc &s, long qrow, int m, int LP) {
-    return s.proj + qrow * s.proj_stride + s.n_off + (long)m * LP;
+template <typename IDX>
+__device__ __forceinline__ const float *fused_logits(const PointSrc &s, IDX qrow, int m, int LP) {
+    return s.proj + (qrow * (IDX)s.proj_stride + (IDX)(s.n_off + m * LP));
 }
 
 // (x, y) of point t of row pm = qrow*M + m (qrow = b*Lq + q) from either source
-template <bool FUSED>
-__device__ __forceinline__ f32x2 point_location(const PointSrc &s, long pm, long qrow, int m, int L, int P, int t,
+template <bool FUSED, typename IDX>
+__device__ __forceinline__ f32x2 point_location(const PointSrc &s, IDX pm, IDX qrow, int m, int L, int P, int t,
                                                 int l, int H, int W) {
-    if (FUSED) return fused_location(s, qrow, m, L, P, t, l, H, W);
-    return *reinterpret_cast<const f32x2 *>(s.loc + (pm * (L * P) + t) * 2);
+    if (FUSED) return fused_location<IDX>(s, qrow, m, L, P, t, l, H, W);
+    return *reinterpret_cast<const f32x2 *>(s.loc + (pm * (IDX)(L * P) + (IDX)t) * 2);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -206,17 +210,19 @@ __device__ __forceinline__ T wave_sum(T x) {
     return x;
 }
 
-// softmax statistics (max, 1/sum handled by the caller as a division) of the row's LP logits, computed by the
-// LANES lanes that own the row: lane `sub` takes logits sub, sub+LANES, ...
+// softmax statistics (max, 1/sum) of the row's LP logits, computed by the LANES lanes that own the row: lane `sub`
+// takes logits sub, sub+LANES, ...  Every kernel forms a weight as exp(logit - max) * (1/sum): one IEEE division
+// per row instead of one per point (<= 1 ulp from the quotient; the same bits in forward, backward and
+// msda_fused_points).
 template <int LANES>
-__device__ __forceinline__ void row_softmax_stats(const float *logits, int LP, int sub, float &mx, float &sum) {
+__device__ __forceinline__ void row_softmax_stats(const float *logits, int LP, int sub, float &mx, float &rsum) {
     float m = -INFINITY;
     for (int t = sub; t < LP; t += LANES) m = fmaxf(m, logits[t]);
     m = row_max<LANES>(m);
     float s = 0.f;
     for (int t = sub; t < LP; t += LANES) s += expf(logits[t] - m);
     mx = m;
-    sum = row_sum<LANES>(s);
+    rsum = 1.f / row_sum<LANES>(s);
 }
 
 // XCD-aware task walk: hardware places block b on XCD b % 8 (observed; speed only).  Give each

@@ -70,14 +70,15 @@ __global__ __launch_bounds__(256) void msda_fwd_generic(
         const long b = pm / M / Lq;
         const TC *lp = loc + pm * LP * 2;
         const TC *ap = attn + pm * LP;
-        TC mx = 0, sum = 1;
+        TC mx = 0, rsum = 1;
         const float *lg = nullptr;
         if constexpr (FUSED) {
             lg = fused_logits(fs, pm / M, m, LP);
             mx = lg[0];
             for (int t = 1; t < LP; ++t) mx = fmaxf(mx, lg[t]);
-            sum = 0;
+            TC sum = 0;
             for (int t = 0; t < LP; ++t) sum += t_exp(lg[t] - mx);
+            rsum = (TC)1 / sum;
         }
         TC acc = (TC)0;
         for (int l = 0; l < L; ++l) {
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(256) void msda_fwd_generic(
                     const f32x2 xy = fused_location(fs, pm / M, m, L, P, t, l, H, W);
                     lx = xy.x;
                     ly = xy.y;
-                    a = t_exp(lg[t] - mx) / sum;
+                    a = t_exp(lg[t] - mx) * rsum;
                 } else {
                     lx = lp[0];
                     ly = lp[1];
@@ -142,14 +143,15 @@ __global__ __launch_bounds__(1024) void msda_bwd_generic(
         const int m = (int)(pm % M);
         const long b = pm / M / Lq;
         const TV *g = grad_out + pm * D;
-        TC mx = 0, sum = 1;
+        TC mx = 0, rsum = 1;
         const float *lg = nullptr;
         if constexpr (FUSED) {
             lg = fused_logits(fs, pm / M, m, LP);
             mx = lg[0];
             for (int t = 1; t < LP; ++t) mx = fmaxf(mx, lg[t]);
-            sum = 0;
+            TC sum = 0;
             for (int t = 0; t < LP; ++t) sum += t_exp(lg[t] - mx);
+            rsum = (TC)1 / sum;
         }
         for (int l = 0; l < L; ++l) {
             const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(1024) void msda_bwd_generic(
                     const f32x2 xy = fused_location(fs, pm / M, m, L, P, tt, l, H, W);
                     lx = xy.x;
                     ly = xy.y;
-                    a = t_exp(lg[tt] - mx) / sum;
+                    a = t_exp(lg[tt] - mx) * rsum;
                 } else {
                     lx = loc[2 * t];
                     ly = loc[2 * t + 1];
@@ -241,8 +243,8 @@ __global__ __launch_bounds__(1024) void msda_bwd_generic(
             float *gp = grad_proj + qrow * fs.proj_stride;
             if (tid < LP) {
                 float dot = 0.f;
-                for (int j = 0; j < LP; ++j) dot += (expf(lg[j] - mx) / sum) * s_res[2 * LP + j];
-                const float a_t = expf(lg[tid] - mx) / sum;
+                for (int j = 0; j < LP; ++j) dot += (expf(lg[j] - mx) * rsum) * s_res[2 * LP + j];
+                const float a_t = expf(lg[tid] - mx) * rsum;
                 gp[fs.n_off + m * LP + tid] = a_t * (s_res[2 * LP + tid] - dot);
                 const int l = tid / P;
                 const float *r = fs.ref + (qrow * L + l) * fs.ref_dim;
@@ -306,15 +308,15 @@ __global__ __launch_bounds__(256) void msda_fused_points_kernel(const int64_t *_
         const long pm = ok ? pm0 : n_rows - 1;
         const int m = (int)(pm % M);
         const float *lg = fused_logits(fs, pm / M, m, LP);
-        float mx, sum;
-        row_softmax_stats<8>(lg, LP, sub, mx, sum);
+        float mx, rsum;
+        row_softmax_stats<8>(lg, LP, sub, mx, rsum);
         for (int t = sub; t < LP; t += 8) {
             const int l = t / P;
             const f32x2 xy = fused_location(fs, pm / M, m, L, P, t, l, (int)shapes[2 * l], (int)shapes[2 * l + 1]);
             if (ok) {
                 loc_out[(pm * LP + t) * 2] = xy.x;
                 loc_out[(pm * LP + t) * 2 + 1] = xy.y;
-                attn_out[pm * LP + t] = expf(lg[t] - mx) / sum;
+                attn_out[pm * LP + t] = expf(lg[t] - mx) * rsum;
             }
         }
     }
@@ -370,16 +372,15 @@ __device__ __forceinline__ void store_row16<bf16_t>(bf16_t *dst, const float *ac
 // 4 corner byte offsets (kOobOffset when the corner is outside the level, masked, or the point is gated off) +
 // the 4 bilinear corner weights pre-multiplied by the attention weight.
 template <typename TV, bool FUSED>
-__device__ __forceinline__ void stage_records_fwd(u32x4 *rec, const PointSrc &src, long pmc, bool row_ok, int sub,
-                                                  int L, int P, int M, int S, int b, unsigned row_base,
-                                                  const int *s_H, const int *s_W, const int *s_start) {
+__device__ __forceinline__ void stage_records_fwd(u32x4 *rec, const PointSrc &src, unsigned pmc, unsigned qrow, int m,
+                                                  bool row_ok, int sub, int L, int P, int M, int S, int b,
+                                                  unsigned row_base, const int *s_H, const int *s_W,
+                                                  const int *s_start) {
     constexpr int LANES = RowGeom<TV>::kLanes;
     constexpr unsigned ROWB = RowGeom<TV>::kRowBytes;
     const int LP = L * P;
-    float mx = 0.f, sum = 1.f;
+    float mx = 0.f, rsum = 1.f;
     const float *lg = nullptr;
-    const long qrow = pmc / M;
-    const int m = (int)(pmc - qrow * M);
     float e0 = 0.f, e1 = 0.f;            // exp(logit - max) of this lane's first two points (all of them when LP <= 2 LANES)
     const bool two = LP <= 2 * LANES;
     if (FUSED) {
@@ -389,16 +390,18 @@ __device__ __forceinline__ void stage_records_fwd(u32x4 *rec, const PointSrc &sr
             mx = row_max<LANES>(fmaxf(l0, l1));
             e0 = expf(l0 - mx);
             e1 = expf(l1 - mx);
-            sum = row_sum<LANES>(e0 + e1);
+            rsum = 1.f / row_sum<LANES>(e0 + e1);
         } else {
-            row_softmax_stats<LANES>(lg, LP, sub, mx, sum);
+            row_softmax_stats<LANES>(lg, LP, sub, mx, rsum);
         }
     }
+    const float rcp_p = 1.f / (float)P;
     for (int t = sub; t < LP; t += LANES) {
-        const int l = t / P;
+        const int l = (int)(((float)t + 0.5f) * rcp_p);      // == t / P (the product stays 0.5/P away from integers)
         const int H = s_H[l], W = s_W[l];
         const f32x2 xy = point_location<FUSED>(src, pmc, qrow, m, L, P, t, l, H, W);
-        const float a_in = FUSED ? (two ? (t == sub ? e0 : e1) : expf(lg[t] - mx)) / sum : src.attn[pmc * LP + t];
+        const float a_in = FUSED ? (two ? (t == sub ? e0 : e1) : expf(lg[t] - mx)) * rsum
+                                 : src.attn[pmc * (unsigned)LP + (unsigned)t];
         Sample<float> s = sample_setup<float>(xy.x, xy.y, H, W);
         const bool live = s.gate && row_ok;
         // a gated-off point contributes nothing (the reference skips it): no NaN * 0 from non-finite locations
@@ -410,7 +413,7 @@ __device__ __forceinline__ void stage_records_fwd(u32x4 *rec, const PointSrc &sr
         const bool okw0 = w0 >= 0, okw1 = w1 <= W - 1;
         bool ok00 = okh0 && okw0, ok01 = okh0 && okw1, ok10 = okh1 && okw0, ok11 = okh1 && okw1;
         if (FUSED && src.mask != nullptr) {
-            const unsigned char *mk = src.mask + (long)b * S + s_start[l];
+            const unsigned char *mk = src.mask + ((unsigned)b * (unsigned)S + (unsigned)s_start[l]);
             const int p00 = h0 * W + w0;
             ok00 = ok00 && !mk[ok00 ? p00 : 0];
             ok01 = ok01 && !mk[ok01 ? p00 + 1 : 0];
@@ -484,19 +487,21 @@ __global__ __launch_bounds__(256) void msda_fwd_d32_gather(
     const int grp = lane / LANES, sub = lane % LANES;
     const int rec_stride = 2 * LP + 1;  // in 16-byte units; +1 staggers the rows over LDS banks
     u32x4 *rec = reinterpret_cast<u32x4 *>(s_dyn) + (size_t)(wave * ROWS + grp) * rec_stride;
-    const long n_rows = (long)N * Lq * M;
-    const long n_tasks = (n_rows + ROWS - 1) / ROWS;
+    // 32-bit row arithmetic: the launch envelope (check_dims) keeps every element index below 2^31
+    const unsigned n_rows = (unsigned)N * (unsigned)Lq * (unsigned)M;
+    const unsigned n_tasks = (n_rows + ROWS - 1) / ROWS;
     const __amdgpu_buffer_rsrc_t vr = make_rsrc(value, value_bytes);
     const unsigned lane_off = (unsigned)sub * 16u;
     const TaskWalk tw = xcd_walk(n_tasks, wpb);
     for (long task = tw.begin; task < tw.end; task += tw.step) {
-        const long pm = task * ROWS + grp;
+        const unsigned pm = (unsigned)task * ROWS + grp;
         const bool row_ok = pm < n_rows;
-        const long pmc = row_ok ? pm : n_rows - 1;
-        const int m = (int)(pmc % M);
-        const int b = (int)(pmc / M / Lq);
+        const unsigned pmc = row_ok ? pm : n_rows - 1;
+        const unsigned qrow = pmc / (unsigned)M;
+        const int m = (int)(pmc - qrow * (unsigned)M);
+        const int b = (int)(qrow / (unsigned)Lq);
         const unsigned row_base = ((unsigned)b * (unsigned)S * (unsigned)M + (unsigned)m) * (D * (unsigned)sizeof(TV));
-        stage_records_fwd<TV, FUSED>(rec, src, pmc, row_ok, sub, L, P, M, S, b, row_base, s_H, s_W, s_start);
+        stage_records_fwd<TV, FUSED>(rec, src, pmc, qrow, m, row_ok, sub, L, P, M, S, b, row_base, s_H, s_W, s_start);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         float acc[CH];
@@ -505,7 +510,7 @@ __global__ __launch_bounds__(256) void msda_fwd_d32_gather(
         int t = 0;
         for (; t + PTS <= LP; t += PTS) fwd_gather_chunk<PTS, TV>(rec, t, vr, lane_off, acc);
         for (; t < LP; ++t) fwd_gather_chunk<1, TV>(rec, t, vr, lane_off, acc);
-        if (row_ok) store_row16<TV>(out + pm * D + sub * CH, acc);
+        if (row_ok) store_row16<TV>(out + (pm * (unsigned)D + (unsigned)(sub * CH)), acc);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
@@ -817,14 +822,14 @@ __global__ __launch_bounds__(kTileThreads, 4) void msda_fwd_d32_hybrid(
         ok[p] = row.ok;
         pmr[p] = row.pm;
         const long qrow = (long)b * pl.Lq + row.q;
-        float mx = 0.f, sum = 1.f, e[2] = {0.f, 0.f};
+        float mx = 0.f, rsum = 1.f, e[2] = {0.f, 0.f};
         if (FUSED) {     // softmax of the row's (<= 16) logits: two per lane, DPP reductions over the row's 8 lanes
             const float *lg = fused_logits(src, qrow, m, LP);
             const float g0 = sub < LP ? lg[sub] : -INFINITY, g1 = sub + 8 < LP ? lg[sub + 8] : -INFINITY;
             mx = row_max<8>(fmaxf(g0, g1));
             e[0] = expf(g0 - mx);
             e[1] = expf(g1 - mx);
-            sum = row_sum<8>(e[0] + e[1]);
+            rsum = 1.f / row_sum<8>(e[0] + e[1]);
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -835,7 +840,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void msda_fwd_d32_hybrid(
                 const f32x2 xy = point_location<FUSED>(src, row.pm, qrow, m, L, P, t, l, tb.H[l], tb.W[l]);
                 lx[p][j] = xy.x;
                 ly[p][j] = xy.y;
-                la[p][j] = FUSED ? e[j] / sum : src.attn[row.pm * LP + t];
+                la[p][j] = FUSED ? e[j] * rsum : src.attn[row.pm * LP + t];
             }
         }
     }
@@ -1042,7 +1047,7 @@ __global__ __launch_bounds__(kTileThreads, PTS <= 2 ? 4 : 2) void msda_bwd_d32_t
     __shared__ float s_lscale[kTileMaxL], s_linv[kTileMaxL];
     __shared__ int s_nonfinite;
     __shared__ unsigned s_rowrange[2];         // min / max over the region's rows of max_c |grad_out[row, c]| (bits)
-    __shared__ f32x2 s_stat[FUSED ? kTileMaxRows + 11 : 1];     // softmax (max, sum) of every row of the region
+    __shared__ f32x2 s_stat[FUSED ? kTileMaxRows + 11 : 1];     // softmax (max, 1/sum) of every row of the region
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     int b, ry, rx, m;
     bool live;
@@ -1097,12 +1102,12 @@ __global__ __launch_bounds__(kTileThreads, PTS <= 2 ? 4 : 2) void msda_bwd_d32_t
             }
             if (FUSED) {
                 const float *lg = fused_logits(src, (long)b * pl.Lq + row.q, m, LP);
-                float mx, sum;
-                row_softmax_stats<8>(lg, LP, sub, mx, sum);
-                if (sub == 0 && r < pl.rows) s_stat[r] = f32x2{mx, sum};
+                float mx, rsum;
+                row_softmax_stats<8>(lg, LP, sub, mx, rsum);
+                if (sub == 0 && r < pl.rows) s_stat[r] = f32x2{mx, rsum};
                 if (row.ok) {
                     for (int t = sub; t < LP; t += 8) {
-                        const unsigned u = __float_as_uint(expf(lg[t] - mx) / sum) & 0x7fffffffu;
+                        const unsigned u = __float_as_uint(expf(lg[t] - mx) * rsum) & 0x7fffffffu;
                         const int l = t / P;
 #pragma unroll
                         for (int k = 0; k < kTileMaxL; ++k) a4[k] = (k == l && u > a4[k]) ? u : a4[k];
@@ -1187,19 +1192,19 @@ __global__ __launch_bounds__(kTileThreads, PTS <= 2 ? 4 : 2) void msda_bwd_d32_t
 #pragma unroll
         for (int j = 0; j < 4; ++j) lane_bypass = lane_bypass || (fabsf(gs[j]) < lane_limit && gs[j] != 0.f);
         const unsigned dump_or = lane_bypass ? 0xffffffffu : 0u;
-        float mx = 0.f, sum = 1.f;
+        float mx = 0.f, rsum = 1.f;
         const float *lg = nullptr;
         if (FUSED) {
             lg = fused_logits(src, qrow, m, LP);
             const f32x2 st = s_stat[r < pl.rows ? r : 0];
             mx = st.x;
-            sum = st.y;
+            rsum = st.y;
         }
         for (int t = sub; t < LP; t += 8) {
             const int l = t / P;
             const int H = tb.H[l], W = tb.W[l];
             const f32x2 xy = point_location<FUSED>(src, row.pm, qrow, m, L, P, t, l, H, W);
-            const float a_in = FUSED ? expf(lg[t] - mx) / sum : src.attn[row.pm * LP + t];
+            const float a_in = FUSED ? expf(lg[t] - mx) * rsum : src.attn[row.pm * LP + t];
             Sample<float> s = sample_setup<float>(xy.x, xy.y, H, W);
             const float a = (s.gate && row.ok) ? a_in : 0.f;
             if (!s.gate) s.lh = s.lw = 0.f;
@@ -1315,11 +1320,11 @@ __global__ __launch_bounds__(kTileThreads, PTS <= 2 ? 4 : 2) void msda_bwd_d32_t
                 // softmax Jacobian with the TRUE weights (the records carry 0 for gated-off points, whose logits still
                 // receive -a_t * sum_j a_j grad_attn_j)
                 float dot = 0.f;
-                for (int t = sub; t < LP; t += 8) dot += (expf(lg[t] - mx) / sum) * res[8 * t + 3];
+                for (int t = sub; t < LP; t += 8) dot += (expf(lg[t] - mx) * rsum) * res[8 * t + 3];
                 dot = row_sum<8>(dot);
                 float *gp = grad_proj + qrow * src.proj_stride;
                 for (int t = sub; t < LP; t += 8)
-                    gp[src.n_off + m * LP + t] = (expf(lg[t] - mx) / sum) * (res[8 * t + 3] - dot);
+                    gp[src.n_off + m * LP + t] = (expf(lg[t] - mx) * rsum) * (res[8 * t + 3] - dot);
                 for (int i = sub; i < 2 * LP; i += 8) {
                     const int t = i >> 1, comp = i & 1, l = t / P;
                     const float size = (float)(comp ? tb.H[l] : tb.W[l]);
@@ -1496,18 +1501,18 @@ __global__ __launch_bounds__(kTileThreads, PTS <= 2 ? 4 : 2) void msda_bwd_d32_t
             const f32x2 s0 = load_ch2<TV>(grad_out + pm * D + cpair[0]), s1 = load_ch2<TV>(grad_out + pm * D + cpair[1]);
             gsr[p][0] = s0.x; gsr[p][1] = s0.y; gsr[p][2] = s1.x; gsr[p][3] = s1.y;
         }
-        float mx = 0.f, sum = 1.f;
+        float mx = 0.f, rsum = 1.f;
         const float *lg = nullptr;
         if (FUSED) {     // (all 64 lanes: the row reductions are DPP)
             lg = fused_logits(src, qrow, m, LP);
-            row_softmax_stats<8>(lg, LP, sub, mx, sum);
+            row_softmax_stats<8>(lg, LP, sub, mx, rsum);
         }
         if (ok[p] && sub < P) {
             const int t = l * P + sub;
             const f32x2 xy = point_location<FUSED>(src, pm, qrow, m, L, P, t, l, H, W);
             px_[p] = xy.x;
             py_[p] = xy.y;
-            pa[p] = FUSED ? expf(lg[t] - mx) / sum : src.attn[pm * LP + t];
+            pa[p] = FUSED ? expf(lg[t] - mx) * rsum : src.attn[pm * LP + t];
         }
     }
     __syncthreads();      // the zeroed window / shared scalars are in place
@@ -1796,13 +1801,13 @@ __global__ __launch_bounds__(256) void msda_softmax_jacobian_kernel(const PointS
         const int m = (int)(pm - qrow * M);
         const float *lg = fused_logits(fs, qrow, m, LP);
         float *ga = grad_proj + qrow * fs.proj_stride + fs.n_off + (long)m * LP;
-        float mx, sum;
-        row_softmax_stats<8>(lg, LP, sub, mx, sum);
+        float mx, rsum;
+        row_softmax_stats<8>(lg, LP, sub, mx, rsum);
         float dot = 0.f;
-        for (int t = sub; t < LP; t += 8) dot += (expf(lg[t] - mx) / sum) * ga[t];
+        for (int t = sub; t < LP; t += 8) dot += (expf(lg[t] - mx) * rsum) * ga[t];
         dot = row_sum<8>(dot);
         if (ok)
-            for (int t = sub; t < LP; t += 8) ga[t] = (expf(lg[t] - mx) / sum) * (ga[t] - dot);
+            for (int t = sub; t < LP; t += 8) ga[t] = (expf(lg[t] - mx) * rsum) * (ga[t] - dot);
     }
 }
 
