@@ -121,6 +121,29 @@ def encode_chunks(core, clip_len: int):
 
 DEFAULT_ENCODE_CHUNKS = "auto"
 
+_ENCODE_STREAMS = {}
+
+
+def encode_stream(device):
+    """Opt-in (MEMOTR_ENCODE_STREAM=1): the HIP stream the later encode groups of a clip run on.
+
+    Idea: the decoder / criterion / query-updater chain of a frame is a serial string of hundreds of small kernels
+    that leave most of the 256 CUs idle, forward and backward; the backbone + encoder of the NEXT group of frames do
+    not depend on it, so queued on a second stream their large GEMMs and convolutions could fill the idle CUs (and
+    autograd replays every backward node on the stream of its forward, so the same holds for the backward).
+    Measured on MI355X it does not pay: 192.4 vs 192.7 ms per step (tools/ab_step.py).  A chain of small kernels
+    that takes 2.6 ms alone takes 16 ms next to 15 ms of GEMMs on another stream, at either stream priority
+    (tools/stream_overlap_probe.py, profiles/r02_stream_overlap_probe.txt): the chain is slowed to the length of
+    the large kernels it shares the CUs with, and the chain is the critical path.  Kept for clips whose groups are
+    not chain-bound; results are identical either way (tests/test_model_gpu.py)."""
+    dev = torch.device(device)
+    if dev.type != "cuda" or os.environ.get("MEMOTR_ENCODE_STREAM", "0") != "1":
+        return None
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if idx not in _ENCODE_STREAMS:
+        _ENCODE_STREAMS[idx] = torch.cuda.Stream(device=idx)
+    return _ENCODE_STREAMS[idx]
+
 
 def clip_forward_backward(model: nn.Module, criterion, batch: dict, device, use_dab: bool = True,
                           accumulation_steps: int = 1, backward: bool = True, no_grad_frames: int = None):
@@ -146,9 +169,27 @@ def clip_forward_backward(model: nn.Module, criterion, batch: dict, device, use_
     starts = [sum(chunks[:i]) for i in range(len(chunks))] if chunks is not None else []
     encoded = {}                                   # frame index -> encode result of that frame
 
+    side = encode_stream(device) if chunks is not None and len(chunks) > 1 else None
+    if side is not None:
+        lazy = False                               # later groups are queued one group ahead, on the side stream
+    on_side = set()                                # frames whose encode result was produced on the side stream
+
     def encode_chunk(ci):
         lo, n = starts[ci], chunks[ci]
-        enc = model(frame=frames(lo, lo + n), stage="encode")
+        if side is not None and ci > 0:
+            main = torch.cuda.current_stream()
+            batch_frames = frames(lo, lo + n)      # assembled on the main stream, read on the side stream
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                enc = model(frame=batch_frames, stage="encode")
+            for t in (batch_frames.tensors, batch_frames.masks):
+                t.record_stream(side)
+            for v in enc.values():                 # produced on the side stream, consumed by the decoder on main
+                if torch.is_tensor(v) and v.is_cuda:
+                    v.record_stream(main)
+            on_side.update(range(lo, lo + n))
+        else:
+            enc = model(frame=frames(lo, lo + n), stage="encode")
         if n == 1:
             encoded[lo] = dict(enc, frame_slot=lo)        # the frame's slot for the decoder's hipGraphs
             return
@@ -189,6 +230,9 @@ def clip_forward_backward(model: nn.Module, criterion, batch: dict, device, use_
             if frozen:
                 continue
         else:
+            if frame_idx in on_side:               # first use of a side-stream result: order the streams
+                torch.cuda.current_stream().wait_stream(side)
+                on_side.difference_update(range(frame_idx, clip_len))
             res = model(tracks=tracks, encoded=encoded.pop(frame_idx))
             pending = criterion.begin_frame(model_outputs=res, tracked_instances=tracks, frame_idx=frame_idx)
             if not lazy and frame_idx in starts and starts.index(frame_idx) + 1 < len(chunks):

@@ -65,13 +65,18 @@ def test_two_frame_inference_on_hip_operator_matches_reference(hip_lib):
             assert np.array_equal(tracks[0].ids.cpu().numpy(), g[f"f{i}_next_ids"])
 
 
-@pytest.mark.parametrize("chunks", ["0", "all", "auto"])
-def test_train_step_on_hip_operator_matches_reference(chunks):
+@pytest.mark.parametrize("chunks", ["0", "all", "auto", "auto/two-streams", "1,1,1/two-streams"])
+def test_train_step_on_hip_operator_matches_reference(chunks, monkeypatch):
     from memotr_amd.engine import clip_forward_backward
     from memotr_amd.models.criterion import build as build_criterion
     g = load_model_golden("M6_train_step")
     model = build_memotr_cuda(g).train()
-    model.encode_chunks = chunks        # reference frame order / one batched encode of the clip / two groups
+    # reference frame order / one batched encode of the clip / two groups / two groups, the second one encoded (and
+    # differentiated) on a side stream / three groups, two of them on the side stream
+    if chunks.endswith("/two-streams"):
+        chunks = chunks.split("/")[0]
+        monkeypatch.setenv("MEMOTR_ENCODE_STREAM", "1")
+    model.encode_chunks = chunks
     cfg = small_config()
     cfg.update(MATCH_COST_CLASS=2, MATCH_COST_BBOX=5, MATCH_COST_GIOU=2, LOSS_WEIGHT_FOCAL=2, LOSS_WEIGHT_L1=5,
                LOSS_WEIGHT_GIOU=2, AUX_LOSS_WEIGHT=[1.0], SAMPLE_LENGTHS=[2, 3, 4, 5])

@@ -4,6 +4,7 @@
 Separate bench.py runs differ by several percent from box to box and with the thermal state of the GPU, which
 hides small host-side changes.  This alternates two settings step by step and reports the median of each.
 Usage: python tools/ab_step.py [steps_per_setting] [encode-chunk specs ...]   e.g.  8 0 1 5 1,4
+A spec may carry environment switches read at run time: "auto@MEMOTR_ENCODE_STREAM=0", "2,3@A=1;B=2".
 """
 import os
 import statistics
@@ -30,6 +31,23 @@ batch = clip_to_device(make_synthetic_clip(5, 800, 1333, 10, seed=42), dev)
 
 
 def step(spec):
+    chunks, _, env = spec.partition("@")
+    saved = {}
+    for kv in filter(None, env.split(";")):
+        k, v = kv.split("=", 1)
+        saved[k] = os.environ.get(k)
+        os.environ[k] = v
+    try:
+        return _step(chunks)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _step(spec):
     model.encode_chunks = spec
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -51,6 +69,6 @@ for i in range(n):
         res[spec].append(step(spec))
 for spec in specs:
     wall, fwd, bwd = ([r[k] for r in res[spec]] for k in range(3))
-    print(f"encode chunks {spec:8s}: step median {statistics.median(wall):7.1f} ms (min {min(wall):7.1f})   "
+    print(f"encode chunks {spec:32s}: step median {statistics.median(wall):7.1f} ms (min {min(wall):7.1f})   "
           f"host: forward {statistics.median(fwd):6.1f} ms, backward call {statistics.median(bwd):6.1f} ms   "
           f"mem {torch.cuda.max_memory_allocated() >> 20} MiB")
