@@ -1,0 +1,63 @@
+/* clip_ops_hip.h -- C ABI of libclip_ops_hip.so: the small-tensor chains of the clip train step as single gfx950
+ * kernels.
+ *
+ * The decoder / criterion side of a MeMOTR train step is hundreds of element-wise torch kernels on tensors of a
+ * few thousand elements (matching cost, focal / L1 / GIoU losses, anchor embedding, box refinement).  On MI355X
+ * each costs 5-7 us of queue time whatever its size, forward and again (2-3x) backward; these entry points
+ * evaluate one whole chain per launch.  Arithmetic follows the reference formulas cited per function; all
+ * tensors are fp32 (indices int64), device pointers, plain sizes and element strides -- no torch types.
+ *
+ * Every function returns 0 on success or a non-zero code (clipops_last_error() has the text) and launches on
+ * `stream` (a hipStream_t passed as void*; NULL = the default stream).  Nothing here synchronises.
+ */
+#ifndef CLIP_OPS_HIP_H
+#define CLIP_OPS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CLIPOPS_ABI_VERSION 1
+
+int clipops_abi_version(void);
+const char *clipops_last_error(void);
+
+/* Matching cost of `n_layers` decoder layers at once (reference models/matcher.py:83-121, focal-style class cost):
+ *   cost[l,q,t] = w_bbox * |box[l,q] - gt_box[t]|_1 + w_class * (pos - neg)(sigmoid(logit[l,q,gt_label[t]]))
+ *                 + w_giou * (-GIoU(xyxy(box[l,q]), xyxy(gt_box[t])))
+ * logits: element (l,q,k) at logits[l*logit_sl + q*logit_sq + k]; boxes: (l,q,c) at boxes[l*box_sl + q*box_sq + c]
+ * (cxcywh).  gt_labels (T) int64, gt_boxes (T,4) and cost (n_layers,Q,T) are contiguous. */
+int clipops_match_cost_f32(const float *logits, long logit_sl, long logit_sq, const float *boxes, long box_sl,
+                           long box_sq, const int64_t *gt_labels, const float *gt_boxes, int n_layers, int Q, int K,
+                           int T, float w_class, float w_bbox, float w_giou, float *cost, void *stream);
+
+/* L1 and GIoU loss of `n` (prediction, target) box pairs (reference models/criterion.py:417-440: l1_loss(reduction
+ * none).sum(-1) and 1 - diag(generalized_box_iou(xyxy(pred), xyxy(tgt)))).
+ * Prediction i is row  lay[i]*row_mul + row_add + qidx[i]  of `boxes` (rows of 4 floats, cxcywh); target i is row
+ * gidx[i] of tgt_boxes (gidx == NULL: row i).  weight (n) may be NULL; both outputs are multiplied by it. */
+int clipops_pair_box_loss_fwd_f32(const float *boxes, const int64_t *lay, const int64_t *qidx, long row_mul,
+                                  long row_add, const float *tgt_boxes, const int64_t *gidx, const float *weight,
+                                  int n, float *l1, float *giou_loss, void *stream);
+/* Gradient of the above with respect to the prediction rows: grad_boxes (same row layout as `boxes`) receives
+ * plain stores for the n rows (the pairs of one call address distinct rows); the caller zero-fills it. */
+int clipops_pair_box_loss_bwd_f32(const float *boxes, const int64_t *lay, const int64_t *qidx, long row_mul,
+                                  long row_add, const float *tgt_boxes, const int64_t *gidx, const float *weight,
+                                  int n, const float *grad_l1, const float *grad_giou, float *grad_boxes,
+                                  void *stream);
+
+/* Sigmoid focal loss of stacked layers (reference models/criterion.py:442-467, RetinaNet form): per layer l
+ *   loss[l] = sum_q mean_k  a_t * ce * (1 - p_t)^gamma,   target one-hot of labels[l,q] (label == K: background).
+ * logits element (l,q,k) at logits[l*sl + q*sq + k]; labels (n_layers,Nq) int64 contiguous; loss (n_layers).
+ * One workgroup per layer with a fixed-order reduction: results are run-to-run identical. */
+int clipops_focal_fwd_f32(const float *logits, long sl, long sq, const int64_t *labels, int n_layers, int Nq, int K,
+                          float alpha, float gamma, float *loss, void *stream);
+/* grad_logits (n_layers,Nq,K) contiguous = grad_loss[l] * d loss[l] / d logit. */
+int clipops_focal_bwd_f32(const float *logits, long sl, long sq, const int64_t *labels, int n_layers, int Nq, int K,
+                          float alpha, float gamma, const float *grad_loss, float *grad_logits, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLIP_OPS_HIP_H */

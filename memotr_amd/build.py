@@ -1,4 +1,5 @@
-"""Build memotr_amd/lib/libmsda_hip.so with hipcc for gfx950 (cross-compiles without a GPU)."""
+"""Build memotr_amd/lib/libmsda_hip.so (the operator) and libclip_ops_hip.so (fused small-tensor chains of the train
+step) with hipcc for gfx950 (cross-compiles without a GPU)."""
 from __future__ import annotations
 
 import os
@@ -11,6 +12,9 @@ HDR = os.path.join(os.path.dirname(_HERE), "include", "msda_hip.h")
 COMMON = os.path.join(_HERE, "csrc", "msda_common.h")
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libmsda_hip.so")
+CLIP_SRC = os.path.join(_HERE, "csrc", "clip_ops.hip")
+CLIP_HDR = os.path.join(os.path.dirname(_HERE), "include", "clip_ops_hip.h")
+CLIP_LIB = os.path.join(LIB_DIR, "libclip_ops_hip.so")
 
 HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
@@ -36,23 +40,38 @@ def source_hash() -> str:
     return h.hexdigest()[:16]
 
 
-def needs_build() -> bool:
-    if not os.path.exists(LIB):
+def _stale(lib: str, deps) -> bool:
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(p) > t for p in (SRC, HDR, COMMON))
+    t = os.path.getmtime(lib)
+    return any(os.path.getmtime(p) > t for p in deps)
+
+
+def needs_build() -> bool:
+    return _stale(LIB, (SRC, HDR, COMMON))
+
+
+def _compile(src: str, lib: str, verbose: bool) -> str:
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [hipcc_path(), *HIPCC_FLAGS, src, "-o", lib]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return lib
 
 
 def build_lib(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
-    os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc_path(), *HIPCC_FLAGS, SRC, "-o", LIB]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    return LIB
+    return _compile(SRC, LIB, verbose)
+
+
+def build_clip_lib(force: bool = False, verbose: bool = False) -> str:
+    if not force and not _stale(CLIP_LIB, (CLIP_SRC, CLIP_HDR)):
+        return CLIP_LIB
+    return _compile(CLIP_SRC, CLIP_LIB, verbose)
 
 
 if __name__ == "__main__":
     print(build_lib(force=True, verbose=True))
+    print(build_clip_lib(force=True, verbose=True))

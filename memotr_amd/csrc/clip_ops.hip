@@ -1,0 +1,318 @@
+// clip_ops.hip -- the small-tensor chains of the clip train step as single gfx950 kernels (C ABI: include/clip_ops_hip.h).
+//
+// Everything here works on a few thousand elements: the cost is the launch, not the arithmetic.  One thread per
+// output element, straight-line fp32 code following the reference formulas (operation order kept where it is
+// cheap to do so; `#pragma clang fp contract(off)` so that a product rounds before it is added, as in torch's
+// separate kernels), fixed-order reductions where a sum is needed.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/clip_ops_hip.h"
+
+namespace {
+
+thread_local char g_err[256] = {0};
+
+int fail(int code, const char *msg) {
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+    return code;
+}
+
+int check_launch(const char *what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+        return (int)e;
+    }
+    g_err[0] = 0;
+    return 0;
+}
+
+struct Box {
+    float x1, y1, x2, y2;
+};
+
+// cxcywh -> xyxy (reference utils/box_ops.py:16-20)
+__device__ __forceinline__ Box to_xyxy(float cx, float cy, float w, float h) {
+#pragma clang fp contract(off)
+    Box b;
+    b.x1 = cx - 0.5f * w;
+    b.y1 = cy - 0.5f * h;
+    b.x2 = cx + 0.5f * w;
+    b.y2 = cy + 0.5f * h;
+    return b;
+}
+
+// generalised IoU of two xyxy boxes (reference utils/box_ops.py:49-70, one pair)
+__device__ __forceinline__ float giou_pair(const Box a, const Box b) {
+#pragma clang fp contract(off)
+    const float iw = fmaxf(fminf(a.x2, b.x2) - fmaxf(a.x1, b.x1), 0.f);
+    const float ih = fmaxf(fminf(a.y2, b.y2) - fmaxf(a.y1, b.y1), 0.f);
+    const float inter = iw * ih;
+    const float area_a = (a.x2 - a.x1) * (a.y2 - a.y1);
+    const float area_b = (b.x2 - b.x1) * (b.y2 - b.y1);
+    const float uni = area_a + area_b - inter;
+    const float iou = inter / uni;
+    const float hw = fmaxf(fmaxf(a.x2, b.x2) - fminf(a.x1, b.x1), 0.f);
+    const float hh = fmaxf(fmaxf(a.y2, b.y2) - fminf(a.y1, b.y1), 0.f);
+    const float hull = hw * hh;
+    return iou - (hull - uni) / hull;
+}
+
+__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
+
+__device__ __forceinline__ float powg(float x, float gamma) { return gamma == 2.f ? x * x : powf(x, gamma); }
+
+// ----------------------------------------------------------------------------------------
+// matching cost
+// ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void match_cost_kernel(const float *__restrict__ logits, long lsl, long lsq,
+                                                        const float *__restrict__ boxes, long bsl, long bsq,
+                                                        const int64_t *__restrict__ gt_labels,
+                                                        const float *__restrict__ gt_boxes, int n_layers, int Q,
+                                                        int K, int T, float w_class, float w_bbox, float w_giou,
+                                                        float *__restrict__ cost) {
+#pragma clang fp contract(off)
+    const long total = (long)n_layers * Q * T;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int t = (int)(i % T);
+        const long lq = i / T;
+        const int q = (int)(lq % Q), l = (int)(lq / Q);
+        long lab = gt_labels[t];
+        lab = lab < 0 ? 0 : (lab >= K ? K - 1 : lab);
+        const float prob = sigmoidf(logits[l * lsl + q * lsq + lab]);
+        const float alpha = 0.25f, gamma = 2.f;
+        const float neg = ((1.f - alpha) * powg(prob, gamma)) * (-logf(1.f - prob + 1e-8f));
+        const float pos = (alpha * powg(1.f - prob, gamma)) * (-logf(prob + 1e-8f));
+        const float c_class = pos - neg;
+        const float *pb = boxes + l * bsl + q * bsq;
+        const float *tb = gt_boxes + (long)t * 4;
+        const float p0 = pb[0], p1 = pb[1], p2 = pb[2], p3 = pb[3];
+        const float t0 = tb[0], t1 = tb[1], t2 = tb[2], t3 = tb[3];
+        const float c_bbox = ((fabsf(p0 - t0) + fabsf(p1 - t1)) + fabsf(p2 - t2)) + fabsf(p3 - t3);
+        const float giou = giou_pair(to_xyxy(p0, p1, p2, p3), to_xyxy(t0, t1, t2, t3));
+        cost[i] = (w_bbox * c_bbox + w_class * c_class) + w_giou * (-giou);
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// paired box losses
+// ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pair_box_loss_fwd_kernel(const float *__restrict__ boxes,
+                                                               const int64_t *__restrict__ lay,
+                                                               const int64_t *__restrict__ qidx, long row_mul,
+                                                               long row_add, const float *__restrict__ tgt,
+                                                               const int64_t *__restrict__ gidx,
+                                                               const float *__restrict__ weight, int n,
+                                                               float *__restrict__ l1, float *__restrict__ gl) {
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *pb = boxes + (lay[i] * row_mul + row_add + qidx[i]) * 4;
+    const float *tb = tgt + (gidx ? gidx[i] : (long)i) * 4;
+    const float p0 = pb[0], p1 = pb[1], p2 = pb[2], p3 = pb[3];
+    const float t0 = tb[0], t1 = tb[1], t2 = tb[2], t3 = tb[3];
+    float a = ((fabsf(p0 - t0) + fabsf(p1 - t1)) + fabsf(p2 - t2)) + fabsf(p3 - t3);
+    float g = 1.f - giou_pair(to_xyxy(p0, p1, p2, p3), to_xyxy(t0, t1, t2, t3));
+    if (weight) {
+        a *= weight[i];
+        g *= weight[i];
+    }
+    l1[i] = a;
+    gl[i] = g;
+}
+
+// d max(a,b)/da and d min(a,b)/da with torch's tie rule (half each)
+__device__ __forceinline__ float dmax_a(float a, float b) { return a > b ? 1.f : (a == b ? 0.5f : 0.f); }
+__device__ __forceinline__ float dmin_a(float a, float b) { return a < b ? 1.f : (a == b ? 0.5f : 0.f); }
+__device__ __forceinline__ float sgn(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
+
+__global__ __launch_bounds__(256) void pair_box_loss_bwd_kernel(const float *__restrict__ boxes,
+                                                               const int64_t *__restrict__ lay,
+                                                               const int64_t *__restrict__ qidx, long row_mul,
+                                                               long row_add, const float *__restrict__ tgt,
+                                                               const int64_t *__restrict__ gidx,
+                                                               const float *__restrict__ weight, int n,
+                                                               const float *__restrict__ g_l1,
+                                                               const float *__restrict__ g_gl,
+                                                               float *__restrict__ grad_boxes) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long row = lay[i] * row_mul + row_add + qidx[i];
+    const float *pb = boxes + row * 4;
+    const float *tb = tgt + (gidx ? gidx[i] : (long)i) * 4;
+    const float p0 = pb[0], p1 = pb[1], p2 = pb[2], p3 = pb[3];
+    const float t0 = tb[0], t1 = tb[1], t2 = tb[2], t3 = tb[3];
+    const float w = weight ? weight[i] : 1.f;
+    const float ga = g_l1[i] * w;         // d/d(l1 sum)
+    const float gg = -g_gl[i] * w;        // d/d(giou): the loss is 1 - giou
+    const Box a = to_xyxy(p0, p1, p2, p3), b = to_xyxy(t0, t1, t2, t3);
+    // forward values
+    const float ltx = fmaxf(a.x1, b.x1), lty = fmaxf(a.y1, b.y1), rbx = fminf(a.x2, b.x2), rby = fminf(a.y2, b.y2);
+    const float dw = rbx - ltx, dh = rby - lty;
+    const float iw = fmaxf(dw, 0.f), ih = fmaxf(dh, 0.f);
+    const float inter = iw * ih;
+    const float aw = a.x2 - a.x1, ah = a.y2 - a.y1;
+    const float area_a = aw * ah, area_b = (b.x2 - b.x1) * (b.y2 - b.y1);
+    const float uni = area_a + area_b - inter;
+    const float hx1 = fminf(a.x1, b.x1), hy1 = fminf(a.y1, b.y1), hx2 = fmaxf(a.x2, b.x2), hy2 = fmaxf(a.y2, b.y2);
+    const float ew = hx2 - hx1, eh = hy2 - hy1;
+    const float hw = fmaxf(ew, 0.f), hh = fmaxf(eh, 0.f);
+    const float hull = hw * hh;
+    // giou = inter/uni - (hull - uni)/hull
+    const float g_inter0 = gg / uni;                                          // via iou
+    const float g_uni = gg * (-inter / (uni * uni)) + gg / hull;              // via iou and via -(hull-uni)/hull
+    const float g_hull = gg * (-(uni / (hull * hull)));                       // d[-(hull-uni)/hull]/d hull = -uni/hull^2
+    const float g_inter = g_inter0 - g_uni;                                   // uni = area_a + area_b - inter
+    const float g_area_a = g_uni;
+    // inter = clamp(dw) * clamp(dh)   (clamp(min=0) passes the gradient where x >= 0)
+    const float g_dw = g_inter * ih * (dw >= 0.f ? 1.f : 0.f), g_dh = g_inter * iw * (dh >= 0.f ? 1.f : 0.f);
+    const float g_ew = g_hull * hh * (ew >= 0.f ? 1.f : 0.f), g_eh = g_hull * hw * (eh >= 0.f ? 1.f : 0.f);
+    // xyxy gradients of box a
+    float gx1 = -g_dw * dmax_a(a.x1, b.x1) - g_ew * dmin_a(a.x1, b.x1) - g_area_a * ah;
+    float gy1 = -g_dh * dmax_a(a.y1, b.y1) - g_eh * dmin_a(a.y1, b.y1) - g_area_a * aw;
+    float gx2 = g_dw * dmin_a(a.x2, b.x2) + g_ew * dmax_a(a.x2, b.x2) + g_area_a * ah;
+    float gy2 = g_dh * dmin_a(a.y2, b.y2) + g_eh * dmax_a(a.y2, b.y2) + g_area_a * aw;
+    // cxcywh: x1 = cx - w/2, x2 = cx + w/2
+    float *go = grad_boxes + row * 4;
+    go[0] = (gx1 + gx2) + ga * sgn(p0 - t0);
+    go[1] = (gy1 + gy2) + ga * sgn(p1 - t1);
+    go[2] = 0.5f * (gx2 - gx1) + ga * sgn(p2 - t2);
+    go[3] = 0.5f * (gy2 - gy1) + ga * sgn(p3 - t3);
+}
+
+// ----------------------------------------------------------------------------------------
+// focal loss of stacked layers
+// ----------------------------------------------------------------------------------------
+struct Focal {
+    float loss, dloss;
+};
+
+// one element: logit x, binary target (t == 1 when is_pos)
+__device__ __forceinline__ Focal focal_elem(float x, bool is_pos, float alpha, float gamma) {
+    const float p = sigmoidf(x);
+    // binary_cross_entropy_with_logits: max(x,0) - x*t + log(1 + exp(-|x|))
+    const float ce = fmaxf(x, 0.f) - (is_pos ? x : 0.f) + log1pf(expf(-fabsf(x)));
+    const float p_t = is_pos ? p : 1.f - p;
+    const float q = 1.f - p_t;
+    const float a_t = alpha >= 0.f ? (is_pos ? alpha : 1.f - alpha) : 1.f;
+    const float mod = powg(q, gamma);
+    Focal f;
+    f.loss = a_t * (ce * mod);
+    // d/dx: -s a_t [gamma q^(gamma-1) (p_t q) ce + q^gamma q],  s = +1 (positive) / -1
+    const float qg1 = gamma == 2.f ? q : powf(q, gamma - 1.f);
+    const float d = a_t * (gamma * qg1 * (p_t * q) * ce + mod * q);
+    f.dloss = is_pos ? -d : d;
+    return f;
+}
+
+__global__ __launch_bounds__(256) void focal_fwd_kernel(const float *__restrict__ logits, long sl, long sq,
+                                                       const int64_t *__restrict__ labels, int Nq, int K, float alpha,
+                                                       float gamma, float *__restrict__ loss) {
+    __shared__ float s_part[256];
+    const int l = blockIdx.x;
+    const int total = Nq * K;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < total; i += 256) {
+        const int q = i / K, k = i - q * K;
+        const float x = logits[l * sl + q * sq + k];
+        acc += focal_elem(x, labels[(long)l * Nq + q] == k, alpha, gamma).loss;
+    }
+    s_part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) s_part[threadIdx.x] += s_part[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[l] = s_part[0] / (float)K;      // mean over the classes, sum over the queries
+}
+
+__global__ __launch_bounds__(256) void focal_bwd_kernel(const float *__restrict__ logits, long sl, long sq,
+                                                       const int64_t *__restrict__ labels, int n_layers, int Nq,
+                                                       int K, float alpha, float gamma,
+                                                       const float *__restrict__ g_loss,
+                                                       float *__restrict__ grad_logits) {
+    const long total = (long)n_layers * Nq * K;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % K);
+        const long lq = i / K;
+        const int q = (int)(lq % Nq), l = (int)(lq / Nq);
+        const float x = logits[l * sl + q * sq + k];
+        const Focal f = focal_elem(x, labels[lq] == k, alpha, gamma);
+        grad_logits[i] = (g_loss[l] / (float)K) * f.dloss;
+    }
+}
+
+int grid_for(long total) {
+    long g = (total + 255) / 256;
+    if (g < 1) g = 1;
+    return (int)(g > 4096 ? 4096 : g);
+}
+
+}  // namespace
+
+extern "C" {
+
+int clipops_abi_version(void) { return CLIPOPS_ABI_VERSION; }
+
+const char *clipops_last_error(void) { return g_err; }
+
+int clipops_match_cost_f32(const float *logits, long logit_sl, long logit_sq, const float *boxes, long box_sl,
+                           long box_sq, const int64_t *gt_labels, const float *gt_boxes, int n_layers, int Q, int K,
+                           int T, float w_class, float w_bbox, float w_giou, float *cost, void *stream) {
+    if (n_layers < 0 || Q < 0 || T < 0 || K <= 0) return fail(1, "clipops_match_cost_f32: bad dimension");
+    if ((long)n_layers * Q * T == 0) { g_err[0] = 0; return 0; }
+    if (!logits || !boxes || !gt_labels || !gt_boxes || !cost) return fail(1, "clipops_match_cost_f32: null pointer");
+    hipLaunchKernelGGL(match_cost_kernel, dim3(grid_for((long)n_layers * Q * T)), dim3(256), 0, (hipStream_t)stream,
+                       logits, logit_sl, logit_sq, boxes, box_sl, box_sq, gt_labels, gt_boxes, n_layers, Q, K, T,
+                       w_class, w_bbox, w_giou, cost);
+    return check_launch("match_cost_kernel");
+}
+
+int clipops_pair_box_loss_fwd_f32(const float *boxes, const int64_t *lay, const int64_t *qidx, long row_mul,
+                                  long row_add, const float *tgt_boxes, const int64_t *gidx, const float *weight,
+                                  int n, float *l1, float *giou_loss, void *stream) {
+    if (n < 0) return fail(1, "clipops_pair_box_loss_fwd_f32: negative count");
+    if (n == 0) { g_err[0] = 0; return 0; }
+    if (!boxes || !lay || !qidx || !tgt_boxes || !l1 || !giou_loss)
+        return fail(1, "clipops_pair_box_loss_fwd_f32: null pointer");
+    hipLaunchKernelGGL(pair_box_loss_fwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, boxes, lay,
+                       qidx, row_mul, row_add, tgt_boxes, gidx, weight, n, l1, giou_loss);
+    return check_launch("pair_box_loss_fwd_kernel");
+}
+
+int clipops_pair_box_loss_bwd_f32(const float *boxes, const int64_t *lay, const int64_t *qidx, long row_mul,
+                                  long row_add, const float *tgt_boxes, const int64_t *gidx, const float *weight,
+                                  int n, const float *grad_l1, const float *grad_giou, float *grad_boxes,
+                                  void *stream) {
+    if (n < 0) return fail(1, "clipops_pair_box_loss_bwd_f32: negative count");
+    if (n == 0) { g_err[0] = 0; return 0; }
+    if (!boxes || !lay || !qidx || !tgt_boxes || !grad_l1 || !grad_giou || !grad_boxes)
+        return fail(1, "clipops_pair_box_loss_bwd_f32: null pointer");
+    hipLaunchKernelGGL(pair_box_loss_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, boxes, lay,
+                       qidx, row_mul, row_add, tgt_boxes, gidx, weight, n, grad_l1, grad_giou, grad_boxes);
+    return check_launch("pair_box_loss_bwd_kernel");
+}
+
+int clipops_focal_fwd_f32(const float *logits, long sl, long sq, const int64_t *labels, int n_layers, int Nq, int K,
+                          float alpha, float gamma, float *loss, void *stream) {
+    if (n_layers < 0 || Nq < 0 || K <= 0) return fail(1, "clipops_focal_fwd_f32: bad dimension");
+    if (n_layers == 0) { g_err[0] = 0; return 0; }
+    if (!loss || (Nq > 0 && (!logits || !labels))) return fail(1, "clipops_focal_fwd_f32: null pointer");
+    hipLaunchKernelGGL(focal_fwd_kernel, dim3(n_layers), dim3(256), 0, (hipStream_t)stream, logits, sl, sq, labels, Nq,
+                       K, alpha, gamma, loss);
+    return check_launch("focal_fwd_kernel");
+}
+
+int clipops_focal_bwd_f32(const float *logits, long sl, long sq, const int64_t *labels, int n_layers, int Nq, int K,
+                          float alpha, float gamma, const float *grad_loss, float *grad_logits, void *stream) {
+    if (n_layers < 0 || Nq < 0 || K <= 0) return fail(1, "clipops_focal_bwd_f32: bad dimension");
+    if ((long)n_layers * Nq == 0) { g_err[0] = 0; return 0; }
+    if (!logits || !labels || !grad_loss || !grad_logits) return fail(1, "clipops_focal_bwd_f32: null pointer");
+    hipLaunchKernelGGL(focal_bwd_kernel, dim3(grid_for((long)n_layers * Nq * K)), dim3(256), 0, (hipStream_t)stream,
+                       logits, sl, sq, labels, n_layers, Nq, K, alpha, gamma, grad_loss, grad_logits);
+    return check_launch("focal_bwd_kernel");
+}
+
+}  // extern "C"

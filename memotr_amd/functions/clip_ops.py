@@ -1,0 +1,153 @@
+"""Fused small-tensor chains of the clip train step: one gfx950 kernel per chain (include/clip_ops_hip.h) where the
+reference issues a string of element-wise torch kernels.
+
+Every function takes CUDA fp32 tensors and launches through the C ABI; ``*_reference`` are the element-wise torch
+formulations of the same arithmetic (the reference's formulas) -- what CPU tensors run and what the GPU tests
+compare the kernels with.  ``fused(t)`` decides: CUDA fp32 tensors use the kernels unless MEMOTR_FUSED_CLIP_OPS=0.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.nn.functional as F
+
+
+def fused(*tensors) -> bool:
+    return (os.environ.get("MEMOTR_FUSED_CLIP_OPS", "1") != "0"
+            and all(t.is_cuda and (t.dtype == torch.float32 or not t.is_floating_point()) for t in tensors))
+
+
+def _lib():
+    from .. import _clip_lib        # raises ImportError when the library is missing: no silent substitute
+    return _clip_lib
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _strides3(t: torch.Tensor):
+    """(layer stride, row stride) in elements of a (n_layers, rows, C) view whose last axis is dense."""
+    if t.dim() != 3 or (t.shape[2] > 1 and t.stride(2) != 1):
+        raise RuntimeError("expected a (layers, rows, C) tensor with a dense last axis")
+    return t.stride(0), t.stride(1)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# matching cost (models/matcher.py of the reference, :83-121)
+# --------------------------------------------------------------------------------------------------------------
+def match_cost(logits: torch.Tensor, boxes: torch.Tensor, gt_labels: torch.Tensor, gt_boxes: torch.Tensor,
+               w_class: float, w_bbox: float, w_giou: float) -> torch.Tensor:
+    """(n_layers, Q, K) logits and (n_layers, Q, 4) cxcywh boxes (views allowed) against (T,) labels / (T, 4) boxes
+    -> (n_layers, Q, T) cost."""
+    n_layers, Q, K = logits.shape
+    T = gt_labels.shape[0]
+    cost = torch.empty((n_layers, Q, T), dtype=torch.float32, device=logits.device)
+    lsl, lsq = _strides3(logits)
+    bsl, bsq = _strides3(boxes)
+    gt_labels, gt_boxes = gt_labels.contiguous(), gt_boxes.contiguous()
+    L = _lib()
+    L.check(L.lib.clipops_match_cost_f32(logits.data_ptr(), lsl, lsq, boxes.data_ptr(), bsl, bsq, gt_labels.data_ptr(),
+                                         gt_boxes.data_ptr(), n_layers, Q, K, T, float(w_class), float(w_bbox),
+                                         float(w_giou), cost.data_ptr(), _stream(logits)), "clipops_match_cost_f32")
+    return cost
+
+
+# --------------------------------------------------------------------------------------------------------------
+# paired L1 + GIoU box losses (models/criterion.py of the reference, :417-440)
+# --------------------------------------------------------------------------------------------------------------
+class _PairBoxLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, boxes_all, lay, qidx, b, tgt_boxes, gidx, weight):
+        n_layers, B, Nq, _ = boxes_all.shape
+        n = lay.shape[0]
+        l1 = torch.empty((n,), dtype=torch.float32, device=boxes_all.device)
+        gl = torch.empty_like(l1)
+        L = _lib()
+        L.check(L.lib.clipops_pair_box_loss_fwd_f32(
+            boxes_all.data_ptr(), lay.data_ptr(), qidx.data_ptr(), B * Nq, b * Nq, tgt_boxes.data_ptr(),
+            None if gidx is None else gidx.data_ptr(), None if weight is None else weight.data_ptr(), n,
+            l1.data_ptr(), gl.data_ptr(), _stream(boxes_all)), "clipops_pair_box_loss_fwd_f32")
+        ctx.save_for_backward(boxes_all, lay, qidx, tgt_boxes, gidx, weight)
+        ctx.b = b
+        return l1, gl
+
+    @staticmethod
+    def backward(ctx, g_l1, g_gl):
+        boxes_all, lay, qidx, tgt_boxes, gidx, weight = ctx.saved_tensors
+        n_layers, B, Nq, _ = boxes_all.shape
+        grad = torch.zeros_like(boxes_all)
+        L = _lib()
+        L.check(L.lib.clipops_pair_box_loss_bwd_f32(
+            boxes_all.data_ptr(), lay.data_ptr(), qidx.data_ptr(), B * Nq, ctx.b * Nq, tgt_boxes.data_ptr(),
+            None if gidx is None else gidx.data_ptr(), None if weight is None else weight.data_ptr(), lay.shape[0],
+            g_l1.contiguous().data_ptr(), g_gl.contiguous().data_ptr(), grad.data_ptr(), _stream(boxes_all)),
+            "clipops_pair_box_loss_bwd_f32")
+        return grad, None, None, None, None, None, None
+
+
+def pair_box_loss(boxes_all: torch.Tensor, lay: torch.Tensor, qidx: torch.Tensor, b: int, tgt_boxes: torch.Tensor,
+                  gidx: torch.Tensor = None, weight: torch.Tensor = None):
+    """L1 (summed over the 4 coordinates) and 1 - GIoU of the pairs (boxes_all[lay[i], b, qidx[i]], tgt_boxes[gidx[i]]
+    or tgt_boxes[i]), each optionally times weight[i].  boxes_all: (n_layers, B, Nq, 4) contiguous, cxcywh; the
+    (lay, qidx) pairs of one call must be distinct.  Returns two (n,) tensors; gradients flow to boxes_all."""
+    if not boxes_all.is_contiguous():
+        boxes_all = boxes_all.contiguous()
+    return _PairBoxLoss.apply(boxes_all, lay.contiguous(), qidx.contiguous(), int(b), tgt_boxes.contiguous(),
+                              None if gidx is None else gidx.contiguous(),
+                              None if weight is None else weight.contiguous())
+
+
+def pair_box_loss_reference(boxes_all, lay, qidx, b, tgt_boxes, gidx=None, weight=None):
+    from ..models.criterion import paired_giou
+    from ..utils.box_ops import box_cxcywh_to_xyxy
+    pb = boxes_all[lay, b, qidx]
+    tb = tgt_boxes if gidx is None else tgt_boxes[gidx]
+    l1 = F.l1_loss(pb, tb, reduction="none").sum(-1)
+    gl = 1 - paired_giou(box_cxcywh_to_xyxy(pb), box_cxcywh_to_xyxy(tb))
+    if weight is not None:
+        l1, gl = l1 * weight, gl * weight
+    return l1, gl
+
+
+# --------------------------------------------------------------------------------------------------------------
+# focal loss of stacked layers (models/criterion.py of the reference, :442-467)
+# --------------------------------------------------------------------------------------------------------------
+class _FocalPerLayer(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, alpha, gamma):
+        n_layers, Nq, K = logits.shape
+        sl, sq = _strides3(logits)
+        loss = torch.empty((n_layers,), dtype=torch.float32, device=logits.device)
+        L = _lib()
+        L.check(L.lib.clipops_focal_fwd_f32(logits.data_ptr(), sl, sq, labels.data_ptr(), n_layers, Nq, K, alpha, gamma,
+                                            loss.data_ptr(), _stream(logits)), "clipops_focal_fwd_f32")
+        ctx.save_for_backward(logits, labels)
+        ctx.alpha, ctx.gamma = alpha, gamma
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, labels = ctx.saved_tensors
+        n_layers, Nq, K = logits.shape
+        sl, sq = _strides3(logits)
+        grad = torch.empty((n_layers, Nq, K), dtype=torch.float32, device=logits.device)
+        L = _lib()
+        L.check(L.lib.clipops_focal_bwd_f32(logits.data_ptr(), sl, sq, labels.data_ptr(), n_layers, Nq, K, ctx.alpha,
+                                            ctx.gamma, g.contiguous().data_ptr(), grad.data_ptr(), _stream(logits)),
+                "clipops_focal_bwd_f32")
+        return grad, None, None, None
+
+
+def focal_loss_per_layer(logits: torch.Tensor, labels: torch.Tensor, alpha: float = 0.25, gamma: float = 2.0):
+    """(n_layers, Nq, K) logits (a view is fine), (n_layers, Nq) int64 labels with K = background -> (n_layers,)
+    sigmoid focal loss, mean over classes and sum over queries."""
+    return _FocalPerLayer.apply(logits, labels.contiguous(), float(alpha), float(gamma))
+
+
+def focal_loss_per_layer_reference(logits, labels, alpha: float = 0.25, gamma: float = 2.0):
+    from ..models.criterion import sigmoid_focal_loss_per_layer
+    K = logits.shape[-1]
+    one_hot = F.one_hot(labels, K + 1)[..., :-1].to(logits.dtype)
+    return sigmoid_focal_loss_per_layer(logits, one_hot, alpha, gamma)

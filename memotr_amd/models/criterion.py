@@ -18,6 +18,7 @@ import torch
 import torch.distributed
 import torch.nn.functional as F
 
+from ..functions import clip_ops
 from ..structures.track_instances import TrackInstances
 from ..utils.box_ops import box_cxcywh_to_xyxy, box_iou_union, generalized_box_iou
 from ..utils.utils import distributed_world_size, is_distributed
@@ -147,8 +148,12 @@ class ClipCriterion:
             else:
                 tr.matched_idx = torch.full((n_tr,), -1, dtype=torch.long, device=dev)
                 free = torch.ones((n_gt,), dtype=torch.bool, device=dev)
-            cost = self.matcher.cost_matrix_stacked(logits_all[:, b, :nd].detach(), boxes_all[:, b, :nd].detach(),
-                                                    gt.labels, gt.boxes)                  # (n_layers, nd, n_gt)
+            lg, bx = logits_all.detach()[:, b, :nd], boxes_all.detach()[:, b, :nd]
+            if clip_ops.fused(lg, bx, gt.boxes):        # one kernel for the whole cost tensor
+                cost = clip_ops.match_cost(lg, bx, gt.labels, gt.boxes, self.matcher.cost_class,
+                                           self.matcher.cost_bbox, self.matcher.cost_giou)
+            else:
+                cost = self.matcher.cost_matrix_stacked(lg, bx, gt.labels, gt.boxes)      # (n_layers, nd, n_gt)
             payload += [free.to(cost.dtype).reshape(-1), cost.reshape(-1)]
         ready = keep = None
         if not payload:
@@ -261,22 +266,27 @@ class ClipCriterion:
                                      else torch.full_like(tr.matched_idx, self.num_classes),
                                      torch.full_like(tr.matched_idx, self.num_classes))
                 labels[:, nd:] = torch.where(late[:, None], tr_lab[None, :], labels[:, nd:])
-            one_hot = F.one_hot(labels, self.num_classes + 1)[..., :-1].to(logits_all.dtype)
-            loss_label = loss_label + sigmoid_focal_loss_per_layer(logits_all[:, b, :n_q], one_hot)
+            use_kernels = clip_ops.fused(logits_all, boxes_all, gt.boxes)
+            if use_kernels:
+                loss_label = loss_label + clip_ops.focal_loss_per_layer(logits_all[:, b, :n_q], labels)
+            else:
+                one_hot = F.one_hot(labels, self.num_classes + 1)[..., :-1].to(logits_all.dtype)
+                loss_label = loss_label + sigmoid_focal_loss_per_layer(logits_all[:, b, :n_q], one_hot)
 
             # box losses: detect pairs of every layer + tracked pairs of the late layers
-            p_boxes, t_boxes, p_layer = [boxes_all[lay_i, b, q_i]], [gt.boxes[g_i]], [lay_i]
+            pair_loss = clip_ops.pair_box_loss if use_kernels else clip_ops.pair_box_loss_reference
             if n_tr > 0 and len(gt) > 0:
-                w_pair = (has[None, :] & late[:, None]).to(boxes_all.dtype)           # (n_layers, n_tr) 0/1 weights
-                tb = gt.boxes[tr.matched_idx.clamp(min=0)]                            # (n_tr, 4)
-                pb = boxes_all[:, b, nd:n_q]                                          # (n_layers, n_tr, 4)
-                l1_t = (F.l1_loss(pb, tb[None].expand_as(pb), reduction="none").sum(-1) * w_pair).sum(1)
-                gi_t = ((1 - paired_giou(box_cxcywh_to_xyxy(pb), box_cxcywh_to_xyxy(tb)[None].expand_as(pb))) * w_pair).sum(1)
-                loss_l1 = loss_l1 + l1_t
-                loss_giou = loss_giou + gi_t
-            pb, tb = torch.cat(p_boxes), torch.cat(t_boxes)
-            l1_pair = F.l1_loss(pb, tb, reduction="none").sum(-1)
-            gi_pair = 1 - paired_giou(box_cxcywh_to_xyxy(pb), box_cxcywh_to_xyxy(tb))
+                # every (layer, track) pair, weight 1 where the layer carries tracks and the track owns a ground truth
+                lay_t = self._constant(("lay_t", n_layers, n_tr), [li for li in range(n_layers) for _ in range(n_tr)],
+                                       torch.long, dev)
+                q_t = self._constant(("q_t", n_layers, n_tr, nd), [nd + j for _ in range(n_layers) for j in range(n_tr)],
+                                     torch.long, dev)
+                w_pair = (has[None, :] & late[:, None]).to(boxes_all.dtype).reshape(-1)
+                g_t = tr.matched_idx.clamp(min=0).repeat(n_layers)
+                l1_t, gi_t = pair_loss(boxes_all, lay_t, q_t, b, gt.boxes, g_t, w_pair)
+                loss_l1 = loss_l1 + l1_t.view(n_layers, n_tr).sum(1)
+                loss_giou = loss_giou + gi_t.view(n_layers, n_tr).sum(1)
+            l1_pair, gi_pair = pair_loss(boxes_all, lay_i, q_i, b, gt.boxes, g_i)
             loss_l1 = loss_l1.index_add(0, lay_i, l1_pair)
             loss_giou = loss_giou.index_add(0, lay_i, gi_pair)
 

@@ -45,6 +45,15 @@ def hip_lib():
     return _lib
 
 
+@pytest.fixture(scope="session")
+def clip_lib():
+    """libclip_ops_hip.so (fused small-tensor chains of the train step); built on demand."""
+    from memotr_amd.build import build_clip_lib
+    build_clip_lib()
+    from memotr_amd import _clip_lib
+    return _clip_lib
+
+
 def has_gpu():
     import torch
     return torch.cuda.is_available()

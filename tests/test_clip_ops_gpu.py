@@ -1,0 +1,142 @@
+"""GPU: the fused criterion kernels (include/clip_ops_hip.h) against the element-wise torch formulation of the same
+reference formulas (models/matcher.py:83-121, models/criterion.py:417-467 of the reference), values and gradients."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu(clip_lib):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def rand_boxes(*shape, gen):
+    c = torch.rand(*shape, 2, generator=gen) * 0.6 + 0.2
+    wh = torch.rand(*shape, 2, generator=gen) * 0.3 + 0.02
+    return torch.cat((c, wh), -1)
+
+
+@pytest.mark.parametrize("n_layers,B,Q,Nq,K,T", [(6, 1, 300, 310, 1, 10), (3, 2, 40, 57, 8, 7), (1, 1, 5, 5, 1, 1),
+                                                 (6, 1, 300, 300, 1, 0)])
+def test_match_cost_equals_the_stacked_torch_cost(n_layers, B, Q, Nq, K, T):
+    from memotr_amd.functions import clip_ops
+    from memotr_amd.models.matcher import HungarianMatcher
+    g = torch.Generator().manual_seed(n_layers * 100 + T)
+    logits = (torch.randn(n_layers, B, Nq, K, generator=g) * 3).cuda()
+    boxes = rand_boxes(n_layers, B, Nq, gen=g).cuda()
+    gt_labels = torch.randint(0, K, (T,), generator=g).cuda()
+    gt_boxes = rand_boxes(T, gen=g).cuda()
+    m = HungarianMatcher(cost_class=2.0, cost_bbox=5.0, cost_giou=2.0)
+    for b in range(B):
+        lg, bx = logits[:, b, :Q], boxes[:, b, :Q]               # strided views, as the criterion passes them
+        got = clip_ops.match_cost(lg, bx, gt_labels, gt_boxes, 2.0, 5.0, 2.0)
+        want = m.cost_matrix_stacked(lg, bx, gt_labels, gt_boxes)
+        assert got.shape == want.shape == (n_layers, Q, T)
+        torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+
+
+def test_match_cost_keeps_the_assignment_of_the_torch_cost():
+    from scipy.optimize import linear_sum_assignment
+    from memotr_amd.functions import clip_ops
+    from memotr_amd.models.matcher import HungarianMatcher
+    g = torch.Generator().manual_seed(5)
+    logits = (torch.randn(6, 1, 300, 1, generator=g) * 2).cuda()
+    boxes = rand_boxes(6, 1, 300, gen=g).cuda()
+    gt_labels = torch.zeros(12, dtype=torch.long).cuda()
+    gt_boxes = rand_boxes(12, gen=g).cuda()
+    got = clip_ops.match_cost(logits[:, 0], boxes[:, 0], gt_labels, gt_boxes, 2.0, 5.0, 2.0).cpu().numpy()
+    want = HungarianMatcher(2.0, 5.0, 2.0).cost_matrix_stacked(logits[:, 0], boxes[:, 0], gt_labels, gt_boxes).cpu().numpy()
+    for l in range(6):
+        assert [list(x) for x in linear_sum_assignment(got[l])] == [list(x) for x in linear_sum_assignment(want[l])]
+
+
+@pytest.mark.parametrize("weighted,indexed", [(False, True), (True, True), (False, False)])
+def test_pair_box_loss_values_and_gradients(weighted, indexed):
+    from memotr_amd.functions import clip_ops
+    g = torch.Generator().manual_seed(11)
+    n_layers, B, Nq, n = 6, 2, 310, 64
+    boxes = rand_boxes(n_layers, B, Nq, gen=g).cuda()
+    flat = torch.randperm(n_layers * Nq, generator=g)[:n]        # distinct (layer, query) pairs
+    lay, q = (flat // Nq).cuda(), (flat % Nq).cuda()
+    tgt = rand_boxes(9 if indexed else n, gen=g).cuda()
+    gidx = torch.randint(0, 9, (n,), generator=g).cuda() if indexed else None
+    w = (torch.rand(n, generator=g) > 0.3).float().cuda() if weighted else None
+    up = torch.randn(2, n, generator=g).cuda()
+    res = {}
+    for name, fn in (("kernel", clip_ops.pair_box_loss), ("torch", clip_ops.pair_box_loss_reference)):
+        x = boxes.clone().requires_grad_(True)
+        l1, gl = fn(x, lay, q, 1, tgt, gidx, w)
+        (l1 * up[0] + gl * up[1]).sum().backward()
+        res[name] = (l1.detach(), gl.detach(), x.grad)
+    for a, b_, what in zip(res["kernel"], res["torch"], ("l1", "giou loss", "gradient")):
+        torch.testing.assert_close(a, b_, rtol=2e-5, atol=2e-6, msg=lambda m, what=what: f"{what}: {m}")
+    assert float(res["kernel"][2][:, 0].abs().max()) == 0.0      # batch element 0 was not addressed
+
+
+def test_pair_box_loss_edge_cases():
+    """Disjoint boxes (zero intersection: the clamp's sub-gradient), nested boxes and an exact match."""
+    from memotr_amd.functions import clip_ops
+    boxes = torch.tensor([[[[0.2, 0.2, 0.1, 0.1], [0.5, 0.5, 0.4, 0.4], [0.5, 0.5, 0.2, 0.2], [0.3, 0.6, 0.2, 0.1]]]]).cuda()
+    tgt = torch.tensor([[0.7, 0.7, 0.1, 0.1], [0.5, 0.5, 0.1, 0.1], [0.5, 0.5, 0.2, 0.2], [0.3, 0.6, 0.25, 0.1]]).cuda()
+    lay = torch.zeros(4, dtype=torch.long).cuda()
+    q = torch.arange(4).cuda()
+    res = {}
+    for name, fn in (("kernel", clip_ops.pair_box_loss), ("torch", clip_ops.pair_box_loss_reference)):
+        x = boxes.clone().requires_grad_(True)
+        l1, gl = fn(x, lay, q, 0, tgt)
+        (l1 + 2 * gl).sum().backward()
+        res[name] = (l1.detach(), gl.detach(), x.grad)
+    torch.testing.assert_close(res["kernel"][0], res["torch"][0], rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(res["kernel"][1], res["torch"][1], rtol=1e-5, atol=1e-6)
+    # the exact match (pair 2) sits on max/min ties, where torch halves the sub-gradient: rows 0, 1, 3 compared
+    torch.testing.assert_close(res["kernel"][2][0, 0, [0, 1, 3]], res["torch"][2][0, 0, [0, 1, 3]], rtol=2e-5, atol=2e-6)
+    assert torch.isfinite(res["kernel"][2]).all()
+
+
+@pytest.mark.parametrize("n_layers,B,Nq,n_q,K", [(6, 1, 320, 310, 1), (6, 2, 320, 303, 8), (1, 1, 7, 7, 3)])
+def test_focal_loss_per_layer_values_and_gradients(n_layers, B, Nq, n_q, K):
+    from memotr_amd.functions import clip_ops
+    g = torch.Generator().manual_seed(K * 10 + B)
+    logits = (torch.randn(n_layers, B, Nq, K, generator=g) * 4).cuda()
+    logits[0, 0, 0, 0] = 40.0            # saturated either way
+    logits[-1, -1, 1, 0] = -40.0
+    labels = torch.randint(0, K + 1, (n_layers, n_q), generator=g).cuda()
+    up = torch.randn(n_layers, generator=g).cuda()
+    res = {}
+    for name, fn in (("kernel", clip_ops.focal_loss_per_layer), ("torch", clip_ops.focal_loss_per_layer_reference)):
+        x = logits.clone().requires_grad_(True)
+        loss = fn(x[:, B - 1, :n_q], labels)
+        (loss * up).sum().backward()
+        res[name] = (loss.detach(), x.grad)
+    torch.testing.assert_close(res["kernel"][0], res["torch"][0], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(res["kernel"][1], res["torch"][1], rtol=1e-4, atol=1e-6)
+    again = clip_ops.focal_loss_per_layer(logits[:, B - 1, :n_q], labels)
+    assert torch.equal(again, res["kernel"][0])                  # fixed-order reduction: run-to-run identical
+
+
+def test_criterion_with_and_without_the_kernels(monkeypatch):
+    """One synthetic clip step of the small model: identical matching, losses within float rounding."""
+    from memotr_amd.configs import dancetrack_config
+    from memotr_amd.engine import clip_forward_backward, clip_to_device, make_synthetic_clip
+    from memotr_amd.models import build_model
+    from memotr_amd.models.criterion import build as build_criterion
+    cfg = dancetrack_config(DEVICE="cuda", AVAILABLE_GPUS="0", NUM_ENC_LAYERS=1, NUM_DEC_LAYERS=3, AUX_LOSS_WEIGHT=[1.0, 1.0])
+    torch.manual_seed(3)
+    model = build_model(cfg).train()
+    batch = clip_to_device(make_synthetic_clip(3, 128, 160, 5, seed=2), torch.device("cuda"))
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MEMOTR_FUSED_CLIP_OPS", flag)
+        monkeypatch.setenv("MEMOTR_DECODER_GRAPHS", "0")
+        model.zero_grad()
+        loss, loss_dict = clip_forward_backward(model, build_criterion(cfg), batch, torch.device("cuda"))
+        out[flag] = (float(loss.detach()), {k: float(v.detach()) for k, v in loss_dict.items()},
+                     {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+    assert out["1"][0] == pytest.approx(out["0"][0], rel=1e-5)
+    for k, v in out["0"][1].items():
+        assert out["1"][1][k] == pytest.approx(v, rel=1e-4, abs=1e-6), k
+    for n, gref in out["0"][2].items():
+        err = float((out["1"][2][n] - gref).norm()) / (float(gref.norm()) + 1e-8)
+        assert err < 2e-3, (n, err)
