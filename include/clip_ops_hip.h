@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define CLIPOPS_ABI_VERSION 1
+#define CLIPOPS_ABI_VERSION 2
 
 int clipops_abi_version(void);
 const char *clipops_last_error(void);
@@ -47,6 +47,11 @@ int clipops_pair_box_loss_bwd_f32(const float *boxes, const int64_t *lay, const 
                                   int n, const float *grad_l1, const float *grad_giou, float *grad_boxes,
                                   void *stream);
 
+/* IoU of n box pairs, no gradient (reference models/criterion.py:241-262, the `iou` field of the tracks):
+ * iou[i] = IoU(xyxy(boxes[i]), xyxy(tgt_boxes[gidx[i]]))  (gidx == NULL: row i); boxes (n,4) cxcywh contiguous. */
+int clipops_pair_iou_f32(const float *boxes, const float *tgt_boxes, const int64_t *gidx, int n, float *iou,
+                         void *stream);
+
 /* Sigmoid focal loss of stacked layers (reference models/criterion.py:442-467, RetinaNet form): per layer l
  *   loss[l] = sum_q mean_k  a_t * ce * (1 - p_t)^gamma,   target one-hot of labels[l,q] (label == K: background).
  * logits element (l,q,k) at logits[l*sl + q*sq + k]; labels (n_layers,Nq) int64 contiguous; loss (n_layers).
@@ -56,6 +61,26 @@ int clipops_focal_fwd_f32(const float *logits, long sl, long sq, const int64_t *
 /* grad_logits (n_layers,Nq,K) contiguous = grad_loss[l] * d loss[l] / d logit. */
 int clipops_focal_bwd_f32(const float *logits, long sl, long sq, const int64_t *labels, int n_layers, int Nq, int K,
                           float alpha, float gamma, const float *grad_loss, float *grad_logits, void *stream);
+
+/* Sine embedding of box coordinates (reference models/utils.py:78-85, `pos_to_pos_embed`): pos (n,K) ->
+ * out (n, K*F),  out[i, k*F + j] = (j even ? sin : cos)((pos[i,k] * scale) / dim_t[j]);  dim_t (F) is the
+ * temperature ladder the caller computed once (passed in so that both sides use the same floats). */
+int clipops_sine_embed_fwd_f32(const float *pos, const float *dim_t, long n, int K, int F, float scale, float *out,
+                               void *stream);
+/* grad_pos (n,K) = sum_j grad_out[i, k*F + j] * d out / d pos. */
+int clipops_sine_embed_bwd_f32(const float *pos, const float *dim_t, long n, int K, int F, float scale,
+                               const float *grad_out, float *grad_pos, void *stream);
+
+/* logit with both odds clamped (reference utils/utils.py:61-74, `inverse_sigmoid`), n elements:
+ *   y = log(clamp(x, eps, 1) / clamp(1 - x, eps, 1));  the backward applies torch's clamp masks. */
+int clipops_inverse_sigmoid_fwd_f32(const float *x, long n, float eps, float *y, void *stream);
+int clipops_inverse_sigmoid_bwd_f32(const float *x, const float *grad_y, long n, float eps, float *grad_x, void *stream);
+
+/* Iterative box refinement of the decoder (reference models/deformable_decoder.py:139-149, 4-d references):
+ *   out = sigmoid(delta + inverse_sigmoid(ref)), n elements.  Backward from the saved `out`; grad_ref may be NULL. */
+int clipops_refine_boxes_fwd_f32(const float *delta, const float *ref, long n, float eps, float *out, void *stream);
+int clipops_refine_boxes_bwd_f32(const float *out, const float *ref, const float *grad_out, long n, float eps,
+                                 float *grad_delta, float *grad_ref, void *stream);
 
 #ifdef __cplusplus
 }

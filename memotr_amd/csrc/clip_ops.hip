@@ -123,6 +123,22 @@ __global__ __launch_bounds__(256) void pair_box_loss_fwd_kernel(const float *__r
     gl[i] = g;
 }
 
+__global__ __launch_bounds__(256) void pair_iou_kernel(const float *__restrict__ boxes, const float *__restrict__ tgt,
+                                                      const int64_t *__restrict__ gidx, int n,
+                                                      float *__restrict__ iou) {
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *pb = boxes + (long)i * 4;
+    const float *tb = tgt + (gidx ? gidx[i] : (long)i) * 4;
+    const Box a = to_xyxy(pb[0], pb[1], pb[2], pb[3]), b = to_xyxy(tb[0], tb[1], tb[2], tb[3]);
+    const float iw = fmaxf(fminf(a.x2, b.x2) - fmaxf(a.x1, b.x1), 0.f);
+    const float ih = fmaxf(fminf(a.y2, b.y2) - fmaxf(a.y1, b.y1), 0.f);
+    const float inter = iw * ih;
+    const float uni = (a.x2 - a.x1) * (a.y2 - a.y1) + (b.x2 - b.x1) * (b.y2 - b.y1) - inter;
+    iou[i] = inter / uni;
+}
+
 // d max(a,b)/da and d min(a,b)/da with torch's tie rule (half each)
 __device__ __forceinline__ float dmax_a(float a, float b) { return a > b ? 1.f : (a == b ? 0.5f : 0.f); }
 __device__ __forceinline__ float dmin_a(float a, float b) { return a < b ? 1.f : (a == b ? 0.5f : 0.f); }
@@ -244,6 +260,90 @@ __global__ __launch_bounds__(256) void focal_bwd_kernel(const float *__restrict_
     }
 }
 
+// ----------------------------------------------------------------------------------------
+// decoder glue: sine embedding of the anchors, clamped logit, box refinement
+// ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sine_embed_fwd_kernel(const float *__restrict__ pos,
+                                                            const float *__restrict__ dim_t, long n, int K, int F,
+                                                            float scale, float *__restrict__ out) {
+#pragma clang fp contract(off)
+    const long total = n * K * F;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(i % F);
+        const long ik = i / F;                      // = row * K + k
+        const float e = (pos[ik] * scale) / dim_t[j];
+        out[i] = (j & 1) ? cosf(e) : sinf(e);
+    }
+}
+
+// one wavefront per (row, coordinate): the F terms of its gradient, summed in a fixed order
+__global__ __launch_bounds__(256) void sine_embed_bwd_kernel(const float *__restrict__ pos,
+                                                            const float *__restrict__ dim_t, long n, int K, int F,
+                                                            float scale, const float *__restrict__ g,
+                                                            float *__restrict__ gpos) {
+    const int lane = threadIdx.x & 63;
+    const long waves = ((long)gridDim.x * blockDim.x) >> 6;
+    for (long ik = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; ik < n * K; ik += waves) {
+        const float ps = pos[ik] * scale;
+        float acc = 0.f;
+        for (int j = lane; j < F; j += 64) {
+            const float e = ps / dim_t[j];
+            const float d = (j & 1) ? -sinf(e) : cosf(e);
+            acc += (g[ik * F + j] * d) / dim_t[j];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (lane == 0) gpos[ik] = acc * scale;
+    }
+}
+
+__device__ __forceinline__ float clamp_keep_nan(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+__device__ __forceinline__ float inv_sigmoid(float x, float eps) {
+    return logf(clamp_keep_nan(x, eps, 1.f) / clamp_keep_nan(1.f - x, eps, 1.f));
+}
+
+// d inverse_sigmoid / dx with torch's clamp(min, max) masks (the gradient passes where min <= v <= max)
+__device__ __forceinline__ float inv_sigmoid_grad(float x, float eps) {
+    const float u = 1.f - x;
+    const float x1 = clamp_keep_nan(x, eps, 1.f), x2 = clamp_keep_nan(u, eps, 1.f);
+    const float a = (x >= eps && x <= 1.f) ? 1.f / x1 : 0.f;
+    const float b = (u >= eps && u <= 1.f) ? 1.f / x2 : 0.f;
+    return a + b;
+}
+
+__global__ __launch_bounds__(256) void inverse_sigmoid_fwd_kernel(const float *__restrict__ x, long n, float eps,
+                                                                 float *__restrict__ y) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        y[i] = inv_sigmoid(x[i], eps);
+}
+
+__global__ __launch_bounds__(256) void inverse_sigmoid_bwd_kernel(const float *__restrict__ x,
+                                                                 const float *__restrict__ g, long n, float eps,
+                                                                 float *__restrict__ gx) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        gx[i] = g[i] * inv_sigmoid_grad(x[i], eps);
+}
+
+__global__ __launch_bounds__(256) void refine_boxes_fwd_kernel(const float *__restrict__ delta,
+                                                              const float *__restrict__ ref, long n, float eps,
+                                                              float *__restrict__ out) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = sigmoidf(delta[i] + inv_sigmoid(ref[i], eps));
+}
+
+__global__ __launch_bounds__(256) void refine_boxes_bwd_kernel(const float *__restrict__ out,
+                                                              const float *__restrict__ ref,
+                                                              const float *__restrict__ g, long n, float eps,
+                                                              float *__restrict__ gdelta, float *__restrict__ gref) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float y = out[i];
+        const float gs = (g[i] * (1.f - y)) * y;          // sigmoid backward
+        gdelta[i] = gs;
+        if (gref) gref[i] = gs * inv_sigmoid_grad(ref[i], eps);
+    }
+}
+
 int grid_for(long total) {
     long g = (total + 255) / 256;
     if (g < 1) g = 1;
@@ -295,6 +395,16 @@ int clipops_pair_box_loss_bwd_f32(const float *boxes, const int64_t *lay, const 
     return check_launch("pair_box_loss_bwd_kernel");
 }
 
+int clipops_pair_iou_f32(const float *boxes, const float *tgt_boxes, const int64_t *gidx, int n, float *iou,
+                         void *stream) {
+    if (n < 0) return fail(1, "clipops_pair_iou_f32: negative count");
+    if (n == 0) { g_err[0] = 0; return 0; }
+    if (!boxes || !tgt_boxes || !iou) return fail(1, "clipops_pair_iou_f32: null pointer");
+    hipLaunchKernelGGL(pair_iou_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, boxes, tgt_boxes,
+                       gidx, n, iou);
+    return check_launch("pair_iou_kernel");
+}
+
 int clipops_focal_fwd_f32(const float *logits, long sl, long sq, const int64_t *labels, int n_layers, int Nq, int K,
                           float alpha, float gamma, float *loss, void *stream) {
     if (n_layers < 0 || Nq < 0 || K <= 0) return fail(1, "clipops_focal_fwd_f32: bad dimension");
@@ -313,6 +423,63 @@ int clipops_focal_bwd_f32(const float *logits, long sl, long sq, const int64_t *
     hipLaunchKernelGGL(focal_bwd_kernel, dim3(grid_for((long)n_layers * Nq * K)), dim3(256), 0, (hipStream_t)stream,
                        logits, sl, sq, labels, n_layers, Nq, K, alpha, gamma, grad_loss, grad_logits);
     return check_launch("focal_bwd_kernel");
+}
+
+int clipops_sine_embed_fwd_f32(const float *pos, const float *dim_t, long n, int K, int F, float scale, float *out,
+                               void *stream) {
+    if (n < 0 || K <= 0 || F <= 0) return fail(1, "clipops_sine_embed_fwd_f32: bad dimension");
+    if (n == 0) { g_err[0] = 0; return 0; }
+    if (!pos || !dim_t || !out) return fail(1, "clipops_sine_embed_fwd_f32: null pointer");
+    hipLaunchKernelGGL(sine_embed_fwd_kernel, dim3(grid_for(n * K * F)), dim3(256), 0, (hipStream_t)stream, pos, dim_t,
+                       n, K, F, scale, out);
+    return check_launch("sine_embed_fwd_kernel");
+}
+
+int clipops_sine_embed_bwd_f32(const float *pos, const float *dim_t, long n, int K, int F, float scale,
+                               const float *grad_out, float *grad_pos, void *stream) {
+    if (n < 0 || K <= 0 || F <= 0) return fail(1, "clipops_sine_embed_bwd_f32: bad dimension");
+    if (n == 0) { g_err[0] = 0; return 0; }
+    if (!pos || !dim_t || !grad_out || !grad_pos) return fail(1, "clipops_sine_embed_bwd_f32: null pointer");
+    hipLaunchKernelGGL(sine_embed_bwd_kernel, dim3(grid_for(n * K * 64)), dim3(256), 0, (hipStream_t)stream, pos,
+                       dim_t, n, K, F, scale, grad_out, grad_pos);
+    return check_launch("sine_embed_bwd_kernel");
+}
+
+int clipops_inverse_sigmoid_fwd_f32(const float *x, long n, float eps, float *y, void *stream) {
+    if (n < 0) return fail(1, "clipops_inverse_sigmoid_fwd_f32: negative count");
+    if (n == 0) { g_err[0] = 0; return 0; }
+    if (!x || !y) return fail(1, "clipops_inverse_sigmoid_fwd_f32: null pointer");
+    hipLaunchKernelGGL(inverse_sigmoid_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, n, eps, y);
+    return check_launch("inverse_sigmoid_fwd_kernel");
+}
+
+int clipops_inverse_sigmoid_bwd_f32(const float *x, const float *grad_y, long n, float eps, float *grad_x,
+                                    void *stream) {
+    if (n < 0) return fail(1, "clipops_inverse_sigmoid_bwd_f32: negative count");
+    if (n == 0) { g_err[0] = 0; return 0; }
+    if (!x || !grad_y || !grad_x) return fail(1, "clipops_inverse_sigmoid_bwd_f32: null pointer");
+    hipLaunchKernelGGL(inverse_sigmoid_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, grad_y, n,
+                       eps, grad_x);
+    return check_launch("inverse_sigmoid_bwd_kernel");
+}
+
+int clipops_refine_boxes_fwd_f32(const float *delta, const float *ref, long n, float eps, float *out, void *stream) {
+    if (n < 0) return fail(1, "clipops_refine_boxes_fwd_f32: negative count");
+    if (n == 0) { g_err[0] = 0; return 0; }
+    if (!delta || !ref || !out) return fail(1, "clipops_refine_boxes_fwd_f32: null pointer");
+    hipLaunchKernelGGL(refine_boxes_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, delta, ref, n,
+                       eps, out);
+    return check_launch("refine_boxes_fwd_kernel");
+}
+
+int clipops_refine_boxes_bwd_f32(const float *out, const float *ref, const float *grad_out, long n, float eps,
+                                 float *grad_delta, float *grad_ref, void *stream) {
+    if (n < 0) return fail(1, "clipops_refine_boxes_bwd_f32: negative count");
+    if (n == 0) { g_err[0] = 0; return 0; }
+    if (!out || !ref || !grad_out || !grad_delta) return fail(1, "clipops_refine_boxes_bwd_f32: null pointer");
+    hipLaunchKernelGGL(refine_boxes_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, out, ref,
+                       grad_out, n, eps, grad_delta, grad_ref);
+    return check_launch("refine_boxes_bwd_kernel");
 }
 
 }  // extern "C"

@@ -111,6 +111,26 @@ def pair_box_loss_reference(boxes_all, lay, qidx, b, tgt_boxes, gidx=None, weigh
     return l1, gl
 
 
+def pair_iou(boxes: torch.Tensor, tgt_boxes: torch.Tensor, gidx: torch.Tensor = None) -> torch.Tensor:
+    """IoU of cxcywh boxes[i] with tgt_boxes[gidx[i]] (or tgt_boxes[i]); no gradient (the tracks' ``iou`` field only
+    feeds threshold comparisons in the query updater)."""
+    boxes, tgt_boxes = boxes.detach().contiguous(), tgt_boxes.contiguous()
+    n = boxes.shape[0]
+    out = torch.empty((n,), dtype=torch.float32, device=boxes.device)
+    L = _lib()
+    L.check(L.lib.clipops_pair_iou_f32(boxes.data_ptr(), tgt_boxes.data_ptr(), None if gidx is None else
+                                       gidx.contiguous().data_ptr(), n, out.data_ptr(), _stream(boxes)),
+            "clipops_pair_iou_f32")
+    return out
+
+
+def pair_iou_reference(boxes, tgt_boxes, gidx=None):
+    from ..models.criterion import paired_iou
+    from ..utils.box_ops import box_cxcywh_to_xyxy
+    tb = tgt_boxes if gidx is None else tgt_boxes[gidx]
+    return paired_iou(box_cxcywh_to_xyxy(boxes), box_cxcywh_to_xyxy(tb))
+
+
 # --------------------------------------------------------------------------------------------------------------
 # focal loss of stacked layers (models/criterion.py of the reference, :442-467)
 # --------------------------------------------------------------------------------------------------------------
@@ -151,3 +171,92 @@ def focal_loss_per_layer_reference(logits, labels, alpha: float = 0.25, gamma: f
     K = logits.shape[-1]
     one_hot = F.one_hot(labels, K + 1)[..., :-1].to(logits.dtype)
     return sigmoid_focal_loss_per_layer(logits, one_hot, alpha, gamma)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# decoder glue: sine embedding of the anchors, clamped logit, box refinement
+# --------------------------------------------------------------------------------------------------------------
+class _SineEmbed(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pos, dim_t, scale):
+        K, F_ = pos.shape[-1], dim_t.shape[0]
+        n = pos.numel() // K
+        out = torch.empty(pos.shape[:-1] + (K * F_,), dtype=torch.float32, device=pos.device)
+        L = _lib()
+        L.check(L.lib.clipops_sine_embed_fwd_f32(pos.data_ptr(), dim_t.data_ptr(), n, K, F_, scale, out.data_ptr(),
+                                                 _stream(pos)), "clipops_sine_embed_fwd_f32")
+        ctx.save_for_backward(pos, dim_t)
+        ctx.scale = scale
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        pos, dim_t = ctx.saved_tensors
+        K, F_ = pos.shape[-1], dim_t.shape[0]
+        grad = torch.empty_like(pos)
+        L = _lib()
+        L.check(L.lib.clipops_sine_embed_bwd_f32(pos.data_ptr(), dim_t.data_ptr(), pos.numel() // K, K, F_, ctx.scale,
+                                                 g.contiguous().data_ptr(), grad.data_ptr(), _stream(pos)),
+                "clipops_sine_embed_bwd_f32")
+        return grad, None, None
+
+
+def sine_embed(pos: torch.Tensor, dim_t: torch.Tensor, scale: float) -> torch.Tensor:
+    """(..., K) -> (..., K * F): out[..., k*F + j] = (sin | cos)(pos[..., k] * scale / dim_t[j]), even j sin, odd j cos."""
+    return _SineEmbed.apply(pos.contiguous(), dim_t, float(scale))
+
+
+class _InverseSigmoid(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, eps):
+        y = torch.empty_like(x)
+        L = _lib()
+        L.check(L.lib.clipops_inverse_sigmoid_fwd_f32(x.data_ptr(), x.numel(), eps, y.data_ptr(), _stream(x)),
+                "clipops_inverse_sigmoid_fwd_f32")
+        ctx.save_for_backward(x)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, = ctx.saved_tensors
+        gx = torch.empty_like(x)
+        L = _lib()
+        L.check(L.lib.clipops_inverse_sigmoid_bwd_f32(x.data_ptr(), g.contiguous().data_ptr(), x.numel(), ctx.eps,
+                                                      gx.data_ptr(), _stream(x)), "clipops_inverse_sigmoid_bwd_f32")
+        return gx, None
+
+
+def inverse_sigmoid(x: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    return _InverseSigmoid.apply(x.contiguous(), float(eps))
+
+
+class _RefineBoxes(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, delta, ref, eps):
+        out = torch.empty_like(delta)
+        L = _lib()
+        L.check(L.lib.clipops_refine_boxes_fwd_f32(delta.data_ptr(), ref.data_ptr(), delta.numel(), eps, out.data_ptr(),
+                                                   _stream(delta)), "clipops_refine_boxes_fwd_f32")
+        ctx.save_for_backward(out, ref)
+        ctx.eps = eps
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        out, ref = ctx.saved_tensors
+        gd = torch.empty_like(out)
+        gr = torch.empty_like(out) if ctx.needs_input_grad[1] else None
+        L = _lib()
+        L.check(L.lib.clipops_refine_boxes_bwd_f32(out.data_ptr(), ref.data_ptr(), g.contiguous().data_ptr(),
+                                                   out.numel(), ctx.eps, gd.data_ptr(),
+                                                   None if gr is None else gr.data_ptr(), _stream(out)),
+                "clipops_refine_boxes_bwd_f32")
+        return gd, gr, None
+
+
+def refine_boxes(delta: torch.Tensor, ref: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """sigmoid(delta + inverse_sigmoid(ref)) for same-shaped tensors."""
+    if delta.shape != ref.shape:
+        raise RuntimeError("refine_boxes: delta and ref must have the same shape")
+    return _RefineBoxes.apply(delta.contiguous(), ref.contiguous(), float(eps))

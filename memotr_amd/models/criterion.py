@@ -29,6 +29,18 @@ _LOSS_KEYS = ("box_l1_loss", "box_giou_loss", "label_focal_loss")
 
 
 
+def batch_item(x: torch.Tensor, b: int) -> torch.Tensor:
+    """x[b]; a view without a Select node when the batch is a single clip (its backward would be a zero-fill + a copy
+    per use)."""
+    return x.squeeze(0) if x.shape[0] == 1 else x[b]
+
+
+def rows_of(x: torch.Tensor, b: int, idx: torch.Tensor) -> torch.Tensor:
+    """x[b][idx] for a 1-d index: index_select, whose backward is one index_add (advanced indexing differentiates
+    through a sort-based accumulate, ~7 kernels for a handful of rows)."""
+    return batch_item(x, b).index_select(0, idx)
+
+
 def upload(values, dtype, device):
     """Host list -> device tensor without stalling the host: a pageable-memory copy blocks until everything
     already queued on the stream has run, a pinned-memory one is queued like a kernel."""
@@ -56,7 +68,7 @@ class ClipCriterion:
         self.hidden_dim = hidden_dim
         self.merge_det_track_layer = merge_det_track_layer
         self.gt_trackinstances_list = None      # [clip_len][B]
-        self.loss: Dict[str, torch.Tensor] = {}
+        self._acc: torch.Tensor = None          # (3 losses, main | aux) running sums of the clip
         self.log: Dict[str, torch.Tensor] = {}
         self.n_gts: List[int] = []
 
@@ -79,8 +91,16 @@ class ClipCriterion:
             self.frame_weights = self.frame_weights + [1.0] * (clip_len - len(self.frame_weights))
         self.n_gts = []
         self.log = {}
-        keys = _LOSS_KEYS + tuple("aux_" + k for k in _LOSS_KEYS) if self.aux_loss else _LOSS_KEYS
-        self.loss = {k: torch.zeros((), device=device) for k in keys}
+        self._acc = torch.zeros((len(_LOSS_KEYS), 2 if self.aux_loss else 1), device=device)
+
+    @property
+    def loss(self) -> Dict[str, torch.Tensor]:
+        """The clip's running loss sums by name (the reference's ``self.loss`` dict, criterion.py:86-102).  They are
+        kept as ONE (3, 2) tensor -- a frame adds ``per-layer losses @ weights`` to it, one small product instead
+        of six select / scale / add chains (and their zero-fill + copy backward nodes) per frame."""
+        cols = self._acc.t().reshape(-1).unbind(0)            # main losses first, then the aux ones
+        keys = _LOSS_KEYS + tuple("aux_" + k for k in _LOSS_KEYS) if self._acc.shape[1] == 2 else _LOSS_KEYS
+        return dict(zip(keys, cols))
 
     def get_sum_loss_dict(self, loss_dict: dict):
         def w(name):
@@ -129,8 +149,12 @@ class ClipCriterion:
         layers = [model_outputs] + (list(model_outputs["aux_outputs"]) if self.aux_loss else [])
         n_layers = len(layers)
         early = [li > 0 and (li - 1) < self.merge_det_track_layer for li in range(n_layers)]
-        logits_all = torch.stack([o["pred_logits"] for o in layers])      # (n_layers, B, Nq, K)
-        boxes_all = torch.stack([o["pred_bboxes"] for o in layers])       # (n_layers, B, Nq, 4)
+        if self.aux_loss and "pred_logits_all" in model_outputs:          # stacks in decoder order: main layer last
+            logits_all = torch.roll(model_outputs["pred_logits_all"], 1, 0)
+            boxes_all = torch.roll(model_outputs["pred_bboxes_all"], 1, 0)
+        else:
+            logits_all = torch.stack([o["pred_logits"] for o in layers])  # (n_layers, B, Nq, K)
+            boxes_all = torch.stack([o["pred_bboxes"] for o in layers])   # (n_layers, B, Nq, 4)
 
         # ---- device side: ownership of ground truths + stacked cost tensors, then one transfer ----
         payload, n_gt_list = [], []
@@ -245,13 +269,13 @@ class ClipCriterion:
                                 num_classes=self.num_classes)
             nt.ids = gt.ids[gt_idx]
             nt.matched_idx = gt_idx
-            queries = model_outputs["aux_outputs"][-1]["queries"][b][q_idx]
+            queries = rows_of(model_outputs["aux_outputs"][-1]["queries"], b, q_idx)
             nt.query_embed = queries if self.use_dab else torch.cat(
                 (model_outputs["det_query_embed"][q_idx][:, :self.hidden_dim], queries), dim=-1)
-            nt.ref_pts = model_outputs["last_ref_pts"][b][q_idx]
-            nt.output_embed = model_outputs["outputs"][b][q_idx]
-            nt.boxes = model_outputs["pred_bboxes"][b][q_idx]
-            nt.logits = model_outputs["pred_logits"][b][q_idx]
+            nt.ref_pts = rows_of(model_outputs["last_ref_pts"], b, q_idx)
+            nt.output_embed = rows_of(model_outputs["outputs"], b, q_idx)
+            nt.boxes = rows_of(model_outputs["pred_bboxes"], b, q_idx)
+            nt.logits = rows_of(model_outputs["pred_logits"], b, q_idx)
             nt.iou = torch.zeros((n_main,), dtype=torch.float, device=dev)
             nt = nt.to(dev)
 
@@ -295,11 +319,11 @@ class ClipCriterion:
             free_q = upload([q for q in range(n_det_out) if q not in taken], torch.long, dev)
             d = TrackInstances(hidden_dim=model_outputs["outputs"].shape[-1],
                                num_classes=model_outputs["pred_logits"].shape[-1]).to(dev)
-            d.ref_pts = model_outputs["init_ref_pts"][b][free_q]
-            d.output_embed = model_outputs["outputs"][b][free_q]
-            d.logits = model_outputs["pred_logits"][b][free_q]
-            d.boxes = model_outputs["pred_bboxes"][b][free_q]
-            queries = model_outputs["aux_outputs"][-1]["queries"][b][free_q]
+            d.ref_pts = rows_of(model_outputs["init_ref_pts"], b, free_q)
+            d.output_embed = rows_of(model_outputs["outputs"], b, free_q)
+            d.logits = rows_of(model_outputs["pred_logits"], b, free_q)
+            d.boxes = rows_of(model_outputs["pred_bboxes"], b, free_q)
+            queries = rows_of(model_outputs["aux_outputs"][-1]["queries"], b, free_q)
             d.query_embed = queries if self.use_dab else torch.cat(
                 (model_outputs["det_query_embed"][free_q][:, :self.hidden_dim], queries), dim=-1)
             d.ids = -torch.ones((len(free_q),), dtype=torch.long, device=dev)
@@ -310,27 +334,27 @@ class ClipCriterion:
             # IoU of every track with the ground truth it owns (kept where it owns none)
             tracked_instances[b] = tr = tr.to(dev)
             if len(gt) > 0:
+                iou_of = clip_ops.pair_iou if use_kernels else clip_ops.pair_iou_reference
                 if n_main > 0:
-                    nt.iou = paired_iou(box_cxcywh_to_xyxy(nt.boxes), box_cxcywh_to_xyxy(gt.boxes[nt.matched_idx]))
+                    nt.iou = iou_of(nt.boxes, gt.boxes, nt.matched_idx)
                 if n_tr > 0:
                     has = tr.matched_idx >= 0
-                    iou = paired_iou(box_cxcywh_to_xyxy(tr.boxes), box_cxcywh_to_xyxy(gt.boxes[tr.matched_idx.clamp(min=0)]))
-                    tr.iou = torch.where(has, iou, tr.iou)
+                    tr.iou = torch.where(has, iou_of(tr.boxes, gt.boxes, tr.matched_idx.clamp(min=0)), tr.iou)
             new_tracks.append(nt)
 
         fw = self.frame_weights[frame_idx]
-        self.loss["box_l1_loss"] = self.loss["box_l1_loss"] + loss_l1[0] * fw
-        self.loss["box_giou_loss"] = self.loss["box_giou_loss"] + loss_giou[0] * fw
-        self.loss["label_focal_loss"] = self.loss["label_focal_loss"] + loss_label[0] * fw
-        self.log[f"frame{frame_idx}_box_l1_loss"] = loss_l1[0].detach()
-        self.log[f"frame{frame_idx}_box_giou_loss"] = loss_giou[0].detach()
-        self.log[f"frame{frame_idx}_label_focal_loss"] = loss_label[0].detach()
+        per_layer = torch.stack((loss_l1, loss_giou, loss_label))               # rows in the order of _LOSS_KEYS
+        log = per_layer.detach()
+        self.log[f"frame{frame_idx}_box_l1_loss"] = log[0, 0]
+        self.log[f"frame{frame_idx}_box_giou_loss"] = log[1, 0]
+        self.log[f"frame{frame_idx}_label_focal_loss"] = log[2, 0]
         self.n_gts.append(sum(n_gt_list))
-        if self.aux_loss and n_layers > 1:
-            aw = self._constant(("aux_w", n_layers), self.aux_weights[:n_layers - 1], loss_l1.dtype, dev) * fw
-            self.loss["aux_box_l1_loss"] = self.loss["aux_box_l1_loss"] + (loss_l1[1:] * aw).sum()
-            self.loss["aux_box_giou_loss"] = self.loss["aux_box_giou_loss"] + (loss_giou[1:] * aw).sum()
-            self.loss["aux_label_focal_loss"] = self.loss["aux_label_focal_loss"] + (loss_label[1:] * aw).sum()
+        # column 0: the last decoder layer (x frame weight); column 1: the auxiliary layers (x their weights)
+        cols = [[fw] + [0.0] * (n_layers - 1)]
+        if self._acc.shape[1] == 2:
+            cols.append([0.0] + [w * fw for w in self.aux_weights[:n_layers - 1]])
+        weights = self._constant(("loss_w", n_layers, fw, self._acc.shape[1]), cols, per_layer.dtype, dev)
+        self._acc = self._acc + per_layer @ weights.t()
         return tracked_instances, new_tracks, unmatched
 
     def update_tracked_instances(self, model_outputs: dict, tracked_instances: List[TrackInstances]):
@@ -340,9 +364,9 @@ class ClipCriterion:
         for b, tr in enumerate(tracked_instances):
             n = len(tr)
             if n > 0:
-                tr.boxes = model_outputs["pred_bboxes"][b][nd:nd + n]
-                tr.logits = model_outputs["pred_logits"][b][nd:nd + n]
-                tr.output_embed = model_outputs["outputs"][b][nd:nd + n]
+                tr.boxes = batch_item(model_outputs["pred_bboxes"], b)[nd:nd + n]
+                tr.logits = batch_item(model_outputs["pred_logits"], b)[nd:nd + n]
+                tr.output_embed = batch_item(model_outputs["outputs"], b)[nd:nd + n]
                 tr.matched_idx = torch.zeros((0,), dtype=tr.matched_idx.dtype)
                 tr.labels = torch.zeros((0,), dtype=tr.matched_idx.dtype)
         return tracked_instances

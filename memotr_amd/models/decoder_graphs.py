@@ -30,7 +30,7 @@ from collections import OrderedDict
 import torch
 import torch.nn as nn
 
-from ..utils.utils import inverse_sigmoid
+from ..utils.utils import inverse_sigmoid, refine_boxes
 from .utils import pos_to_pos_embed
 
 BUCKET = 32
@@ -70,7 +70,7 @@ class DecoderLoop(nn.Module):
             query_pos = raw_pos if lid == 0 else self.query_scale(output) * raw_pos
             merge = lid >= self.merge_from
             output = layer(output, query_pos, ref_in, src, self._shapes, self._lsi, query_mask, src_padding_mask, merge)
-            new_ref = (self.bbox_embed[lid](output) + inverse_sigmoid(reference_points)).sigmoid()
+            new_ref = refine_boxes(self.bbox_embed[lid](output), reference_points)
             boxes.append(new_ref)
             if merge:
                 reference_points = new_ref.detach()
@@ -129,7 +129,8 @@ class DecoderGraphs:
 
     def run(self, frame_slot: int, args, shapes, lsi):
         """The decoder loop of frame ``frame_slot`` through its graph (captured on first use); None if capture failed."""
-        key = (frame_slot, tuple(a.shape for a in args), tuple(bool(a.requires_grad) for a in args), id(shapes))
+        key = (frame_slot, tuple(a.shape for a in args), tuple(bool(a.requires_grad) for a in args), id(shapes),
+               os.environ.get("MEMOTR_FUSED_CLIP_OPS", "1"))          # (a capture bakes the kernel choice in)
         slot = self.slots.get(key)
         if slot is None:
             slot = self._capture(args, shapes, lsi)

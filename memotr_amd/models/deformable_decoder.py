@@ -8,7 +8,7 @@ from torch.utils.checkpoint import checkpoint
 
 from ..modules import MSDeformAttn
 from ..modules.attention import self_attention
-from ..utils.utils import inverse_sigmoid
+from ..utils.utils import inverse_sigmoid, refine_boxes
 from .decoder_graphs import DecoderGraphs
 from .mlp import MLP
 from .utils import get_activation_layer, get_clones, pos_to_pos_embed
@@ -108,7 +108,7 @@ class DeformableDecoder(nn.Module):
             if self.bbox_embed is not None:
                 delta = self.bbox_embed[lid](output)
                 if reference_points.shape[-1] == 4:
-                    new_ref = (delta + inverse_sigmoid(reference_points)).sigmoid()
+                    new_ref = refine_boxes(delta, reference_points)
                 else:
                     xy = delta[..., :2] + inverse_sigmoid(reference_points)
                     new_ref = torch.cat((xy, delta[..., 2:]), -1).sigmoid()

@@ -135,12 +135,13 @@ class MeMOTR(nn.Module):
         # (DAB only: without DAB the decoder refines from the 2-d slice of the reference while this head adds the
         # full 4-d inverse sigmoid at level 0, reference models/memotr.py:148-158 -- not the same boxes for tracks)
         reuse = refined is not None and self.use_dab and self.transformer.decoder.bbox_embed is self.bbox_embed
+        per_layer = outputs.unbind(0)          # one backward node for the six uses (a select each: zero-fill + copy)
         for lvl in range(outputs.shape[0]):
-            classes.append(self.class_embed[lvl](outputs[lvl]))
+            classes.append(self.class_embed[lvl](per_layer[lvl]))
             if reuse:
                 continue
             reference = inverse_sigmoid(init_reference if lvl == 0 else inter_references[lvl - 1])
-            box = self.bbox_embed[lvl](outputs[lvl])
+            box = self.bbox_embed[lvl](per_layer[lvl])
             if reference.shape[-1] == 4:
                 box = box + reference
             else:
@@ -159,7 +160,10 @@ class MeMOTR(nn.Module):
         }
         if self.aux_loss:
             res["aux_outputs"] = self.set_aux_loss(classes, boxes, query_mask, inter_queries)
-        res["outputs"] = outputs[-1]
+            # the same predictions as stacks over the decoder layers (last = the main output): the criterion reads
+            # these instead of re-stacking the per-layer views above
+            res["pred_logits_all"], res["pred_bboxes_all"] = classes, boxes
+        res["outputs"] = per_layer[-1]
         return res
 
     @torch.jit.unused
@@ -191,13 +195,14 @@ class MeMOTR(nn.Module):
                                self.hidden_dim if self.use_dab else self.hidden_dim * 2)
 
     def get_reference_points(self, tracks: List[TrackInstances]):
-        det = self.get_det_reference_points().repeat(len(tracks), 1, 1)
+        det = self.get_det_reference_points()
+        det = det[None] if det.dim() == 2 and len(tracks) == 1 else det.repeat(len(tracks), 1, 1)
         if det.shape[-1] == 2:
             det = torch.cat((det, torch.zeros_like(det)), dim=-1)
         return torch.cat((det, self.get_track_reference_points(tracks).to(det.device)), dim=1)
 
     def get_query_embed(self, tracks: List[TrackInstances]):
-        det = self.det_query_embed.repeat(len(tracks), 1, 1)
+        det = self.det_query_embed[None] if len(tracks) == 1 else self.det_query_embed.repeat(len(tracks), 1, 1)
         return torch.cat((det, self.get_track_query_embed(tracks).to(det.device)), dim=1)
 
     def get_query_mask(self, tracks: List[TrackInstances]):

@@ -48,6 +48,9 @@ def pos_to_pos_embed(pos: torch.Tensor, num_pos_feats: int = 64, temperature: in
     """Sine embedding of the last axis: (..., K) -> (..., K * num_pos_feats), sin/cos interleaved
     (models/utils.py:78-85; (n,4) boxes with 128 feats give (n,512))."""
     dim_i = _sine_dims(num_pos_feats, temperature, pos.device)
+    from ..functions import clip_ops
+    if clip_ops.fused(pos) and pos.dtype == torch.float32:
+        return clip_ops.sine_embed(pos, dim_i, scale)      # one kernel instead of eight (and one backward)
     e = (pos * scale)[..., None] / dim_i
     e = torch.stack((e[..., 0::2].sin(), e[..., 1::2].cos()), dim=-1)
     return torch.flatten(e, start_dim=-3)

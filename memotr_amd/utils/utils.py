@@ -44,6 +44,22 @@ def yaml_to_dict(path: str) -> dict:
 
 def inverse_sigmoid(x: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
     """logit with both odds clamped at eps (utils/utils.py:61-74)."""
+    from ..functions import clip_ops
+    if clip_ops.fused(x) and x.dtype == torch.float32:
+        return clip_ops.inverse_sigmoid(x, eps)            # one kernel (and one backward) instead of five (twelve)
+    return inverse_sigmoid_reference(x, eps)
+
+
+def inverse_sigmoid_reference(x: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
     # clamp(clamp(x, 0, 1), min=eps) == clamp(x, eps, 1) and clamp(1 - clamp(x, 0, 1), min=eps) == clamp(1 - x, eps, 1)
     # value for value and gradient mask for gradient mask (eps > 0): one kernel fewer, forward and backward
     return torch.log(x.clamp(min=eps, max=1) / (1 - x).clamp(min=eps, max=1))
+
+
+def refine_boxes(delta: torch.Tensor, reference: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """sigmoid(delta + inverse_sigmoid(reference)): the decoder's iterative box refinement for 4-d references
+    (models/deformable_decoder.py:139-149 of the reference)."""
+    from ..functions import clip_ops
+    if delta.shape == reference.shape and clip_ops.fused(delta, reference) and delta.dtype == torch.float32:
+        return clip_ops.refine_boxes(delta, reference, eps)
+    return (delta + inverse_sigmoid_reference(reference, eps)).sigmoid()

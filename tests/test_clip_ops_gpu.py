@@ -140,3 +140,62 @@ def test_criterion_with_and_without_the_kernels(monkeypatch):
     for n, gref in out["0"][2].items():
         err = float((out["1"][2][n] - gref).norm()) / (float(gref.norm()) + 1e-8)
         assert err < 2e-3, (n, err)
+
+
+def _composite_sine_embed(pos, F_=128, temperature=10000, scale=6.283185307179586):
+    from memotr_amd.models.utils import _sine_dims
+    dim_i = _sine_dims(F_, temperature, pos.device)
+    e = (pos * scale)[..., None] / dim_i
+    e = torch.stack((e[..., 0::2].sin(), e[..., 1::2].cos()), dim=-1)
+    return torch.flatten(e, start_dim=-3)
+
+
+@pytest.mark.parametrize("shape", [(1, 320, 4), (7, 4), (2, 33, 2)])
+def test_sine_embed_values_and_gradient(shape):
+    from memotr_amd.models.utils import pos_to_pos_embed
+    g = torch.Generator().manual_seed(len(shape))
+    pos = torch.rand(*shape, generator=g).cuda()
+    up = torch.randn(*shape[:-1], shape[-1] * 128, generator=g).cuda()
+    res = {}
+    for name, fn in (("kernel", lambda p: pos_to_pos_embed(p, num_pos_feats=128)), ("torch", _composite_sine_embed)):
+        x = pos.clone().requires_grad_(True)
+        y = fn(x)
+        (y * up).sum().backward()
+        res[name] = (y.detach(), x.grad)
+    assert res["kernel"][0].shape == res["torch"][0].shape
+    torch.testing.assert_close(res["kernel"][0], res["torch"][0], rtol=1e-5, atol=2e-6)
+    torch.testing.assert_close(res["kernel"][1], res["torch"][1], rtol=1e-4, atol=1e-4)
+
+
+def test_inverse_sigmoid_and_refine_boxes_values_masks_and_gradients():
+    from memotr_amd.utils.utils import inverse_sigmoid, inverse_sigmoid_reference, refine_boxes
+    g = torch.Generator().manual_seed(9)
+    x = torch.cat((torch.rand(500, generator=g), torch.tensor([0.0, 1.0, 1e-5, 1 - 1e-5, 5e-6, 1 - 5e-6, -0.2, 1.3, 0.5])))
+    x = x.cuda()
+    up = torch.randn(x.shape, generator=g).cuda()
+    res = {}
+    for name, fn in (("kernel", inverse_sigmoid), ("torch", inverse_sigmoid_reference)):
+        v = x.clone().requires_grad_(True)
+        y = fn(v)
+        (y * up).sum().backward()
+        res[name] = (y.detach(), v.grad)
+    torch.testing.assert_close(res["kernel"][0], res["torch"][0], rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(res["kernel"][1], res["torch"][1], rtol=1e-5, atol=1e-6)
+    assert torch.isnan(inverse_sigmoid(torch.tensor([float("nan")]).cuda())).all()
+
+    delta = (torch.randn(2, 40, 4, generator=g) * 2).cuda()
+    ref = torch.rand(2, 40, 4, generator=g).cuda()
+    ref[0, 0] = torch.tensor([0.0, 1.0, 5e-6, 0.5])
+    up = torch.randn(2, 40, 4, generator=g).cuda()
+    res = {}
+    for name in ("kernel", "torch"):
+        d, r = delta.clone().requires_grad_(True), ref.clone().requires_grad_(True)
+        y = refine_boxes(d, r) if name == "kernel" else (d + inverse_sigmoid_reference(r)).sigmoid()
+        (y * up).sum().backward()
+        res[name] = (y.detach(), d.grad, r.grad)
+    for a, b_ in zip(res["kernel"], res["torch"]):
+        torch.testing.assert_close(a, b_, rtol=1e-5, atol=1e-6)
+    # the decoder's use: a detached reference gets no gradient buffer
+    d = delta.clone().requires_grad_(True)
+    refine_boxes(d, ref).sum().backward()
+    assert d.grad is not None
