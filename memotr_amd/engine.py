@@ -168,6 +168,7 @@ def clip_forward_backward(model: nn.Module, criterion, batch: dict, device, use_
         chunks, lazy = None, False
     starts = [sum(chunks[:i]) for i in range(len(chunks))] if chunks is not None else []
     encoded = {}                                   # frame index -> encode result of that frame
+    clip_key = object()                            # identifies this clip's autograd graph to per-clip caches
 
     side = encode_stream(device) if chunks is not None and len(chunks) > 1 else None
     if side is not None:
@@ -191,13 +192,14 @@ def clip_forward_backward(model: nn.Module, criterion, batch: dict, device, use_
         else:
             enc = model(frame=frames(lo, lo + n), stage="encode")
         if n == 1:
-            encoded[lo] = dict(enc, frame_slot=lo)        # the frame's slot for the decoder's hipGraphs
+            encoded[lo] = dict(enc, frame_slot=lo, clip_key=clip_key)   # the frame's slot for the decoder's hipGraphs
             return
         per_frame = {k: (v.split(n_clips, dim=0) if k in ("memory", "valid_ratios", "mask_flatten") else None)
                      for k, v in enc.items()}
         for j in range(n):
             encoded[lo + j] = {k: (per_frame[k][j] if per_frame[k] is not None else v) for k, v in enc.items()}
             encoded[lo + j]["frame_slot"] = lo + j
+            encoded[lo + j]["clip_key"] = clip_key
 
     def set_up():
         tr = TrackInstances.init_tracks(batch=batch, hidden_dim=core.hidden_dim, num_classes=core.num_classes,

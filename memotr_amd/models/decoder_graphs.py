@@ -16,8 +16,8 @@ Constraints handled here:
   * a graphed callable owns its activations: it cannot run twice before its backward.  A clip holds T frames of
     activations at once, so every frame index gets its own capture ("slot");
   * the pyramid geometry is part of the key (multi-scale training re-captures per geometry, LRU-bounded);
-  * parameters are shared by all slots: each graph returns its own parameter gradients and autograd adds them up,
-    so DistributedDataParallel's hooks fire once per parameter as usual.
+  * parameters are shared by all slots and enter a graph as ONE flat tensor (made once per clip): the frames'
+    parameter gradients meet in one add per frame and DistributedDataParallel's hooks fire once per parameter.
 Anything that cannot be captured (CPU tensors, checkpointing, no grad mode mismatch, a capture error) takes the eager
 path -- same arithmetic, kernel by kernel.
 """
@@ -127,7 +127,7 @@ class DecoderGraphs:
         n = max(n_queries, n_det + 1)
         return (n + BUCKET - 1) // BUCKET * BUCKET
 
-    def run(self, frame_slot: int, args, shapes, lsi):
+    def run(self, frame_slot: int, args, shapes, lsi, clip_key=None):
         """The decoder loop of frame ``frame_slot`` through its graph (captured on first use); None if capture failed."""
         key = (frame_slot, tuple(a.shape for a in args), tuple(bool(a.requires_grad) for a in args), id(shapes),
                os.environ.get("MEMOTR_FUSED_CLIP_OPS", "1"))          # (a capture bakes the kernel choice in)
@@ -142,30 +142,51 @@ class DecoderGraphs:
         else:
             self.slots.move_to_end(key)
         fn, params = slot
-        return fn(*args, *params)
+        return fn(*args, self._flat_parameters(params, clip_key))
+
+    def _flat_parameters(self, params, clip_key):
+        """All decoder parameters as ONE tensor, made once per clip and read by the graphs of all its frames.
+
+        A graph returns the gradient of each tensor argument in its own buffer and autograd adds the frames up
+        argument by argument: with ~170 parameter tensors as arguments that was 170 copy / add kernels per frame
+        outside the graphs (850 per train step, ~5 ms).  With one flat argument the frames' gradients meet in four
+        adds, the split back to the parameters happens once per clip (the cat's backward hands out views), and
+        DistributedDataParallel's hooks still fire once per parameter."""
+        cache = self.__dict__.get("_flat")
+        if (clip_key is not None and cache is not None and cache[0] is clip_key and len(cache[1]) == len(params)
+                and all(a is b for a, b in zip(cache[1], params))):
+            return cache[2]
+        flat = torch.cat([p.reshape(-1) for p in params])
+        self.__dict__["_flat"] = (clip_key, params, flat)
+        return flat
 
     def _capture(self, args, shapes, lsi):
-        """Capture ``DecoderLoop`` as a function of (inputs..., parameters...).
+        """Capture ``DecoderLoop`` as a function of (inputs..., flat parameters).
 
-        The parameters travel as ordinary tensor ARGUMENTS (``torch.func.functional_call`` substitutes them): the
-        captured backward then differentiates with respect to fresh leaf tensors only.  Capturing with respect to the
-        live ``nn.Parameter`` objects instead makes autograd reuse their gradient-accumulator nodes, which remember the
-        stream they were created on -- any earlier use of a decoder parameter on the default stream (an eager step, a
-        kept-alive graph) then drags the legacy stream into the capture and hipStreamEndCapture faults.
-        The sample parameters ALIAS the real ones (``p.detach()`` shares storage), so a replay reads the live weights
-        in place: make_graphed_callables skips the refresh copy of an argument whose address equals its placeholder's."""
+        The parameters travel as an ordinary tensor ARGUMENT (``torch.func.functional_call`` substitutes views of
+        it): the captured backward then differentiates with respect to a fresh leaf tensor only.  Capturing with
+        respect to the live ``nn.Parameter`` objects instead makes autograd reuse their gradient-accumulator nodes,
+        which remember the stream they were created on -- any earlier use of a decoder parameter on the default
+        stream (an eager step, a kept-alive graph) then drags the legacy stream into the capture and
+        hipStreamEndCapture faults.  Inside the graph the flat tensor is split into the parameter shapes (views);
+        the split's backward is one concatenation."""
         loop = DecoderLoop(self.decoder, shapes, lsi)
         names, params = zip(*loop.named_parameters())
         if len(names) != sum(1 for _ in loop.named_parameters(remove_duplicate=False)):
             self.failed = True      # a module shared between layers (no box refinement clones): see DecoderLoop
             return None
+        sizes = [p.numel() for p in params]
+        views = [p.shape for p in params]
         n_user = len(args)
 
-        def run(*flat):
-            return torch.func.functional_call(loop, dict(zip(names, flat[n_user:])), tuple(flat[:n_user]))
+        def run(*flat_in):
+            pieces = flat_in[n_user].split(sizes)
+            return torch.func.functional_call(loop, {n: w.view(s) for n, w, s in zip(names, pieces, views)},
+                                              tuple(flat_in[:n_user]))
 
-        sample = tuple(a.detach().clone().requires_grad_(a.requires_grad) for a in args) + \
-            tuple(p.detach().requires_grad_(p.requires_grad) for p in params)
+        with torch.no_grad():
+            flat = torch.cat([p.reshape(-1) for p in params])
+        sample = tuple(a.detach().clone().requires_grad_(a.requires_grad) for a in args) + (flat.requires_grad_(True),)
         try:
             with _thread_local_capture():
                 fn = torch.cuda.make_graphed_callables(run, sample, num_warmup_iters=2, allow_unused_input=True)

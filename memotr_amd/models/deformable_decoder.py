@@ -41,7 +41,7 @@ class DeformableDecoder(nn.Module):
         return g
 
     def _forward_graphed(self, tgt, reference_points, src, spatial_shapes, level_start_index, valid_ratios, query_mask,
-                         src_padding_mask, frame_slot):
+                         src_padding_mask, frame_slot, clip_key=None):
         """The loop below with every iteration replayed from a hipGraph (models/decoder_graphs.py).  Returns None
         when a capture fails; the caller then runs the eager loop."""
         graphs = self.graphs()
@@ -56,7 +56,7 @@ class DeformableDecoder(nn.Module):
         ratios4 = torch.cat([valid_ratios, valid_ratios], -1)[:, None].contiguous()
         query_mask = query_mask.contiguous()
         res = graphs.run(frame_slot, (tgt.contiguous(), reference_points.contiguous(), src, ratios4, query_mask,
-                                      src_padding_mask), spatial_shapes, level_start_index)
+                                      src_padding_mask), spatial_shapes, level_start_index, clip_key)
         if res is None:
             return None
         outs, refs, layer_inputs, boxes = res
@@ -65,18 +65,20 @@ class DeformableDecoder(nn.Module):
         return outs, refs, layer_inputs, boxes
 
     def forward(self, tgt, reference_points, src, src_spatial_shapes, src_level_start_index, src_valid_ratios,
-                query_pos, query_mask, src_padding_mask, frame_slot=None):
+                query_pos, query_mask, src_padding_mask, frame_slot=None, clip_key=None):
         """tgt (B,Nq,C); reference_points (B,Nq,4) in [0,1]; src (B,S,C).
         Returns stacks over layers: outputs (n,B,Nq,C), refined references (n,B,Nq,4), layer inputs (n,B,Nq,C),
         refined boxes with their graph (n,B,Nq,4) or None without box refinement.
         ``frame_slot`` (the frame's index inside its clip, given by the training loop) selects the hipGraph slot the
-        loop is replayed from; without it -- inference, the reference's frame order -- the loop runs eagerly."""
+        loop is replayed from; without it -- inference, the reference's frame order -- the loop runs eagerly.
+        ``clip_key`` (any object, one per clip) lets the frames of a clip share the flat copy of the decoder
+        parameters their graphs read."""
         if not self.return_intermediate:
             raise NotImplementedError("Not Support for no Inter Outputs.")
         if (frame_slot is not None and reference_points.shape[-1] == 4 and src_padding_mask is not None
                 and self.graphs().usable(tgt, src)):
             res = self._forward_graphed(tgt, reference_points, src, src_spatial_shapes, src_level_start_index,
-                                        src_valid_ratios, query_mask, src_padding_mask, frame_slot)
+                                        src_valid_ratios, query_mask, src_padding_mask, frame_slot, clip_key)
             if res is not None:
                 return res
         nd = self.n_det_queries

@@ -125,7 +125,7 @@ class DeformableTransformer(nn.Module):
             tgt=tgt, reference_points=init_reference_points, src=memory, src_spatial_shapes=enc["spatial_shapes"],
             src_level_start_index=enc["level_start_index"], src_valid_ratios=enc["valid_ratios"],
             query_pos=query_pos, query_mask=query_mask, src_padding_mask=enc["mask_flatten"],
-            frame_slot=enc.get("frame_slot"))
+            frame_slot=enc.get("frame_slot"), clip_key=enc.get("clip_key"))
         if return_boxes:
             return output, init_reference_points, res_reference_points, inter_queries, boxes
         return output, init_reference_points, res_reference_points, inter_queries
