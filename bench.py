@@ -130,6 +130,8 @@ class FusedCall(MsdaCall):
         f = to_fused_inputs(x)
         self.proj, self.ref = f["proj"], f["ref"]
         self.gp = torch.empty_like(self.proj)
+        nbytes = int(self.lib.msda_fused_workspace_bytes(self.N, self.Lq, self.M, self.L, self.P))
+        self.ws = torch.empty((nbytes,), dtype=torch.uint8, device=self.proj.device)   # as the operator wrapper does
 
     def fwd(self):
         x = self.x
@@ -142,12 +144,12 @@ class FusedCall(MsdaCall):
 
     def bwd(self):
         x = self.x
-        rc = self.lib.msda_fused_backward_f32(x["value"].data_ptr(), x["shapes"].data_ptr(),
-                                              x["level_start"].data_ptr(), self.proj.data_ptr(), self.proj.shape[2],
-                                              self.ref.data_ptr(), 2, None, x["grad_out"].data_ptr(), self.N, self.S,
-                                              self.M, self.D, self.L, self.Lq, self.P, self.gv.data_ptr(),
-                                              self.gp.data_ptr(), None, 1, self.hptr,
-                                              torch.cuda.current_stream().cuda_stream)
+        rc = self.lib.msda_fused_backward_ws_f32(x["value"].data_ptr(), x["shapes"].data_ptr(),
+                                                 x["level_start"].data_ptr(), self.proj.data_ptr(), self.proj.shape[2],
+                                                 self.ref.data_ptr(), 2, None, x["grad_out"].data_ptr(), self.N, self.S,
+                                                 self.M, self.D, self.L, self.Lq, self.P, self.gv.data_ptr(),
+                                                 self.gp.data_ptr(), None, 1, self.hptr, self.ws.data_ptr(),
+                                                 self.ws.numel(), torch.cuda.current_stream().cuda_stream)
         if rc:
             raise RuntimeError(self._lib.last_error())
 

@@ -51,6 +51,7 @@
 #ifndef MSDA_HIP_H_
 #define MSDA_HIP_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -148,6 +149,29 @@ int msda_fused_backward_bf16(const uint16_t *value, const int64_t *shapes_dev, c
                              float *grad_value, float *grad_proj, float *grad_ref_part,
                              int zero_grad_value, const int64_t *shapes_host, void *stream);
 
+/* The same backward with a caller-provided scratch buffer of msda_fused_workspace_bytes(N, Lq, M, L, P) bytes
+ * (device memory, contents undefined on entry and exit).  With it the region-tiled path runs as three kernels --
+ * the prologue once per row into the workspace, the plain tiled kernel, the Jacobians in place in grad_proj --
+ * instead of redoing the row softmax and the location arithmetic in each of the L workgroups a region takes
+ * (298 -> ~250 us at the encoder shape).  workspace == NULL or too small: exactly msda_fused_backward_*. */
+size_t msda_fused_workspace_bytes(int N, int Lq, int M, int L, int P);
+
+int msda_fused_backward_ws_f32(const float *value, const int64_t *shapes_dev, const int64_t *lstart_dev,
+                               const float *proj, int proj_stride, const float *ref, int ref_dim,
+                               const uint8_t *pad_mask, const float *grad_out,
+                               int N, int S, int M, int D, int L, int Lq, int P,
+                               float *grad_value, float *grad_proj, float *grad_ref_part,
+                               int zero_grad_value, const int64_t *shapes_host,
+                               void *workspace, size_t workspace_bytes, void *stream);
+
+int msda_fused_backward_ws_bf16(const uint16_t *value, const int64_t *shapes_dev, const int64_t *lstart_dev,
+                                const float *proj, int proj_stride, const float *ref, int ref_dim,
+                                const uint8_t *pad_mask, const uint16_t *grad_out,
+                                int N, int S, int M, int D, int L, int Lq, int P,
+                                float *grad_value, float *grad_proj, float *grad_ref_part,
+                                int zero_grad_value, const int64_t *shapes_host,
+                                void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- parity hooks ----
  * msda_sample_indices_f32: the integer side of the sampling arithmetic.  For every (n,q,m,l,p):
  * h_low = floor(loc_y*H_l - 0.5), w_low = floor(loc_x*W_l - 0.5) and gate = (-1 < h < H_l && -1 < w < W_l) as computed
@@ -167,7 +191,7 @@ int msda_fused_points_f32(const int64_t *shapes_dev, const float *proj, int proj
  *       kernels, >=2 = specialised kernels), "fwd_block" | "bwd_block"
  *       (threads per block, multiple of 64), "fwd_grid_mult" | "bwd_grid_mult" (blocks per CU),
  *       "fwd_tile_margin" | "bwd_tile_margin" (LDS window margin in pixels), "fwd_tile_l0" (first pyramid level the
- *       hybrid forward serves from LDS).
+ *       hybrid forward serves from LDS), "bwd_split" (1 = the three-kernel fused backward when a workspace is given).
  * Returns MSDA_OK or MSDA_EINVAL for an unknown key / bad value. */
 int msda_set_option(const char *key, int value);
 int msda_get_option(const char *key, int *value);

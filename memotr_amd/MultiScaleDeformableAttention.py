@@ -246,13 +246,16 @@ def ms_deform_attn_fused_backward(value, spatial_shapes, level_start_index, proj
             gref = ref_part.sum(2) if ref_part is not None else None
             return [grad_value.to(value.dtype), grad_proj, gref]
         keep, hptr = _host_ptr(spatial_shapes, D == 32 and Lq == S and L <= 4 and not need_ref_grad)
-        rc = getattr(_lib.lib, f"msda_fused_backward_{suf}")(
+        # scratch for the three-kernel form of the region-tiled backward (the prologue materialised once per row)
+        ws_bytes = int(_lib.lib.msda_fused_workspace_bytes(N, Lq, M, L, P)) if hptr else 0
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=value.device) if ws_bytes else None
+        rc = getattr(_lib.lib, f"msda_fused_backward_ws_{suf}")(
             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), proj.data_ptr(),
             proj.shape[2], reference_points.data_ptr(), reference_points.shape[3],
             pad_mask.data_ptr() if pad_mask is not None else None, grad_output.data_ptr(), N, S, M, D, L, Lq, P,
             grad_value.data_ptr(), grad_proj.data_ptr(), ref_part.data_ptr() if ref_part is not None else None, 0,
-            hptr, _stream(value.device))
-        del keep
+            hptr, ws.data_ptr() if ws is not None else None, ws_bytes, _stream(value.device))
+        del keep, ws
     if rc != 0:
         _raise(rc, "ms_deform_attn_fused_backward")
     if grad_value.dtype != value.dtype:

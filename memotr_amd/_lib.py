@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmsda_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_int = ctypes.c_int
 c_void_p = ctypes.c_void_p
@@ -22,6 +22,8 @@ _BWD_ARGS = [c_void_p] * 6 + [c_int] * 7 + [c_void_p] * 3 + [c_int, c_void_p, c_
 _FUSED_FWD_ARGS = [c_void_p] * 4 + [c_int, c_void_p, c_int, c_void_p] + [c_int] * 7 + [c_void_p, c_void_p, c_void_p]
 _FUSED_BWD_ARGS = ([c_void_p] * 4 + [c_int, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p] * 3 +
                    [c_int, c_void_p, c_void_p])
+
+_FUSED_BWD_WS_ARGS = _FUSED_BWD_ARGS[:-1] + [c_void_p, ctypes.c_size_t, c_void_p]
 
 SYMBOLS = {
     "msda_abi_version": ([], c_int),
@@ -37,6 +39,9 @@ SYMBOLS = {
     "msda_fused_forward_bf16": (_FUSED_FWD_ARGS, c_int),
     "msda_fused_backward_f32": (_FUSED_BWD_ARGS, c_int),
     "msda_fused_backward_bf16": (_FUSED_BWD_ARGS, c_int),
+    "msda_fused_backward_ws_f32": (_FUSED_BWD_WS_ARGS, c_int),
+    "msda_fused_backward_ws_bf16": (_FUSED_BWD_WS_ARGS, c_int),
+    "msda_fused_workspace_bytes": ([c_int] * 5, ctypes.c_size_t),
     "msda_sample_indices_f32": ([c_void_p, c_void_p] + [c_int] * 5 + [c_void_p] * 4, c_int),
     "msda_fused_points_f32": ([c_void_p, c_void_p, c_int, c_void_p, c_int] + [c_int] * 5 + [c_void_p] * 3, c_int),
     "msda_set_option": ([ctypes.c_char_p, c_int], c_int),

@@ -1635,7 +1635,7 @@ __global__ __launch_bounds__(kTileThreads, PTS <= 2 ? 4 : 2) void msda_bwd_d32_t
             const bool okh0 = on && h0 >= 0, okh1 = on && h0 + 1 <= H - 1;
             const bool okw0 = w0 >= 0, okw1 = w0 + 1 <= W - 1;
             bool v00 = okh0 && okw0, v01 = okh0 && okw1, v10 = okh1 && okw0, v11 = okh1 && okw1;
-            if (FUSED && src.mask != nullptr) {
+            if (src.mask != nullptr) {      // (the split fused backward runs the plain instantiation with a mask)
                 const unsigned char *mk = src.mask + mask_base;
                 const int p00 = h0 * W + w0;
                 v00 = v00 && !mk[v00 ? p00 : 0];
@@ -1753,13 +1753,17 @@ __global__ __launch_bounds__(kTileThreads, PTS <= 2 ? 4 : 2) void msda_bwd_d32_t
                         go = (r_ * size) * (rp[2 + comp] * (0.5f / (float)P));
                     }
                     grad_proj[qrow * src.proj_stride + m * 2 * LP + l * P * 2 + i] = go;
+                } else if (grad_proj != nullptr) {            // split fused backward: d/d loc parked in the offset columns
+                    grad_proj[qrow * src.proj_stride + m * 2 * LP + l * P * 2 + i] = r_ * size;
                 } else {
                     grad_loc[pm * LP * 2 + l * P * 2 + i] = r_ * size;
                 }
             }
             if (sub < P) {
-                if (FUSED) grad_proj[qrow * src.proj_stride + src.n_off + m * LP + l * P + sub] = res[8 * sub + 3];
-                else grad_attn[pm * LP + l * P + sub] = res[8 * sub + 3];
+                if (FUSED || grad_proj != nullptr)
+                    grad_proj[qrow * src.proj_stride + src.n_off + m * LP + l * P + sub] = res[8 * sub + 3];
+                else
+                    grad_attn[pm * LP + l * P + sub] = res[8 * sub + 3];
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1811,6 +1815,42 @@ __global__ __launch_bounds__(256) void msda_softmax_jacobian_kernel(const PointS
     }
 }
 
+// Split fused backward, last step.  The plain tiled kernel has left d/d(sampling location) in the offset columns and
+// d/d(attention) in the logit columns of grad_proj; `fs.attn` is the workspace copy of the softmax weights the
+// prologue kernel wrote.  In place: offsets <- location Jacobian (ms_deform_attn.py:114-120 of the reference module),
+// logits <- softmax Jacobian  a_t (ga_t - sum_j a_j ga_j).  8 lanes per (query, head) row.
+__global__ __launch_bounds__(256) void msda_fused_finish_kernel(const int64_t *__restrict__ shapes, const PointSrc fs,
+                                                               long n_rows, int M, int L, int P,
+                                                               float *__restrict__ grad_proj) {
+    const int LP = L * P;
+    const int sub = threadIdx.x & 7;
+    for (long pm0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 3; pm0 < ((n_rows + 7) & ~7L);
+         pm0 += ((long)gridDim.x * blockDim.x) >> 3) {
+        const bool ok = pm0 < n_rows;
+        const long pm = ok ? pm0 : n_rows - 1;
+        const long qrow = pm / M;
+        const int m = (int)(pm - qrow * M);
+        const float *a = fs.attn + pm * LP;
+        float *ga = grad_proj + qrow * fs.proj_stride + fs.n_off + (long)m * LP;
+        float *gl = grad_proj + qrow * fs.proj_stride + (long)m * LP * 2;
+        float dot = 0.f;
+        for (int t = sub; t < LP; t += 8) dot += a[t] * ga[t];
+        dot = row_sum<8>(dot);
+        if (!ok) continue;
+        for (int t = sub; t < LP; t += 8) ga[t] = a[t] * (ga[t] - dot);
+        for (int i = sub; i < 2 * LP; i += 8) {
+            const int t = i >> 1, comp = i & 1, l = t / P;
+            const float g = gl[i];
+            if (fs.ref_dim == 2) {
+                gl[i] = g / (float)shapes[2 * l + 1 - comp];                    // x / W_l, y / H_l
+            } else {
+                const float *rp = fs.ref + (qrow * L + l) * 4;
+                gl[i] = g * (rp[2 + comp] * (0.5f / (float)P));
+            }
+        }
+    }
+}
+
 // ----------------------------------------------------------------------------------------
 // host side
 // ----------------------------------------------------------------------------------------
@@ -1822,6 +1862,7 @@ std::atomic<int> opt_fwd_block{256}, opt_bwd_block{256};
 std::atomic<int> opt_fwd_grid_mult{32}, opt_bwd_grid_mult{16};
 std::atomic<int> opt_fwd_tile_margin{3}, opt_bwd_tile_margin{3};
 std::atomic<int> opt_fwd_tile_l0{1};      // hybrid forward: first level served from LDS windows
+std::atomic<int> opt_bwd_split{1};        // fused backward with a workspace: prologue kernel + plain tiled kernel + finish kernel
 std::atomic<int> opt_bwd_wide_log2{12};   // tiled backward: row-magnitude range (log2) that makes a region "wide"; 0 = off
 std::atomic<int> opt_bwd_ablate{0};       // profiling only: drop parts of the tiled backward (results are then wrong)
 
@@ -2063,7 +2104,8 @@ template <typename TV, typename TC, typename TG>
 int backward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart, const TC *loc, const TC *attn,
                   const FusedArgs &fa, const TV *grad_out, int N, int S, int M, int D, int L, int Lq, int P,
                   TG *grad_value, TC *grad_loc, TC *grad_attn, float *grad_proj, float *grad_ref_part,
-                  int zero_grad_value, const int64_t *shapes_host, hipStream_t stream) {
+                  int zero_grad_value, const int64_t *shapes_host, hipStream_t stream, float *workspace = nullptr,
+                  size_t workspace_bytes = 0) {
     const bool fused = fa.proj != nullptr;
     int rc = fused ? check_dims(value, shapes, lstart, fa.proj, fa.ref, grad_out, N, S, M, D, L, Lq, P)
                    : check_dims(value, shapes, lstart, loc, attn, grad_out, N, S, M, D, L, Lq, P);
@@ -2102,9 +2144,24 @@ int backward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart,
                 for (int l = 0; l < L; ++l) win_max = pl.win[l] > win_max ? pl.win[l] : win_max;
                 const size_t lds = (size_t)(win_max * win_max + 8) * 128 + (size_t)32 * (2 * P + 1) * 16;
                 const int grid = (pl.n_blocks * L + 7) & ~7;
-                const PointSrc src = make_src(loc, attn, fa, M, L, P);
+                PointSrc src = make_src(loc, attn, fa, M, L, P);
                 pl.ablate = opt_bwd_ablate.load();
                 pl.wide_log2 = opt_bwd_wide_log2.load();
+                const long n_rows = (long)N * Lq * M;
+                // Split fused backward (needs the caller's workspace): materialise the prologue once -- the tiled
+                // kernel would otherwise redo the row softmax and the location arithmetic in each of its L
+                // workgroups per region -- run the plain kernel on it, finish the Jacobians in place.
+                const bool split = fused && opt_bwd_split.load() != 0 && workspace != nullptr &&
+                                   workspace_bytes >= (size_t)n_rows * L * P * 3 * sizeof(float);
+                if (split) {
+                    float *loc_ws = workspace, *attn_ws = workspace + (size_t)n_rows * L * P * 2;
+                    const int pgrid = clamp_grid((n_rows * 8 + 255) / 256, 16);
+                    hipLaunchKernelGGL(msda_fused_points_kernel, dim3(pgrid), dim3(256), 0, stream, shapes, src, n_rows,
+                                       M, L, P, loc_ws, attn_ws);
+                    if ((rc = check_launch("msda_fused_points_kernel"))) return rc;
+                    src.loc = loc_ws;
+                    src.attn = attn_ws;
+                }
 #define MSDA_LAUNCH_LV(PTS, FU, NAME)                                                                                \
     do {                                                                                                             \
         rc = allow_big_lds(msda_bwd_d32_tile_lv<PTS, TV, FU>, lds);                                                  \
@@ -2116,17 +2173,26 @@ int backward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart,
     } while (0)
                 const bool b16 = sizeof(TV) == 2;
                 if (variant == 11) {
-                    if (fused) MSDA_LAUNCH_LV(4, true, b16 ? "msda_bwd_d32_tile_lv<4,bf16,fused>" : "msda_bwd_d32_tile_lv<4,fused>");
+                    if (split) MSDA_LAUNCH_LV(4, false, b16 ? "msda_bwd_d32_tile_lv<4,bf16,split>" : "msda_bwd_d32_tile_lv<4,split>");
+                    else if (fused) MSDA_LAUNCH_LV(4, true, b16 ? "msda_bwd_d32_tile_lv<4,bf16,fused>" : "msda_bwd_d32_tile_lv<4,fused>");
                     else MSDA_LAUNCH_LV(4, false, b16 ? "msda_bwd_d32_tile_lv<4,bf16>" : "msda_bwd_d32_tile_lv<4>");
                 } else {
-                    if (fused) MSDA_LAUNCH_LV(2, true, b16 ? "msda_bwd_d32_tile_lv<2,bf16,fused>" : "msda_bwd_d32_tile_lv<2,fused>");
+                    if (split) MSDA_LAUNCH_LV(2, false, b16 ? "msda_bwd_d32_tile_lv<2,bf16,split>" : "msda_bwd_d32_tile_lv<2,split>");
+                    else if (fused) MSDA_LAUNCH_LV(2, true, b16 ? "msda_bwd_d32_tile_lv<2,bf16,fused>" : "msda_bwd_d32_tile_lv<2,fused>");
                     else MSDA_LAUNCH_LV(2, false, b16 ? "msda_bwd_d32_tile_lv<2,bf16>" : "msda_bwd_d32_tile_lv<2>");
                 }
 #undef MSDA_LAUNCH_LV
                 rc = check_launch(g_kernel);
                 if (rc || !fused) return rc;
-                const long n_rows = (long)N * Lq * M;
                 const int jgrid = clamp_grid((n_rows * 8 + 255) / 256, 16);
+                if (split) {
+                    hipLaunchKernelGGL(msda_fused_finish_kernel, dim3(jgrid), dim3(256), 0, stream, shapes, src, n_rows,
+                                       M, L, P, grad_proj);
+                    const char *name = g_kernel;
+                    rc = check_launch("msda_fused_finish_kernel");
+                    g_kernel = name;
+                    return rc;
+                }
                 hipLaunchKernelGGL(msda_softmax_jacobian_kernel, dim3(jgrid), dim3(256), 0, stream, src, n_rows, M, L * P,
                                    grad_proj);
                 const char *name = g_kernel;
@@ -2194,7 +2260,7 @@ int backward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart,
 
 extern "C" {
 
-int msda_abi_version(void) { return 2; }
+int msda_abi_version(void) { return 3; }
 const char *msda_last_error(void) { return g_err; }
 const char *msda_last_kernel(void) { return g_kernel; }
 
@@ -2302,6 +2368,38 @@ int msda_fused_backward_bf16(const uint16_t *value, const int64_t *shapes_dev, c
                                                (hipStream_t)stream);
 }
 
+size_t msda_fused_workspace_bytes(int N, int Lq, int M, int L, int P) {
+    if (N < 0 || Lq < 0 || M <= 0 || L <= 0 || P <= 0) return 0;
+    return (size_t)N * Lq * M * L * P * 3 * sizeof(float);
+}
+
+int msda_fused_backward_ws_f32(const float *value, const int64_t *shapes_dev, const int64_t *lstart_dev,
+                               const float *proj, int proj_stride, const float *ref, int ref_dim,
+                               const uint8_t *pad_mask, const float *grad_out, int N, int S, int M, int D, int L, int Lq,
+                               int P, float *grad_value, float *grad_proj, float *grad_ref_part, int zero_grad_value,
+                               const int64_t *shapes_host, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!proj) return fail(MSDA_EINVAL, "null pointer argument");
+    return backward_impl<float, float, float>(value, shapes_dev, lstart_dev, nullptr, nullptr,
+                                              fused_args(proj, proj_stride, ref, ref_dim, pad_mask), grad_out, N, S, M,
+                                              D, L, Lq, P, grad_value, nullptr, nullptr, grad_proj, grad_ref_part,
+                                              zero_grad_value, shapes_host, (hipStream_t)stream, (float *)workspace,
+                                              workspace_bytes);
+}
+
+int msda_fused_backward_ws_bf16(const uint16_t *value, const int64_t *shapes_dev, const int64_t *lstart_dev,
+                                const float *proj, int proj_stride, const float *ref, int ref_dim,
+                                const uint8_t *pad_mask, const uint16_t *grad_out, int N, int S, int M, int D, int L,
+                                int Lq, int P, float *grad_value, float *grad_proj, float *grad_ref_part,
+                                int zero_grad_value, const int64_t *shapes_host, void *workspace,
+                                size_t workspace_bytes, void *stream) {
+    if (!proj) return fail(MSDA_EINVAL, "null pointer argument");
+    return backward_impl<bf16_t, float, float>((const bf16_t *)value, shapes_dev, lstart_dev, nullptr, nullptr,
+                                               fused_args(proj, proj_stride, ref, ref_dim, pad_mask),
+                                               (const bf16_t *)grad_out, N, S, M, D, L, Lq, P, grad_value, nullptr,
+                                               nullptr, grad_proj, grad_ref_part, zero_grad_value, shapes_host,
+                                               (hipStream_t)stream, (float *)workspace, workspace_bytes);
+}
+
 int msda_fused_points_f32(const int64_t *shapes_dev, const float *proj, int proj_stride, const float *ref, int ref_dim,
                           int N, int M, int L, int Lq, int P, float *loc_out, float *attn_out, void *stream) {
     if (!shapes_dev || !proj || !ref || !loc_out || !attn_out) return fail(MSDA_EINVAL, "null pointer argument");
@@ -2343,6 +2441,7 @@ static std::atomic<int> *find_opt(const char *key) {
     if (!strcmp(key, "fwd_tile_l0")) return &opt_fwd_tile_l0;
     if (!strcmp(key, "bwd_ablate")) return &opt_bwd_ablate;
     if (!strcmp(key, "bwd_wide_log2")) return &opt_bwd_wide_log2;
+    if (!strcmp(key, "bwd_split")) return &opt_bwd_split;
     return nullptr;
 }
 

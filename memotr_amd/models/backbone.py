@@ -96,7 +96,7 @@ class Backbone(nn.Module):
         res = {}
         for name, feat in self.backbone(ntensor.tensors).items():
             m = F.interpolate(masks[None].float(), mode="nearest", size=feat.shape[-2:]).to(masks.dtype)[0]
-            res[name] = NestedTensor(feat, m)
+            res[name] = NestedTensor(feat, m, getattr(ntensor, "sizes", None))
         return res
 
 

@@ -113,7 +113,8 @@ class MeMOTR(nn.Module):
         for lvl in range(len(srcs), self.n_feature_levels):   # extra levels: stride-2 conv on the raw last map
             src = self.feature_projs[lvl](features[-1].tensors if lvl == len(features) else srcs[-1])
             mask = F.interpolate(frame.masks[None].float(), size=src.shape[-2:])[0].to(torch.bool)
-            pos.append(self.backbone.position_embedding(NestedTensor(src, mask)).to(src.device))
+            level = NestedTensor(src, mask, getattr(frame, "sizes", None))
+            pos.append(self.backbone.position_embedding(level).to(src.device))
             srcs.append(src)
             masks.append(mask)
         return self.transformer.encode(srcs=srcs, masks=masks, pos_embeds=pos)

@@ -21,9 +21,34 @@ class PositionEmbeddingSine(nn.Module):
         self.normalize = normalize
         self.scale = scale
 
+    CACHE_ENTRIES = 16
+
     def forward(self, ntensor: NestedTensor) -> torch.Tensor:
+        """The embedding depends on the padding mask only.  When the NestedTensor says which image sizes its mask
+        was drawn from (``sizes``), the result is cached by them: a clip's frames share one size, so the ~30
+        element-wise kernels per level run once per geometry instead of once per encode call."""
         tensors, masks = ntensor.decompose()
         assert masks is not None, "Masks in ntensor should be NOT NONE."
+        key = None
+        if getattr(ntensor, "sizes", None) is not None:
+            key = (ntensor.sizes, tuple(masks.shape), str(masks.device))
+            cache = self.__dict__.setdefault("_cache", {})
+            hit = cache.get(key)
+            if hit is not None:
+                return hit
+        pos = self._embed(tensors, masks)
+        if key is not None:
+            while len(cache) >= self.CACHE_ENTRIES:
+                cache.pop(next(iter(cache)))
+            cache[key] = pos
+        return pos
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state.pop("_cache", None)
+        return state
+
+    def _embed(self, tensors: torch.Tensor, masks: torch.Tensor) -> torch.Tensor:
         valid = ~masks
         y = valid.cumsum(dim=1, dtype=torch.float32)
         x = valid.cumsum(dim=2, dtype=torch.float32)

@@ -134,7 +134,7 @@ class QueryUpdater(nn.Module):
             self._seed_memories(new_tracks[b])
             self._seed_memories(unmatched_dets[b])
             if self.tp_drop_ratio == 0.0 and self.fp_insert_ratio == 0.0:
-                active = cat(cat(previous_tracks[b], new_tracks[b]), unmatched_dets[b])
+                active = cat(previous_tracks[b], new_tracks[b], unmatched_dets[b])
                 scores = torch.max(logits_to_scores(active.logits), dim=1).values
                 active = active[(scores > self.update_threshold) | (active.ids >= 0)]
                 active.ids = torch.where(active.iou < 0.5, torch.full_like(active.ids, -1), active.ids)

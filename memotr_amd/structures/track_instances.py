@@ -77,10 +77,13 @@ class TrackInstances:
         if torch.is_tensor(item) and item.dtype == torch.bool:
             # one nonzero (one device sync) for all fields instead of one per boolean-indexed field
             item = item.nonzero().squeeze(1)
+        # a 1-d index tensor gathers through index_select: its backward is one index_add, where advanced indexing
+        # differentiates through a sort-based accumulate (~7 kernels per field that carries a gradient)
+        rows = torch.is_tensor(item) and item.dim() == 1 and item.dtype in (torch.int64, torch.int32)
         res = self._blank_like()
         for k, v in vars(self).items():
             if hasattr(v, "__getitem__") and v.shape[0] != 0:
-                setattr(res, k, v[item])
+                setattr(res, k, v.index_select(0, item) if rows and torch.is_tensor(v) else v[item])
             else:
                 setattr(res, k, v)
         return res
@@ -98,11 +101,13 @@ class TrackInstances:
         ]
 
     @staticmethod
-    def cat_tracked_instances(tracked1: "TrackInstances", tracked2: "TrackInstances") -> "TrackInstances":
+    def cat_tracked_instances(tracked1: "TrackInstances", tracked2: "TrackInstances",
+                              *more: "TrackInstances") -> "TrackInstances":
+        """Concatenation of two (the reference's signature) or more instance lists, one ``cat`` per field."""
         res = TrackInstances(frame_height=tracked1.frame_height, frame_width=tracked1.frame_width)
         for k, v in vars(tracked1).items():
             if type(v) is torch.Tensor:
-                setattr(res, k, torch.cat((v, getattr(tracked2, k))))
+                setattr(res, k, torch.cat((v, getattr(tracked2, k)) + tuple(getattr(t, k) for t in more)))
         return res
 
     @staticmethod

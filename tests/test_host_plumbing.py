@@ -188,3 +188,26 @@ def test_decoder_loop_module_equals_the_eager_decoder_and_leaves_parameters_alon
         assert torch.equal(a, b)
     assert DecoderGraphs.bucket(300, 300) == 320 and DecoderGraphs.bucket(311, 300) == 320
     assert DecoderGraphs.bucket(321, 300) == 352 and DecoderGraphs.bucket(20, 20) == 32
+
+
+def test_position_embedding_cache_by_image_geometry():
+    """The sine embedding is a function of the padding mask; NestedTensors that carry their image sizes are served
+    from a cache keyed by them, anything else is computed."""
+    import math
+
+    import torch
+    from memotr_amd.models.position_embedding import PositionEmbeddingSine
+    from memotr_amd.utils.nested_tensor import NestedTensor, tensor_list_to_nested_tensor
+    pe = PositionEmbeddingSine(num_pos_feats=8, normalize=True, scale=2 * math.pi, temperature=20)
+    a = tensor_list_to_nested_tensor([torch.zeros(3, 40, 50), torch.zeros(3, 33, 64)])
+    assert a.sizes == ((64, 64), (40, 50), (33, 64))
+    first = pe(a)
+    again = pe(tensor_list_to_nested_tensor([torch.ones(3, 40, 50), torch.ones(3, 33, 64)]))
+    assert again is first                                   # same geometry, other pixels: the cached tensor
+    plain = pe(NestedTensor(a.tensors, a.masks))            # no sizes: computed
+    assert plain is not first and torch.equal(plain, first)
+    other = pe(tensor_list_to_nested_tensor([torch.zeros(3, 40, 50), torch.zeros(3, 40, 64)]))
+    assert other is not first and not torch.equal(other[1], first[1])
+    assert len(pe._cache) == 2
+    import copy
+    assert "_cache" not in copy.deepcopy(pe).__dict__

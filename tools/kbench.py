@@ -22,7 +22,7 @@ from memotr_amd.synth import make_inputs  # noqa: E402
 
 def reset():
     for k, v in (("fwd_variant", 0), ("bwd_variant", 0), ("fwd_tile_margin", 3), ("bwd_tile_margin", 3),
-                 ("fwd_tile_l0", 1), ("fwd_block", 256), ("fwd_grid_mult", 32)):
+                 ("fwd_tile_l0", 1), ("fwd_block", 256), ("fwd_grid_mult", 32), ("bwd_split", 1)):
         _lib.set_option(k, v)
 
 
@@ -78,6 +78,9 @@ def main():
                     for mg in ((2, 3, 4) if not args.quick else (3,)):
                         bwd_cfgs.append((f"v{v} {'tile_q2' if v < 10 else 'tile_lv'} m{mg}",
                                          dict(bwd_variant=v, bwd_tile_margin=mg)))
+                        if v >= 10:     # fused call without the three-kernel split (the plain call ignores the knob)
+                            bwd_cfgs.append((f"v{v} tile_lv m{mg} one-kernel", dict(bwd_variant=v, bwd_tile_margin=mg,
+                                                                                     bwd_split=0)))
             for name, opts in bwd_cfgs:
                 for c, tag in ((call, "bwd"), (fcall, "bwd_fused")):
                     reset()
