@@ -322,6 +322,41 @@ __global__ __launch_bounds__(256) void msda_fused_points_kernel(const int64_t *_
     }
 }
 
+// The same for L*P <= 16 with one lane per point (16 lanes per row): every lane reads and writes consecutive
+// addresses.  The softmax sum adds in the order of the 8-lane form above ((t, t+8) pairs first, then the butterfly
+// over 8 lanes), so both produce the same bits.
+__global__ __launch_bounds__(256) void msda_fused_points16_kernel(const int64_t *__restrict__ shapes, const PointSrc fs,
+                                                                 long n_rows, int M, int L, int P,
+                                                                 float *__restrict__ loc_out,
+                                                                 float *__restrict__ attn_out) {
+    const int LP = L * P;
+    const int t = threadIdx.x & 15;
+    const long rows_pad = (n_rows + 3) & ~3L;
+    for (long pm0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 4; pm0 < rows_pad;
+         pm0 += ((long)gridDim.x * blockDim.x) >> 4) {
+        const bool ok = pm0 < n_rows && t < LP;
+        const long pm = pm0 < n_rows ? pm0 : n_rows - 1;
+        const long qrow = pm / M;
+        const int m = (int)(pm - qrow * M);
+        const float lg = t < LP ? fused_logits(fs, qrow, m, LP)[t] : -INFINITY;
+        float mx = lg;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
+        const float e = expf(lg - mx);
+        float sum = e + __shfl_xor(e, 8, 16);
+        sum += __shfl_xor(sum, 1, 16);
+        sum += __shfl_xor(sum, 2, 16);
+        sum += __shfl_xor(sum, 4, 16);
+        const float rsum = 1.f / sum;
+        if (ok) {
+            const int l = t / P;
+            const f32x2 xy = fused_location(fs, qrow, m, L, P, t, l, (int)shapes[2 * l], (int)shapes[2 * l + 1]);
+            *reinterpret_cast<f32x2 *>(loc_out + (pm * LP + t) * 2) = xy;
+            attn_out[pm * LP + t] = e * rsum;
+        }
+    }
+}
+
 // ----------------------------------------------------------------------------------------
 // D = 32 specialised kernels.
 // ----------------------------------------------------------------------------------------
@@ -1491,14 +1526,14 @@ __global__ __launch_bounds__(kTileThreads, PTS <= 2 ? 4 : 2) void msda_bwd_d32_t
         const LevelPlanRow row = level_tile_row(pl, p * 32 + wave * 8 + grp, ry, rx);
         ok[p] = row.ok && p * 32 < pl.rows;
         qq[p] = row.q;
-        const long qrow = (long)b * pl.Lq + row.q;
-        const long pm = qrow * pl.M + m;
+        const unsigned qrow = (unsigned)b * (unsigned)pl.Lq + (unsigned)row.q;   // 32-bit: check_dims' envelope
+        const unsigned pm = qrow * (unsigned)pl.M + (unsigned)m;
         g[p] = f32x4{0.f, 0.f, 0.f, 0.f};
         gsr[p][0] = gsr[p][1] = gsr[p][2] = gsr[p][3] = 0.f;
         px_[p] = py_[p] = pa[p] = 0.f;
         if (ok[p]) {
-            g[p] = load_ch4<TV>(grad_out + pm * D + sub * 4);
-            const f32x2 s0 = load_ch2<TV>(grad_out + pm * D + cpair[0]), s1 = load_ch2<TV>(grad_out + pm * D + cpair[1]);
+            g[p] = load_ch4<TV>(grad_out + (pm * (unsigned)D + (unsigned)(sub * 4)));
+            const f32x2 s0 = load_ch2<TV>(grad_out + (pm * (unsigned)D + (unsigned)cpair[0])), s1 = load_ch2<TV>(grad_out + (pm * (unsigned)D + (unsigned)cpair[1]));
             gsr[p][0] = s0.x; gsr[p][1] = s0.y; gsr[p][2] = s1.x; gsr[p][3] = s1.y;
         }
         float mx = 0.f, rsum = 1.f;
@@ -1512,7 +1547,7 @@ __global__ __launch_bounds__(kTileThreads, PTS <= 2 ? 4 : 2) void msda_bwd_d32_t
             const f32x2 xy = point_location<FUSED>(src, pm, qrow, m, L, P, t, l, H, W);
             px_[p] = xy.x;
             py_[p] = xy.y;
-            pa[p] = FUSED ? expf(lg[t] - mx) * rsum : src.attn[pm * LP + t];
+            pa[p] = FUSED ? expf(lg[t] - mx) * rsum : src.attn[pm * (unsigned)LP + (unsigned)t];
         }
     }
     __syncthreads();      // the zeroed window / shared scalars are in place
@@ -1616,8 +1651,8 @@ __global__ __launch_bounds__(kTileThreads, PTS <= 2 ? 4 : 2) void msda_bwd_d32_t
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
         if (p * 32 >= pl.rows) break;
-        const long qrow = (long)b * pl.Lq + qq[p];
-        const long pm = qrow * pl.M + m;
+        const unsigned qrow = (unsigned)b * (unsigned)pl.Lq + (unsigned)qq[p];
+        const unsigned pm = qrow * (unsigned)pl.M + (unsigned)m;
         float gs[4];
         bool lane_bypass = nonfinite;
 #pragma unroll
@@ -1693,9 +1728,12 @@ __global__ __launch_bounds__(kTileThreads, PTS <= 2 ? 4 : 2) void msda_bwd_d32_t
                     const float hh = 1.f - lh, hw = 1.f - lw;
                     const float wk[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
                     unsigned cells[4] = {ra[i].y & 0xffffu, ra[i].y >> 16, ra[i].z & 0xffffu, ra[i].z >> 16};
+                    unsigned fpath = fl >> 4;
+                    if (wide || nonfinite) {      // block-uniform: ordinary regions skip the per-lane overrides
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) cells[k] = dump_or ? dump_cell : cells[k];
-                    const unsigned fpath = (fl >> 4) | (dump_or & fl);
+                        for (int k = 0; k < 4; ++k) cells[k] = dump_or ? dump_cell : cells[k];
+                        fpath |= dump_or & fl;
+                    }
                     if (!(pl.ablate & 2))
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -1749,21 +1787,21 @@ __global__ __launch_bounds__(kTileThreads, PTS <= 2 ? 4 : 2) void msda_bwd_d32_t
                 if (FUSED) {
                     float go = r_;                            // 2-d: (r_ * size) / size
                     if (src.ref_dim != 2) {
-                        const float *rp = src.ref + (qrow * L + l) * 4;
+                        const float *rp = src.ref + (qrow * (unsigned)L + (unsigned)l) * 4u;
                         go = (r_ * size) * (rp[2 + comp] * (0.5f / (float)P));
                     }
-                    grad_proj[qrow * src.proj_stride + m * 2 * LP + l * P * 2 + i] = go;
+                    grad_proj[qrow * (unsigned)src.proj_stride + (unsigned)(m * 2 * LP + l * P * 2 + i)] = go;
                 } else if (grad_proj != nullptr) {            // split fused backward: d/d loc parked in the offset columns
-                    grad_proj[qrow * src.proj_stride + m * 2 * LP + l * P * 2 + i] = r_ * size;
+                    grad_proj[qrow * (unsigned)src.proj_stride + (unsigned)(m * 2 * LP + l * P * 2 + i)] = r_ * size;
                 } else {
-                    grad_loc[pm * LP * 2 + l * P * 2 + i] = r_ * size;
+                    grad_loc[pm * (unsigned)(LP * 2) + (unsigned)(l * P * 2 + i)] = r_ * size;
                 }
             }
             if (sub < P) {
                 if (FUSED || grad_proj != nullptr)
-                    grad_proj[qrow * src.proj_stride + src.n_off + m * LP + l * P + sub] = res[8 * sub + 3];
+                    grad_proj[qrow * (unsigned)src.proj_stride + (unsigned)(src.n_off + m * LP + l * P + sub)] = res[8 * sub + 3];
                 else
-                    grad_attn[pm * LP + l * P + sub] = res[8 * sub + 3];
+                    grad_attn[pm * (unsigned)LP + (unsigned)(l * P + sub)] = res[8 * sub + 3];
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1773,20 +1811,22 @@ __global__ __launch_bounds__(kTileThreads, PTS <= 2 ? 4 : 2) void msda_bwd_d32_t
     // ---- flush: one coalesced global float atomic per touched window element ----
     if (!(pl.ablate & 1)) {
         const unsigned long long *win_u64 = reinterpret_cast<const unsigned long long *>(s_dyn);
-        const int n = win_px * D;
-        for (int i = threadIdx.x; i < n; i += kTileThreads) {
-            const int pix = i >> 5, c = i & 31;
+        const int c = threadIdx.x & 31;                       // this thread's channel in every pixel row it visits
+        const bool high = (c & 1) != 0;
+        const float back = s_cinv[c] * linv;                  // powers of two: exact
+        const unsigned col = (unsigned)m * 128u + (unsigned)c * 4u;
+        for (int pix = threadIdx.x >> 5; pix < win_px; pix += kTileThreads / 32) {
             const unsigned long long tot = win_u64[pix * (D / 2) + (c >> 1)];
             const int lo = (int)(unsigned)(tot & 0xffffffffull);
-            const int q = (c & 1) ? (int)(unsigned)(tot >> 32) + (lo < 0 ? 1 : 0) : lo;
+            const int q = high ? (int)(unsigned)(tot >> 32) + (lo < 0 ? 1 : 0) : lo;
             if (q != 0) {
                 const int wy = (pix * magic) >> 16, wx = pix - wy * win;
                 const int gy = oy + wy, gx = ox + wx;
                 if (gy < H && gx < W)
                     __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(
-                        (float)q * s_cinv[c] * linv, gr,
-                        (int)((((unsigned)b * (unsigned)pl.S + (unsigned)(lstart_l + gy * W + gx)) * (unsigned)pl.M +
-                               (unsigned)m) * 128u + (unsigned)c * 4u), 0, 0);
+                        (float)q * back, gr,
+                        (int)(((unsigned)b * (unsigned)pl.S + (unsigned)(lstart_l + gy * W + gx)) * (unsigned)pl.M * 128u +
+                              col), 0, 0);
             }
         }
     }
@@ -1848,6 +1888,42 @@ __global__ __launch_bounds__(256) void msda_fused_finish_kernel(const int64_t *_
                 gl[i] = g * (rp[2 + comp] * (0.5f / (float)P));
             }
         }
+    }
+}
+
+// The same for L*P <= 16 with one lane per point: coalesced reads / writes of the three column groups.
+__global__ __launch_bounds__(256) void msda_fused_finish16_kernel(const int64_t *__restrict__ shapes, const PointSrc fs,
+                                                                 long n_rows, int M, int L, int P,
+                                                                 float *__restrict__ grad_proj) {
+    const int LP = L * P;
+    const int t = threadIdx.x & 15;
+    const long rows_pad = (n_rows + 3) & ~3L;
+    for (long pm0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 4; pm0 < rows_pad;
+         pm0 += ((long)gridDim.x * blockDim.x) >> 4) {
+        const bool ok = pm0 < n_rows && t < LP;
+        const long pm = pm0 < n_rows ? pm0 : n_rows - 1;
+        const long qrow = pm / M;
+        const int m = (int)(pm - qrow * M);
+        float *ga = grad_proj + qrow * fs.proj_stride + fs.n_off + (long)m * LP;
+        float *gl = grad_proj + qrow * fs.proj_stride + (long)m * LP * 2;
+        const float a = t < LP ? fs.attn[pm * LP + t] : 0.f;
+        const float g = t < LP ? ga[t] : 0.f;
+        float dot = a * g;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 16);
+        if (!ok) continue;
+        ga[t] = a * (g - dot);
+        const int l = t / P;
+        f32x2 d = *reinterpret_cast<f32x2 *>(gl + 2 * t);
+        if (fs.ref_dim == 2) {
+            d.x = d.x / (float)shapes[2 * l + 1];
+            d.y = d.y / (float)shapes[2 * l];
+        } else {
+            const float *rp = fs.ref + (qrow * L + l) * 4;
+            d.x = d.x * (rp[2] * (0.5f / (float)P));
+            d.y = d.y * (rp[3] * (0.5f / (float)P));
+        }
+        *reinterpret_cast<f32x2 *>(gl + 2 * t) = d;
     }
 }
 
@@ -2155,9 +2231,13 @@ int backward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart,
                                    workspace_bytes >= (size_t)n_rows * L * P * 3 * sizeof(float);
                 if (split) {
                     float *loc_ws = workspace, *attn_ws = workspace + (size_t)n_rows * L * P * 2;
-                    const int pgrid = clamp_grid((n_rows * 8 + 255) / 256, 16);
-                    hipLaunchKernelGGL(msda_fused_points_kernel, dim3(pgrid), dim3(256), 0, stream, shapes, src, n_rows,
-                                       M, L, P, loc_ws, attn_ws);
+                    if (L * P <= 16) {
+                        hipLaunchKernelGGL(msda_fused_points16_kernel, dim3(clamp_grid((n_rows * 16 + 255) / 256, 32)),
+                                           dim3(256), 0, stream, shapes, src, n_rows, M, L, P, loc_ws, attn_ws);
+                    } else {
+                        hipLaunchKernelGGL(msda_fused_points_kernel, dim3(clamp_grid((n_rows * 8 + 255) / 256, 16)),
+                                           dim3(256), 0, stream, shapes, src, n_rows, M, L, P, loc_ws, attn_ws);
+                    }
                     if ((rc = check_launch("msda_fused_points_kernel"))) return rc;
                     src.loc = loc_ws;
                     src.attn = attn_ws;
@@ -2186,8 +2266,13 @@ int backward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart,
                 if (rc || !fused) return rc;
                 const int jgrid = clamp_grid((n_rows * 8 + 255) / 256, 16);
                 if (split) {
-                    hipLaunchKernelGGL(msda_fused_finish_kernel, dim3(jgrid), dim3(256), 0, stream, shapes, src, n_rows,
-                                       M, L, P, grad_proj);
+                    if (L * P <= 16) {
+                        hipLaunchKernelGGL(msda_fused_finish16_kernel, dim3(clamp_grid((n_rows * 16 + 255) / 256, 32)),
+                                           dim3(256), 0, stream, shapes, src, n_rows, M, L, P, grad_proj);
+                    } else {
+                        hipLaunchKernelGGL(msda_fused_finish_kernel, dim3(jgrid), dim3(256), 0, stream, shapes, src,
+                                           n_rows, M, L, P, grad_proj);
+                    }
                     const char *name = g_kernel;
                     rc = check_launch("msda_fused_finish_kernel");
                     g_kernel = name;
@@ -2410,6 +2495,11 @@ int msda_fused_points_f32(const int64_t *shapes_dev, const float *proj, int proj
     const long n_rows = (long)N * Lq * M;
     if (n_rows == 0) { g_err[0] = 0; return MSDA_OK; }
     const PointSrc src = make_src(nullptr, nullptr, fa, M, L, P);
+    if (L * P <= 16) {
+        hipLaunchKernelGGL(msda_fused_points16_kernel, dim3(clamp_grid((n_rows * 16 + 255) / 256, 32)), dim3(256), 0,
+                           (hipStream_t)stream, shapes_dev, src, n_rows, M, L, P, loc_out, attn_out);
+        return check_launch("msda_fused_points16_kernel");
+    }
     const int grid = clamp_grid((n_rows * 8 + 255) / 256, 16);
     hipLaunchKernelGGL(msda_fused_points_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, shapes_dev, src, n_rows,
                        M, L, P, loc_out, attn_out);
