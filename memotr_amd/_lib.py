@@ -9,7 +9,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmsda_hip.so")
+LIB_PATH = os.environ.get("MEMOTR_MSDA_LIB") or os.path.join(_HERE, "lib", "libmsda_hip.so")   # (override: A/B builds)
 
 ABI_VERSION = 3
 

@@ -1458,8 +1458,11 @@ __device__ __forceinline__ f32x2 load_ch2<bf16_t>(const bf16_t *p) {
     return f32x2{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
 }
 
+#ifndef MSDA_LV_WGS
+#define MSDA_LV_WGS 4      // workgroups per CU the register budget of tile_lv<2> is sized for
+#endif
 template <int PTS, typename TV, bool FUSED>
-__global__ __launch_bounds__(kTileThreads, PTS <= 2 ? 4 : 2) void msda_bwd_d32_tile_lv(
+__global__ __launch_bounds__(kTileThreads, PTS <= 2 ? MSDA_LV_WGS : 2) void msda_bwd_d32_tile_lv(
     const TV *__restrict__ value, const int64_t *__restrict__ lstart, const PointSrc src,
     const TV *__restrict__ grad_out, float *__restrict__ grad_value, float *__restrict__ grad_loc,
     float *__restrict__ grad_attn, float *__restrict__ grad_proj, const TilePlan pl) {
