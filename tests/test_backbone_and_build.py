@@ -190,11 +190,14 @@ def test_folded_resnet50_equals_unfolded_definition(device):
     want = _resnet50_from_definition(nt.tensors, sd)
     seeds = [torch.randn(w.shape, generator=torch.Generator().manual_seed(20 + i)).to(device)
              for i, w in enumerate(want)]
+    # on the GPU MIOpen picks the convolution algorithms per box (its find step): a Winograd pick differs from a
+    # direct one by ~1e-4 relative through 16 blocks, so the device run gets that headroom; the CPU run stays tight
+    out_tol, grad_tol = (2e-5, 2e-4) if device == "cpu" else (3e-4, 3e-3)
     for i, name in enumerate(("0", "1", "2")):
         a, b = got[name].tensors, want[i]
         assert a.shape == b.shape
-        scale = float(b.abs().max())
-        assert float((a - b).abs().max()) <= 2e-5 * max(scale, 1.0), (name, float((a - b).abs().max()), scale)
+        scale = float(b.detach().abs().max())
+        assert float((a - b).abs().max()) <= out_tol * max(scale, 1.0), (name, float((a - b).abs().max()), scale)
     sum((got[n].tensors * s).sum() for n, s in zip(("0", "1", "2"), seeds)).backward()
     grads = torch.autograd.grad(sum((w * s).sum() for w, s in zip(want, seeds)), [sd[k] for k in train_keys])
     params = dict(bb.backbone.named_parameters())
@@ -203,7 +206,7 @@ def test_folded_resnet50_equals_unfolded_definition(device):
         g_got = params[k].grad
         assert g_got is not None, k
         rel = float((g_got - g_ref).norm()) / (float(g_ref.norm()) + 1e-12)
-        assert rel < 2e-4, (k, rel)
+        assert rel < grad_tol, (k, rel)
     for n, p in params.items():                     # conv1 / layer1 stay frozen (models/backbone.py:72-74)
         if n.split(".")[0] in ("conv1", "layer1"):
             assert p.grad is None and not p.requires_grad
