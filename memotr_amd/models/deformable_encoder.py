@@ -36,9 +36,10 @@ class DeformableEncoder(nn.Module):
         return ref[:, :, None] * valid_ratios[:, None]
 
     def forward(self, src, spatial_shapes, level_start_index, valid_ratios, pos=None, padding_mask=None,
-                shapes_list=None):
-        reference_points = self.get_reference_points(shapes_list if shapes_list is not None else spatial_shapes,
-                                                     valid_ratios, device=src.device)
+                shapes_list=None, reference_points=None):
+        if reference_points is None:        # (the caller may hold them for this pyramid / mask geometry)
+            reference_points = self.get_reference_points(shapes_list if shapes_list is not None else spatial_shapes,
+                                                         valid_ratios, device=src.device)
         output = src
         if self.use_checkpoint:
             # CHECKPOINT_LEVEL 1: recompute in groups of three layers (reference :46-57)

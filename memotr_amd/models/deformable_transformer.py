@@ -89,24 +89,41 @@ class DeformableTransformer(nn.Module):
             cache[key] = (spatial_shapes, level_start_index)
         return cache[key]
 
-    def encode(self, srcs: List[torch.Tensor], masks: List[torch.Tensor], pos_embeds: List[torch.Tensor]) -> dict:
-        """Query-independent half: flatten the pyramid and run the encoder.  Returns what ``decode`` needs."""
+    def encode(self, srcs: List[torch.Tensor], masks: List[torch.Tensor], pos_embeds: List[torch.Tensor],
+               geometry=None) -> dict:
+        """Query-independent half: flatten the pyramid and run the encoder.  Returns what ``decode`` needs.
+        ``geometry`` (optional, hashable: ``NestedTensor.sizes`` of the frames) says which image sizes the masks were
+        drawn from; what depends on the masks alone -- their flattened copy, the valid ratios, the encoder's
+        reference points, ~70 small kernels -- is then computed once per geometry."""
         shapes_list = [(int(s.shape[2]), int(s.shape[3])) for s in srcs]
         src_flatten = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)                 # (B, S, C)
-        mask_flatten = torch.cat([m.flatten(1) for m in masks], 1)                                # (B, S)
         lvl_pos_embed_flatten = torch.cat(
             [p.flatten(2).transpose(1, 2) + self.level_embed[lvl].view(1, 1, -1) for lvl, p in enumerate(pos_embeds)],
             1)
         spatial_shapes, level_start_index = self._pyramid_tensors(shapes_list, src_flatten.device)
-        valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)                   # (B, L, 2)
+        key = None if geometry is None else (geometry, tuple(shapes_list), str(src_flatten.device))
+        cache = self.__dict__.setdefault("_mask_derived", {})
+        enc_ref = None
+        if key is not None and key in cache:
+            mask_flatten, valid_ratios, enc_ref = cache[key]
+        else:
+            mask_flatten = torch.cat([m.flatten(1) for m in masks], 1)                            # (B, S)
+            valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)               # (B, L, 2)
+            if key is not None:
+                with torch.no_grad():
+                    enc_ref = self.encoder.get_reference_points(shapes_list, valid_ratios, src_flatten.device)
+                if len(cache) >= 16:
+                    cache.clear()
+                cache[key] = (mask_flatten, valid_ratios, enc_ref)
 
         if self.use_checkpoint and self.checkpoint_level in (2, 3):
             memory = checkpoint(self.encoder, src_flatten, spatial_shapes, level_start_index, valid_ratios,
-                                lvl_pos_embed_flatten, mask_flatten, shapes_list, use_reentrant=False)
+                                lvl_pos_embed_flatten, mask_flatten, shapes_list, enc_ref, use_reentrant=False)
         else:
             memory = self.encoder(src=src_flatten, spatial_shapes=spatial_shapes,
                                   level_start_index=level_start_index, valid_ratios=valid_ratios,
-                                  pos=lvl_pos_embed_flatten, padding_mask=mask_flatten, shapes_list=shapes_list)
+                                  pos=lvl_pos_embed_flatten, padding_mask=mask_flatten, shapes_list=shapes_list,
+                                  reference_points=enc_ref)
         return {"memory": memory, "spatial_shapes": spatial_shapes, "level_start_index": level_start_index,
                 "valid_ratios": valid_ratios, "mask_flatten": mask_flatten}
 

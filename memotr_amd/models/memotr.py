@@ -117,7 +117,7 @@ class MeMOTR(nn.Module):
             pos.append(self.backbone.position_embedding(level).to(src.device))
             srcs.append(src)
             masks.append(mask)
-        return self.transformer.encode(srcs=srcs, masks=masks, pos_embeds=pos)
+        return self.transformer.encode(srcs=srcs, masks=masks, pos_embeds=pos, geometry=getattr(frame, "sizes", None))
 
     def decode_frame(self, encoded: dict, tracks: List[TrackInstances]) -> dict:
         """Query assembly -> decoder -> heads over an ``encode_frame`` result."""
@@ -137,8 +137,15 @@ class MeMOTR(nn.Module):
         # full 4-d inverse sigmoid at level 0, reference models/memotr.py:148-158 -- not the same boxes for tracks)
         reuse = refined is not None and self.use_dab and self.transformer.decoder.bbox_embed is self.bbox_embed
         per_layer = outputs.unbind(0)          # one backward node for the six uses (a select each: zero-fill + copy)
+        n_lvl, B_, Nq_, C_ = outputs.shape
+        batched_heads = reuse and all(isinstance(m, nn.Linear) for m in self.class_embed)
+        if batched_heads:      # the per-layer class heads as ONE batched product (6 x {GEMM, bias} forward, 18 kernels backward)
+            w = torch.stack([m.weight for m in self.class_embed]).transpose(1, 2)          # (n, C, K)
+            b = torch.stack([m.bias for m in self.class_embed])[:, None, :]                 # (n, 1, K)
+            classes = torch.baddbmm(b, outputs.reshape(n_lvl, B_ * Nq_, C_), w).view(n_lvl, B_, Nq_, -1)
         for lvl in range(outputs.shape[0]):
-            classes.append(self.class_embed[lvl](per_layer[lvl]))
+            if not batched_heads:
+                classes.append(self.class_embed[lvl](per_layer[lvl]))
             if reuse:
                 continue
             reference = inverse_sigmoid(init_reference if lvl == 0 else inter_references[lvl - 1])
@@ -149,7 +156,8 @@ class MeMOTR(nn.Module):
                 assert reference.shape[-1] == 2, f"Reference should have only 2 coord, but get {reference.shape[-1]}."
                 box = torch.cat((box[..., :2] + reference, box[..., 2:]), -1)
             boxes.append(box.sigmoid())
-        classes = torch.stack(classes, dim=0)
+        if not batched_heads:
+            classes = torch.stack(classes, dim=0)
         boxes = refined if reuse else torch.stack(boxes, dim=0)
         res = {
             "pred_logits": classes[-1],
@@ -179,14 +187,17 @@ class MeMOTR(nn.Module):
         return self.transformer.reference_points(self.det_query_embed[:, :self.hidden_dim])
 
     def _pad_stack(self, parts: List[torch.Tensor], width: int) -> torch.Tensor:
-        """(B, max_len, width) zero-padded stack of per-clip (n_i, width) tensors, on the model's device."""
+        """(B, max_len, width) zero-padded stack of per-clip (n_i, width) tensors, on the model's device.
+        Built from views / pads / one stack: writing the parts into a zero tensor slice by slice would put a
+        CopySlices node (zero-fill + strided copies, forward and backward) on every carried track tensor."""
         device = self.det_query_embed.device
         max_len = max(p.shape[0] for p in parts)
-        out = torch.zeros((len(parts), max_len, width), device=device)
-        for i, p in enumerate(parts):
-            if p.shape[0]:
-                out[i, :p.shape[0]] = p.to(device)
-        return out
+        if max_len == 0:
+            return torch.zeros((len(parts), 0, width), device=device)
+        parts = [p.to(device) for p in parts]
+        if len(parts) == 1:
+            return parts[0][None]
+        return torch.stack([p if p.shape[0] == max_len else F.pad(p, (0, 0, 0, max_len - p.shape[0])) for p in parts])
 
     def get_track_reference_points(self, tracks: List[TrackInstances]):
         return self._pad_stack([t.ref_pts for t in tracks], 4)

@@ -16,6 +16,38 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+class _PackedInProj(torch.autograd.Function):
+    """(qk W_qk^T + b_qk, v W_v^T + b_v) from the packed ``in_proj_weight`` (3E, E) / ``in_proj_bias`` (3E).
+
+    Written as one autograd node because slicing the packed parameters in the graph costs more in the backward than
+    the projections themselves: every slice gets a zero-filled full-size gradient, a strided copy and an add into the
+    parameter's buffer (~20 small kernels per call against the 6 below, x 6 layers x every frame of a clip)."""
+
+    @staticmethod
+    def forward(ctx, qk, v, w, b):
+        E = w.shape[1]
+        qk2, v2 = qk.reshape(-1, E), v.reshape(-1, E)
+        qk_p = torch.addmm(b[:2 * E], qk2, w[:2 * E].t())
+        v_p = torch.addmm(b[2 * E:], v2, w[2 * E:].t())
+        ctx.save_for_backward(qk2, v2, w)
+        ctx.shapes = (qk.shape, v.shape)
+        return qk_p.view(*qk.shape[:-1], 2 * E), v_p.view(*v.shape[:-1], E)
+
+    @staticmethod
+    def backward(ctx, g_qk, g_v):
+        qk2, v2, w = ctx.saved_tensors
+        E = w.shape[1]
+        g_qk2, g_v2 = g_qk.reshape(-1, 2 * E), g_v.reshape(-1, E)
+        gw, gb = torch.empty_like(w), torch.empty((3 * E,), dtype=w.dtype, device=w.device)
+        torch.mm(g_qk2.t(), qk2, out=gw[:2 * E])
+        torch.mm(g_v2.t(), v2, out=gw[2 * E:])
+        torch.sum(g_qk2, 0, out=gb[:2 * E])
+        torch.sum(g_v2, 0, out=gb[2 * E:])
+        g_in_qk = (g_qk2 @ w[:2 * E]).view(ctx.shapes[0]) if ctx.needs_input_grad[0] else None
+        g_in_v = (g_v2 @ w[2 * E:]).view(ctx.shapes[1]) if ctx.needs_input_grad[1] else None
+        return g_in_qk, g_in_v, gw, gb
+
+
 def self_attention(mha: nn.MultiheadAttention, qk: torch.Tensor, v: torch.Tensor,
                    key_padding_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``mha(qk, qk, v, key_padding_mask=..., need_weights=False)[0]`` for a batch-first module with packed
@@ -29,9 +61,15 @@ def self_attention(mha: nn.MultiheadAttention, qk: torch.Tensor, v: torch.Tensor
     d = E // H
     B, L, _ = qk.shape
     w, b = mha.in_proj_weight, mha.in_proj_bias
-    qk_p = F.linear(qk, w[:2 * E], b[:2 * E]).view(B, L, 2, H, d)
-    q, k = qk_p[:, :, 0].transpose(1, 2), qk_p[:, :, 1].transpose(1, 2)            # (B, H, L, d)
-    vh = F.linear(v, w[2 * E:], b[2 * E:]).view(B, L, H, d).transpose(1, 2)
+    if (torch.is_grad_enabled() and w.requires_grad and not torch.is_autocast_enabled() and qk.dtype == w.dtype
+            and v.dtype == w.dtype):
+        qk_p, v_p = _PackedInProj.apply(qk, v, w, b)
+        q, k = (t.transpose(1, 2) for t in qk_p.view(B, L, 2, H, d).unbind(2))     # (B, H, L, d)
+        vh = v_p.view(B, L, H, d).transpose(1, 2)
+    else:
+        qk_p = F.linear(qk, w[:2 * E], b[:2 * E]).view(B, L, 2, H, d)
+        q, k = qk_p[:, :, 0].transpose(1, 2), qk_p[:, :, 1].transpose(1, 2)        # (B, H, L, d)
+        vh = F.linear(v, w[2 * E:], b[2 * E:]).view(B, L, H, d).transpose(1, 2)
     mask = None
     if key_padding_mask is not None and not getattr(key_padding_mask, "_no_padding", False):
         mask = ~key_padding_mask.view(B, 1, 1, L)                                   # True = take part
