@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define CLIPOPS_ABI_VERSION 2
+#define CLIPOPS_ABI_VERSION 3
 
 int clipops_abi_version(void);
 const char *clipops_last_error(void);
@@ -81,6 +81,11 @@ int clipops_inverse_sigmoid_bwd_f32(const float *x, const float *grad_y, long n,
 int clipops_refine_boxes_fwd_f32(const float *delta, const float *ref, long n, float eps, float *out, void *stream);
 int clipops_refine_boxes_bwd_f32(const float *out, const float *ref, const float *grad_out, long n, float eps,
                                  float *grad_delta, float *grad_ref, void *stream);
+
+/* Column sums of a small row-major matrix: out[c] = sum_r x[r*cols + c] -- the bias gradient of a Linear over a few
+ * hundred query rows.  torch's generic reduction takes 12-17 us for 310 x 256 .. 2048 on MI355X (one of ~400 such calls
+ * per train step); this one tiles 32 columns x 8 row lanes per workgroup and sums in a fixed order. */
+int clipops_colsum_f32(const float *x, long rows, int cols, float *out, void *stream);
 
 #ifdef __cplusplus
 }

@@ -344,6 +344,33 @@ __global__ __launch_bounds__(256) void refine_boxes_bwd_kernel(const float *__re
     }
 }
 
+// 32 columns x 8 row lanes per workgroup; lane (ty, tx) sums rows ty, ty + 8, ... of column tile tx
+__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ x, long rows, int cols,
+                                                    float *__restrict__ out) {
+    __shared__ float s_part[8][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + tx;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (c < cols) {
+        long r = ty;
+        for (; r + 24 < rows; r += 32) {          // four independent loads in flight
+            a0 += x[r * cols + c];
+            a1 += x[(r + 8) * cols + c];
+            a2 += x[(r + 16) * cols + c];
+            a3 += x[(r + 24) * cols + c];
+        }
+        for (; r < rows; r += 8) a0 += x[r * cols + c];
+    }
+    s_part[ty][tx] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (ty == 0 && c < cols) {
+        float t = s_part[0][tx];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) t += s_part[i][tx];
+        out[c] = t;
+    }
+}
+
 int grid_for(long total) {
     long g = (total + 255) / 256;
     if (g < 1) g = 1;
@@ -480,6 +507,14 @@ int clipops_refine_boxes_bwd_f32(const float *out, const float *ref, const float
     hipLaunchKernelGGL(refine_boxes_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, out, ref,
                        grad_out, n, eps, grad_delta, grad_ref);
     return check_launch("refine_boxes_bwd_kernel");
+}
+
+int clipops_colsum_f32(const float *x, long rows, int cols, float *out, void *stream) {
+    if (rows < 0 || cols < 0) return fail(1, "clipops_colsum_f32: bad dimension");
+    if (cols == 0) { g_err[0] = 0; return 0; }
+    if (!out || (rows > 0 && !x)) return fail(1, "clipops_colsum_f32: null pointer");
+    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 31) / 32), dim3(256), 0, (hipStream_t)stream, x, rows, cols, out);
+    return check_launch("colsum_kernel");
 }
 
 }  // extern "C"

@@ -260,3 +260,23 @@ def refine_boxes(delta: torch.Tensor, ref: torch.Tensor, eps: float = 1e-5) -> t
     if delta.shape != ref.shape:
         raise RuntimeError("refine_boxes: delta and ref must have the same shape")
     return _RefineBoxes.apply(delta.contiguous(), ref.contiguous(), float(eps))
+
+
+# --------------------------------------------------------------------------------------------------------------
+# bias gradients of the query-sized linears
+# --------------------------------------------------------------------------------------------------------------
+COLSUM_MAX_ROWS = 2048
+
+
+def colsum(x: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+    """x.sum(0) of a 2-d fp32 CUDA matrix with at most COLSUM_MAX_ROWS rows through the tiled kernel (torch's
+    generic reduction otherwise); ``out`` may be a contiguous (cols,) destination."""
+    if (x.dim() == 2 and x.shape[0] <= COLSUM_MAX_ROWS and x.is_contiguous() and fused(x)
+            and (out is None or (out.is_contiguous() and out.dtype == torch.float32))):
+        if out is None:
+            out = torch.empty((x.shape[1],), dtype=torch.float32, device=x.device)
+        L = _lib()
+        L.check(L.lib.clipops_colsum_f32(x.data_ptr(), x.shape[0], x.shape[1], out.data_ptr(), _stream(x)),
+                "clipops_colsum_f32")
+        return out
+    return torch.sum(x, 0, out=out) if out is not None else x.sum(0)

@@ -8,6 +8,7 @@ from torch.utils.checkpoint import checkpoint
 
 from ..modules import MSDeformAttn
 from ..modules.attention import self_attention
+from ..modules.linear import row_linear
 from ..utils.utils import inverse_sigmoid, refine_boxes
 from .decoder_graphs import DecoderGraphs
 from .mlp import MLP
@@ -178,8 +179,12 @@ class DeformableDecoderLayer(nn.Module):
         return torch.cat([tgt[:, :nd], self.norm4(tgt[:, nd:] + self.dropout5(attn))], dim=1)
 
     def forward_ffn(self, tgt):
-        hidden = self.dropout3(self.activation(self.linear1(tgt)))
-        return self.norm3(tgt + self.dropout4(self.linear2(hidden)))
+        hidden = row_linear(tgt, self.linear1.weight, self.linear1.bias)
+        # out of place: nn.Linear on a (B, L, E) input returns a VIEW of its product, and an in-place op on a view makes
+        # autograd rebase the graph (CopySlices + AsStrided backward nodes, six extra kernels per layer and frame)
+        hidden = torch.relu(hidden) if isinstance(self.activation, nn.ReLU) else self.activation(hidden)
+        hidden = self.dropout3(hidden)
+        return self.norm3(tgt + self.dropout4(row_linear(hidden, self.linear2.weight, self.linear2.bias)))
 
     def forward(self, tgt, query_pos, reference_points, src, src_spatial_shapes, level_start_index, query_mask,
                 src_padding_mask=None, merge_det_track=False):

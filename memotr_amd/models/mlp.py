@@ -2,6 +2,8 @@
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ..modules.linear import row_linear
+
 
 class MLP(nn.Module):
     def __init__(self, input_dim, hidden_dim, output_dim, num_layers):
@@ -13,7 +15,7 @@ class MLP(nn.Module):
     def forward(self, x):
         last = self.num_layers - 1
         for i, layer in enumerate(self.layers):
-            x = layer(x)
+            x = row_linear(x, layer.weight, layer.bias)
             if i < last:
                 x = F.relu(x)
         return x

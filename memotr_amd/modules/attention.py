@@ -41,8 +41,9 @@ class _PackedInProj(torch.autograd.Function):
         gw, gb = torch.empty_like(w), torch.empty((3 * E,), dtype=w.dtype, device=w.device)
         torch.mm(g_qk2.t(), qk2, out=gw[:2 * E])
         torch.mm(g_v2.t(), v2, out=gw[2 * E:])
-        torch.sum(g_qk2, 0, out=gb[:2 * E])
-        torch.sum(g_v2, 0, out=gb[2 * E:])
+        from ..functions import clip_ops
+        clip_ops.colsum(g_qk2.contiguous(), out=gb[:2 * E])          # (tiled kernel for query-sized inputs)
+        clip_ops.colsum(g_v2.contiguous(), out=gb[2 * E:])
         g_in_qk = (g_qk2 @ w[:2 * E]).view(ctx.shapes[0]) if ctx.needs_input_grad[0] else None
         g_in_v = (g_v2 @ w[2 * E:]).view(ctx.shapes[1]) if ctx.needs_input_grad[1] else None
         return g_in_qk, g_in_v, gw, gb
@@ -76,4 +77,5 @@ def self_attention(mha: nn.MultiheadAttention, qk: torch.Tensor, v: torch.Tensor
     out = F.scaled_dot_product_attention(q, k, vh, attn_mask=mask,
                                          dropout_p=mha.dropout if mha.training else 0.0)
     out = out.transpose(1, 2).reshape(B, L, E)
-    return F.linear(out, mha.out_proj.weight, mha.out_proj.bias)
+    from .linear import row_linear
+    return row_linear(out, mha.out_proj.weight, mha.out_proj.bias)

@@ -199,3 +199,36 @@ def test_inverse_sigmoid_and_refine_boxes_values_masks_and_gradients():
     d = delta.clone().requires_grad_(True)
     refine_boxes(d, ref).sum().backward()
     assert d.grad is not None
+
+
+@pytest.mark.parametrize("rows,cols", [(310, 256), (300, 2048), (1, 4), (0, 8), (2048, 33), (320, 512)])
+def test_colsum_equals_torch_sum(rows, cols):
+    from memotr_amd.functions import clip_ops
+    x = torch.randn(rows, cols, generator=torch.Generator().manual_seed(rows + cols)).cuda()
+    got = clip_ops.colsum(x)
+    torch.testing.assert_close(got, x.double().sum(0).float(), rtol=1e-5, atol=1e-4)
+    out = torch.empty(3 * cols, device="cuda")
+    clip_ops.colsum(x, out=out[cols:2 * cols])
+    assert torch.equal(out[cols:2 * cols], got)                  # fixed summation order
+    big = torch.randn(clip_ops.COLSUM_MAX_ROWS + 1, 8).cuda()     # beyond the tile kernel's range: torch's reduction
+    torch.testing.assert_close(clip_ops.colsum(big), big.sum(0))
+
+
+def test_row_linear_matches_f_linear():
+    import torch.nn.functional as F
+    from memotr_amd.modules.linear import row_linear
+    g = torch.Generator().manual_seed(4)
+    for shape in ((1, 310, 256), (300, 256)):
+        x = torch.randn(*shape, generator=g).cuda()
+        w, b = torch.randn(512, 256, generator=g).cuda(), torch.randn(512, generator=g).cuda()
+        up = torch.randn(*shape[:-1], 512, generator=g).cuda()
+        res = {}
+        for name, fn in (("row", row_linear), ("torch", F.linear)):
+            xi, wi, bi = (t.clone().requires_grad_(True) for t in (x, w, b))
+            y = fn(xi, wi, bi)
+            (y * up).sum().backward()
+            res[name] = (y.detach(), xi.grad, wi.grad, bi.grad)
+        for a, b_ in zip(res["row"], res["torch"]):
+            torch.testing.assert_close(a, b_, rtol=1e-5, atol=1e-4)
+    with torch.no_grad():                                         # nothing to differentiate: plain F.linear
+        assert row_linear(x, w, b).grad_fn is None
