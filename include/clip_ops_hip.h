@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define CLIPOPS_ABI_VERSION 3
+#define CLIPOPS_ABI_VERSION 4
 
 int clipops_abi_version(void);
 const char *clipops_last_error(void);
@@ -86,6 +86,9 @@ int clipops_refine_boxes_bwd_f32(const float *out, const float *ref, const float
  * hundred query rows.  torch's generic reduction takes 12-17 us for 310 x 256 .. 2048 on MI355X (one of ~400 such calls
  * per train step); this one tiles 32 columns x 8 row lanes per workgroup and sums in a fixed order. */
 int clipops_colsum_f32(const float *x, long rows, int cols, float *out, void *stream);
+/* First pass for tall matrices: partial[k*cols + c] = sum of rows [k*chunk_rows, (k+1)*chunk_rows) of column c,
+ * k < ceil(rows / chunk_rows); clipops_colsum_f32 over `partial` finishes (fixed order end to end). */
+int clipops_colsum_partial_f32(const float *x, long rows, int cols, int chunk_rows, float *partial, void *stream);
 
 #ifdef __cplusplus
 }

@@ -371,6 +371,35 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ x
     }
 }
 
+// the same tile over one chunk of rows per workgroup row (blockIdx.y): partial sums for tall matrices
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__restrict__ x, long rows, int cols,
+                                                            int chunk_rows, float *__restrict__ partial) {
+    __shared__ float s_part[8][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + tx;
+    const long r0 = (long)blockIdx.y * chunk_rows;
+    const long r1 = r0 + chunk_rows < rows ? r0 + chunk_rows : rows;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (c < cols) {
+        long r = r0 + ty;
+        for (; r + 24 < r1; r += 32) {
+            a0 += x[r * cols + c];
+            a1 += x[(r + 8) * cols + c];
+            a2 += x[(r + 16) * cols + c];
+            a3 += x[(r + 24) * cols + c];
+        }
+        for (; r < r1; r += 8) a0 += x[r * cols + c];
+    }
+    s_part[ty][tx] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (ty == 0 && c < cols) {
+        float t = s_part[0][tx];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) t += s_part[i][tx];
+        partial[(long)blockIdx.y * cols + c] = t;
+    }
+}
+
 int grid_for(long total) {
     long g = (total + 255) / 256;
     if (g < 1) g = 1;
@@ -515,6 +544,17 @@ int clipops_colsum_f32(const float *x, long rows, int cols, float *out, void *st
     if (!out || (rows > 0 && !x)) return fail(1, "clipops_colsum_f32: null pointer");
     hipLaunchKernelGGL(colsum_kernel, dim3((cols + 31) / 32), dim3(256), 0, (hipStream_t)stream, x, rows, cols, out);
     return check_launch("colsum_kernel");
+}
+
+int clipops_colsum_partial_f32(const float *x, long rows, int cols, int chunk_rows, float *partial, void *stream) {
+    if (rows < 0 || cols < 0 || chunk_rows <= 0) return fail(1, "clipops_colsum_partial_f32: bad dimension");
+    if (cols == 0 || rows == 0) { g_err[0] = 0; return 0; }
+    if (!x || !partial) return fail(1, "clipops_colsum_partial_f32: null pointer");
+    const long chunks = (rows + chunk_rows - 1) / chunk_rows;
+    if (chunks > 65535) return fail(1, "clipops_colsum_partial_f32: too many chunks");
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 31) / 32, (unsigned)chunks), dim3(256), 0,
+                       (hipStream_t)stream, x, rows, cols, chunk_rows, partial);
+    return check_launch("colsum_partial_kernel");
 }
 
 }  // extern "C"

@@ -18,6 +18,11 @@ def fused(*tensors) -> bool:
             and all(t.is_cuda and (t.dtype == torch.float32 or not t.is_floating_point()) for t in tensors))
 
 
+def config_key() -> tuple:
+    """The environment switches that change which kernels a captured graph contains."""
+    return (os.environ.get("MEMOTR_FUSED_CLIP_OPS", "1"), os.environ.get("MEMOTR_COLSUM_TALL", "1"))
+
+
 def _lib():
     from .. import _clip_lib        # raises ImportError when the library is missing: no silent substitute
     return _clip_lib
@@ -265,18 +270,30 @@ def refine_boxes(delta: torch.Tensor, ref: torch.Tensor, eps: float = 1e-5) -> t
 # --------------------------------------------------------------------------------------------------------------
 # bias gradients of the query-sized linears
 # --------------------------------------------------------------------------------------------------------------
-COLSUM_MAX_ROWS = 2048
+COLSUM_MAX_ROWS = 2048          # one pass of the tile kernel
+COLSUM_CHUNK_ROWS = 256         # tall matrices: partial sums per 256 rows, then one pass over the partials
 
 
 def colsum(x: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
-    """x.sum(0) of a 2-d fp32 CUDA matrix with at most COLSUM_MAX_ROWS rows through the tiled kernel (torch's
-    generic reduction otherwise); ``out`` may be a contiguous (cols,) destination."""
-    if (x.dim() == 2 and x.shape[0] <= COLSUM_MAX_ROWS and x.is_contiguous() and fused(x)
-            and (out is None or (out.is_contiguous() and out.dtype == torch.float32))):
-        if out is None:
-            out = torch.empty((x.shape[1],), dtype=torch.float32, device=x.device)
-        L = _lib()
-        L.check(L.lib.clipops_colsum_f32(x.data_ptr(), x.shape[0], x.shape[1], out.data_ptr(), _stream(x)),
-                "clipops_colsum_f32")
-        return out
-    return torch.sum(x, 0, out=out) if out is not None else x.sum(0)
+    """x.sum(0) of a contiguous 2-d fp32 CUDA matrix through the tiled kernels (fixed summation order): one pass up to
+    COLSUM_MAX_ROWS rows, two passes (per-chunk partial sums, then the partials) above; anything else takes torch's
+    reduction.  ``out`` may be a contiguous (cols,) destination."""
+    ok = (x.dim() == 2 and x.is_contiguous() and fused(x) and x.dtype == torch.float32
+          and (out is None or (out.is_contiguous() and out.dtype == torch.float32))
+          and x.shape[0] <= COLSUM_MAX_ROWS * COLSUM_CHUNK_ROWS)
+    if not ok:
+        return torch.sum(x, 0, out=out) if out is not None else x.sum(0)
+    if x.shape[0] > COLSUM_MAX_ROWS and os.environ.get("MEMOTR_COLSUM_TALL", "1") == "0":
+        return torch.sum(x, 0, out=out) if out is not None else x.sum(0)
+    L = _lib()
+    if x.shape[0] > COLSUM_MAX_ROWS:
+        chunks = -(-x.shape[0] // COLSUM_CHUNK_ROWS)
+        partial = torch.empty((chunks, x.shape[1]), dtype=torch.float32, device=x.device)
+        L.check(L.lib.clipops_colsum_partial_f32(x.data_ptr(), x.shape[0], x.shape[1], COLSUM_CHUNK_ROWS,
+                                                 partial.data_ptr(), _stream(x)), "clipops_colsum_partial_f32")
+        x = partial
+    if out is None:
+        out = torch.empty((x.shape[1],), dtype=torch.float32, device=x.device)
+    L.check(L.lib.clipops_colsum_f32(x.data_ptr(), x.shape[0], x.shape[1], out.data_ptr(), _stream(x)),
+            "clipops_colsum_f32")
+    return out

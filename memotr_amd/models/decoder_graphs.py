@@ -30,6 +30,7 @@ from collections import OrderedDict
 import torch
 import torch.nn as nn
 
+from ..functions import clip_ops
 from ..utils.utils import inverse_sigmoid, refine_boxes
 from .utils import pos_to_pos_embed
 
@@ -130,7 +131,7 @@ class DecoderGraphs:
     def run(self, frame_slot: int, args, shapes, lsi, clip_key=None):
         """The decoder loop of frame ``frame_slot`` through its graph (captured on first use); None if capture failed."""
         key = (frame_slot, tuple(a.shape for a in args), tuple(bool(a.requires_grad) for a in args), id(shapes),
-               os.environ.get("MEMOTR_FUSED_CLIP_OPS", "1"))          # (a capture bakes the kernel choice in)
+               clip_ops.config_key())                                  # (a capture bakes the kernel choice in)
         slot = self.slots.get(key)
         if slot is None:
             slot = self._capture(args, shapes, lsi)

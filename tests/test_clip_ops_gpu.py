@@ -210,8 +210,10 @@ def test_colsum_equals_torch_sum(rows, cols):
     out = torch.empty(3 * cols, device="cuda")
     clip_ops.colsum(x, out=out[cols:2 * cols])
     assert torch.equal(out[cols:2 * cols], got)                  # fixed summation order
-    big = torch.randn(clip_ops.COLSUM_MAX_ROWS + 1, 8).cuda()     # beyond the tile kernel's range: torch's reduction
-    torch.testing.assert_close(clip_ops.colsum(big), big.sum(0))
+    for tall in (clip_ops.COLSUM_MAX_ROWS + 1, 22323, 66969):     # two passes: per-chunk partials, then the partials
+        big = torch.randn(tall, 40, generator=torch.Generator().manual_seed(tall)).cuda()
+        torch.testing.assert_close(clip_ops.colsum(big), big.double().sum(0).float(), rtol=1e-5, atol=2e-3)
+    torch.testing.assert_close(clip_ops.colsum(x.t().contiguous().t()), x.sum(0)) # not contiguous: torch's reduction
 
 
 def test_row_linear_matches_f_linear():
