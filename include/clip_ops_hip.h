@@ -47,7 +47,7 @@ int clipops_pair_box_loss_bwd_f32(const float *boxes, const int64_t *lay, const 
                                   int n, const float *grad_l1, const float *grad_giou, float *grad_boxes,
                                   void *stream);
 
-/* IoU of n box pairs, no gradient (reference models/criterion.py:241-262, the `iou` field of the tracks):
+/* IoU of n box pairs, no gradient (reference models/criterion.py:354-367, the `iou` field of the tracks):
  * iou[i] = IoU(xyxy(boxes[i]), xyxy(tgt_boxes[gidx[i]]))  (gidx == NULL: row i); boxes (n,4) cxcywh contiguous. */
 int clipops_pair_iou_f32(const float *boxes, const float *tgt_boxes, const int64_t *gidx, int n, float *iou,
                          void *stream);
