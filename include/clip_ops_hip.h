@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define CLIPOPS_ABI_VERSION 4
+#define CLIPOPS_ABI_VERSION 5
 
 int clipops_abi_version(void);
 const char *clipops_last_error(void);
@@ -89,6 +89,26 @@ int clipops_colsum_f32(const float *x, long rows, int cols, float *out, void *st
 /* First pass for tall matrices: partial[k*cols + c] = sum of rows [k*chunk_rows, (k+1)*chunk_rows) of column c,
  * k < ceil(rows / chunk_rows); clipops_colsum_f32 over `partial` finishes (fixed order end to end). */
 int clipops_colsum_partial_f32(const float *x, long rows, int cols, int chunk_rows, float *partial, void *stream);
+
+/* Multi-head self-attention over the decoder queries (reference models/deformable_decoder.py:245-249: the
+ * nn.MultiheadAttention call with query = key = tgt + pos, value = tgt; here after the input projections):
+ *   out[b,i,h,:] = sum_j softmax_j(scale * q[b,i,h,:] . k[b,j,h,:]  |  key_mask[b,j] == 0) * v[b,j,h,:]
+ * head_dim is 32, L <= CLIPOPS_MHA_MAX_L; fp32, exact softmax (per-lane online softmax merged over the 8 lanes of a
+ * query row), K and V of a head staged in LDS.  q / k / v are addressed as base + b*batch_stride + i*row_stride + h*32
+ * (element strides), so the packed (B, L, 2E) projection of q and k needs no copy; key_mask (B, L) bytes, non-zero =
+ * ignore that key, may be NULL; out (B, L, H*32) contiguous; lse (B, H, L) receives max + log(sum) per row for the
+ * backward.  Replaces the AOTriton kernels behind F.scaled_dot_product_attention on this path. */
+#define CLIPOPS_MHA_MAX_L 512
+int clipops_mha_fwd_f32(const float *q, const float *k, const float *v, long q_bs, long q_rs, long k_bs, long k_rs,
+                        long v_bs, long v_rs, const uint8_t *key_mask, int B, int H, int L, float scale, float *out,
+                        float *lse, void *stream);
+/* Gradients of the above.  grad_out (B, L, H*32) contiguous; grad_q / grad_k / grad_v are addressed like q / k / v
+ * (each its own batch / row stride, so grad_q and grad_k can be the two halves of one (B, L, 2E) buffer).  Two kernels:
+ * one by query rows (grad_q), one by key rows (grad_k, grad_v); probabilities are recomputed from lse. */
+int clipops_mha_bwd_f32(const float *q, const float *k, const float *v, long q_bs, long q_rs, long k_bs, long k_rs,
+                        long v_bs, long v_rs, const uint8_t *key_mask, const float *out, const float *lse,
+                        const float *grad_out, int B, int H, int L, float scale, float *grad_q, long gq_bs, long gq_rs,
+                        float *grad_k, long gk_bs, long gk_rs, float *grad_v, long gv_bs, long gv_rs, void *stream);
 
 #ifdef __cplusplus
 }

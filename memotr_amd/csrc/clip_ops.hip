@@ -8,6 +8,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <atomic>
+
 #include "../../include/clip_ops_hip.h"
 
 namespace {
@@ -400,6 +402,238 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__rest
     }
 }
 
+// ----------------------------------------------------------------------------------------
+// multi-head self-attention over the decoder queries (head_dim 32, L <= 512): forward and backward
+// ----------------------------------------------------------------------------------------
+// One workgroup = 32 rows x 8 lanes (256 threads) of one (batch, head).  A lane of a row visits the rows of the
+// OTHER axis j = lane, lane + 8, ... : 32-float dot products against rows staged in LDS (pitch 36 floats: the eight
+// lanes of a row hit eight different bank groups, the eight rows of a wavefront read the same addresses = broadcast).
+constexpr int kHd = 32;            // head dimension
+constexpr int kPitch = 36;         // LDS row pitch in floats
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void load_row32(const float *p, float *r) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const f32x4_t v = *reinterpret_cast<const f32x4_t *>(p + 4 * i);
+        r[4 * i] = v.x; r[4 * i + 1] = v.y; r[4 * i + 2] = v.z; r[4 * i + 3] = v.w;
+    }
+}
+
+__device__ __forceinline__ float dot32(const float *a, const float *lds_row) {
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const f32x4_t v = *reinterpret_cast<const f32x4_t *>(lds_row + 4 * i);
+        s0 = fmaf(a[4 * i], v.x, s0);
+        s1 = fmaf(a[4 * i + 1], v.y, s1);
+        s0 = fmaf(a[4 * i + 2], v.z, s0);
+        s1 = fmaf(a[4 * i + 3], v.w, s1);
+    }
+    return s0 + s1;
+}
+
+__device__ __forceinline__ void axpy32(float *acc, float w, const float *lds_row) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const f32x4_t v = *reinterpret_cast<const f32x4_t *>(lds_row + 4 * i);
+        acc[4 * i] = fmaf(w, v.x, acc[4 * i]);
+        acc[4 * i + 1] = fmaf(w, v.y, acc[4 * i + 1]);
+        acc[4 * i + 2] = fmaf(w, v.z, acc[4 * i + 2]);
+        acc[4 * i + 3] = fmaf(w, v.w, acc[4 * i + 3]);
+    }
+}
+
+// sum over the 8 lanes of a row (lanes differ in bits 0..2 of the lane id)
+__device__ __forceinline__ float sum8l(float x) {
+    x += __shfl_xor(x, 1, 64);
+    x += __shfl_xor(x, 2, 64);
+    x += __shfl_xor(x, 4, 64);
+    return x;
+}
+
+// cooperative copy of L rows (32 floats each, `rs` apart) into LDS at pitch kPitch
+__device__ __forceinline__ void stage_rows(float *dst, const float *src, long rs, int L) {
+    for (int i = threadIdx.x; i < L * 8; i += blockDim.x) {
+        const int r = i >> 3, c = (i & 7) * 4;
+        *reinterpret_cast<f32x4_t *>(dst + r * kPitch + c) = *reinterpret_cast<const f32x4_t *>(src + r * rs + c);
+    }
+}
+
+__global__ __launch_bounds__(256) void mha_fwd_kernel(const float *__restrict__ q, const float *__restrict__ k,
+                                                     const float *__restrict__ v, long q_bs, long q_rs, long k_bs,
+                                                     long k_rs, long v_bs, long v_rs,
+                                                     const uint8_t *__restrict__ key_mask, int H, int L, float scale,
+                                                     float *__restrict__ out, float *__restrict__ lse) {
+    extern __shared__ __attribute__((aligned(16))) float s_mem[];
+    float *Ks = s_mem, *Vs = s_mem + (size_t)L * kPitch;
+    const int h = blockIdx.y, b = blockIdx.z;
+    stage_rows(Ks, k + b * k_bs + h * kHd, k_rs, L);
+    stage_rows(Vs, v + b * v_bs + h * kHd, v_rs, L);
+    __syncthreads();
+    const int row = blockIdx.x * 32 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
+    const bool row_ok = row < L;
+    const int rowc = row_ok ? row : L - 1;
+    float qr[kHd];
+    load_row32(q + b * q_bs + rowc * q_rs + h * kHd, qr);
+#pragma unroll
+    for (int i = 0; i < kHd; ++i) qr[i] *= scale;
+    const uint8_t *mk = key_mask ? key_mask + (long)b * L : nullptr;
+    float m = -INFINITY, l = 0.f, acc[kHd];
+#pragma unroll
+    for (int i = 0; i < kHd; ++i) acc[i] = 0.f;
+    for (int j = sub; j < L; j += 8) {
+        if (mk && mk[j]) continue;
+        const float s = dot32(qr, Ks + j * kPitch);
+        const float m_new = fmaxf(m, s);
+        const float corr = expf(m - m_new), p = expf(s - m_new);      // exp(-inf) = 0 on the first key
+        l = l * corr + p;
+#pragma unroll
+        for (int i = 0; i < kHd; ++i) acc[i] *= corr;
+        axpy32(acc, p, Vs + j * kPitch);
+        m = m_new;
+    }
+    // merge the 8 lanes of the row
+    float M = m;
+    M = fmaxf(M, __shfl_xor(M, 1, 64));
+    M = fmaxf(M, __shfl_xor(M, 2, 64));
+    M = fmaxf(M, __shfl_xor(M, 4, 64));
+    const float w = (m == -INFINITY) ? 0.f : expf(m - M);          // a lane may have seen no key at all
+    const float Lsum = sum8l(l * w);
+    const float inv = 1.f / Lsum;
+    float *o = out + ((long)b * L + rowc) * (H * kHd) + h * kHd;
+#pragma unroll
+    for (int i = 0; i < kHd; ++i) {
+        const float t = sum8l(acc[i] * w) * inv;
+        if (row_ok && (i >> 2) == sub) o[i] = t;                   // lane `sub` stores floats 4*sub .. 4*sub+3
+    }
+    if (row_ok && sub == 0) lse[((long)b * H + h) * L + row] = M + logf(Lsum);
+}
+
+// grad_q: same decomposition as the forward (a workgroup = 32 query rows; K and V of the head in LDS)
+__global__ __launch_bounds__(256) void mha_bwd_q_kernel(const float *__restrict__ q, const float *__restrict__ k,
+                                                       const float *__restrict__ v, long q_bs, long q_rs, long k_bs,
+                                                       long k_rs, long v_bs, long v_rs,
+                                                       const uint8_t *__restrict__ key_mask,
+                                                       const float *__restrict__ out, const float *__restrict__ lse,
+                                                       const float *__restrict__ go, int H, int L, float scale,
+                                                       float *__restrict__ gq, long gq_bs, long gq_rs) {
+    extern __shared__ __attribute__((aligned(16))) float s_mem[];
+    float *Ks = s_mem, *Vs = s_mem + (size_t)L * kPitch;
+    const int h = blockIdx.y, b = blockIdx.z;
+    stage_rows(Ks, k + b * k_bs + h * kHd, k_rs, L);
+    stage_rows(Vs, v + b * v_bs + h * kHd, v_rs, L);
+    __syncthreads();
+    const int row = blockIdx.x * 32 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
+    const bool row_ok = row < L;
+    const int rowc = row_ok ? row : L - 1;
+    float qr[kHd], gr[kHd], acc[kHd];
+    load_row32(q + b * q_bs + rowc * q_rs + h * kHd, qr);
+    const long orow = ((long)b * L + rowc) * (H * kHd) + h * kHd;
+    load_row32(go + orow, gr);
+    float D = 0.f;                                                  // rowsum(dP o P) = dO . O
+    {
+        float orr[kHd];
+        load_row32(out + orow, orr);
+#pragma unroll
+        for (int i = 0; i < kHd; ++i) D = fmaf(gr[i], orr[i], D);
+    }
+#pragma unroll
+    for (int i = 0; i < kHd; ++i) { qr[i] *= scale; acc[i] = 0.f; }
+    const float ls = lse[((long)b * H + h) * L + rowc];
+    const uint8_t *mk = key_mask ? key_mask + (long)b * L : nullptr;
+    for (int j = sub; j < L; j += 8) {
+        if (mk && mk[j]) continue;
+        const float p = expf(dot32(qr, Ks + j * kPitch) - ls);
+        const float ds = p * (dot32(gr, Vs + j * kPitch) - D);
+        axpy32(acc, ds, Ks + j * kPitch);
+    }
+    float *g = gq + b * gq_bs + rowc * gq_rs + h * kHd;
+#pragma unroll
+    for (int i = 0; i < kHd; ++i) {
+        const float t = sum8l(acc[i]) * scale;
+        if (row_ok && (i >> 2) == sub) g[i] = t;
+    }
+}
+
+// grad_k, grad_v: a workgroup = 32 KEY rows; Q and dO of the head in LDS, lse and D = dO . O per query too
+__global__ __launch_bounds__(256) void mha_bwd_kv_kernel(const float *__restrict__ q, const float *__restrict__ k,
+                                                        const float *__restrict__ v, long q_bs, long q_rs, long k_bs,
+                                                        long k_rs, long v_bs, long v_rs,
+                                                        const uint8_t *__restrict__ key_mask,
+                                                        const float *__restrict__ out, const float *__restrict__ lse,
+                                                        const float *__restrict__ go, int H, int L, float scale,
+                                                        float *__restrict__ gk, long gk_bs, long gk_rs,
+                                                        float *__restrict__ gv, long gv_bs, long gv_rs) {
+    extern __shared__ __attribute__((aligned(16))) float s_mem[];
+    float *Qs = s_mem, *Gs = s_mem + (size_t)L * kPitch;
+    float *s_lse = Gs + (size_t)L * kPitch, *s_D = s_lse + L;
+    const int h = blockIdx.y, b = blockIdx.z;
+    stage_rows(Qs, q + b * q_bs + h * kHd, q_rs, L);
+    stage_rows(Gs, go + (long)b * L * (H * kHd) + h * kHd, (long)H * kHd, L);
+    for (int i = threadIdx.x; i < L; i += blockDim.x) s_lse[i] = lse[((long)b * H + h) * L + i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < L; i += blockDim.x) {             // D_i = dO_i . O_i
+        const float *o = out + ((long)b * L + i) * (H * kHd) + h * kHd;
+        float d = 0.f;
+#pragma unroll
+        for (int c = 0; c < kHd; ++c) d = fmaf(Gs[i * kPitch + c], o[c], d);
+        s_D[i] = d;
+    }
+    __syncthreads();
+    const int row = blockIdx.x * 32 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
+    const bool row_ok = row < L;
+    const int rowc = row_ok ? row : L - 1;
+    const bool dead = key_mask && key_mask[(long)b * L + rowc];     // a masked key receives no gradient
+    float kr[kHd], vr[kHd], ak[kHd], av[kHd];
+    load_row32(k + b * k_bs + rowc * k_rs + h * kHd, kr);
+    load_row32(v + b * v_bs + rowc * v_rs + h * kHd, vr);
+#pragma unroll
+    for (int i = 0; i < kHd; ++i) { kr[i] *= scale; ak[i] = 0.f; av[i] = 0.f; }
+    if (!dead) {
+        for (int i = sub; i < L; i += 8) {
+            const float p = expf(dot32(kr, Qs + i * kPitch) - s_lse[i]);
+            const float ds = p * (dot32(vr, Gs + i * kPitch) - s_D[i]);
+            axpy32(av, p, Gs + i * kPitch);
+            axpy32(ak, ds, Qs + i * kPitch);
+        }
+    }
+    float *pk = gk + b * gk_bs + rowc * gk_rs + h * kHd, *pv = gv + b * gv_bs + rowc * gv_rs + h * kHd;
+#pragma unroll
+    for (int i = 0; i < kHd; ++i) {
+        const float tk = sum8l(ak[i]) * scale, tv = sum8l(av[i]);
+        if (row_ok && (i >> 2) == sub) {
+            pk[i] = tk;
+            pv[i] = tv;
+        }
+    }
+}
+
+// dynamic LDS above 64 KiB has to be allowed once per kernel and device (one bit per device ordinal in `done`)
+int allow_lds(const void *kernel, size_t lds, std::atomic<unsigned long long> &done) {
+    if (lds <= 64 * 1024) return 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return 0;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+    if (e != hipSuccess) {
+        snprintf(g_err, sizeof(g_err), "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    done.fetch_or(bit, std::memory_order_release);
+    return 0;
+}
+
+std::atomic<unsigned long long> g_lds_fwd{0}, g_lds_bq{0}, g_lds_bkv{0};
+
+int mha_check(const void *q, const void *k, const void *v, int B, int H, int L) {
+    if (B < 0 || H <= 0 || L < 0) return fail(1, "clipops_mha: bad dimension");
+    if (L > CLIPOPS_MHA_MAX_L) return fail(2, "clipops_mha: L exceeds CLIPOPS_MHA_MAX_L");
+    if ((long)B * L > 0 && (!q || !k || !v)) return fail(1, "clipops_mha: null pointer");
+    return 0;
+}
+
 int grid_for(long total) {
     long g = (total + 255) / 256;
     if (g < 1) g = 1;
@@ -555,6 +789,41 @@ int clipops_colsum_partial_f32(const float *x, long rows, int cols, int chunk_ro
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 31) / 32, (unsigned)chunks), dim3(256), 0,
                        (hipStream_t)stream, x, rows, cols, chunk_rows, partial);
     return check_launch("colsum_partial_kernel");
+}
+
+int clipops_mha_fwd_f32(const float *q, const float *k, const float *v, long q_bs, long q_rs, long k_bs, long k_rs,
+                        long v_bs, long v_rs, const uint8_t *key_mask, int B, int H, int L, float scale, float *out,
+                        float *lse, void *stream) {
+    int rc = mha_check(q, k, v, B, H, L);
+    if (rc) return rc;
+    if ((long)B * L == 0) { g_err[0] = 0; return 0; }
+    if (!out || !lse) return fail(1, "clipops_mha_fwd_f32: null pointer");
+    const size_t lds = (size_t)2 * L * kPitch * sizeof(float);
+    if ((rc = allow_lds(reinterpret_cast<const void *>(mha_fwd_kernel), lds, g_lds_fwd))) return rc;
+    hipLaunchKernelGGL(mha_fwd_kernel, dim3((L + 31) / 32, H, B), dim3(256), lds, (hipStream_t)stream, q, k, v, q_bs,
+                       q_rs, k_bs, k_rs, v_bs, v_rs, key_mask, H, L, scale, out, lse);
+    return check_launch("mha_fwd_kernel");
+}
+
+int clipops_mha_bwd_f32(const float *q, const float *k, const float *v, long q_bs, long q_rs, long k_bs, long k_rs,
+                        long v_bs, long v_rs, const uint8_t *key_mask, const float *out, const float *lse,
+                        const float *grad_out, int B, int H, int L, float scale, float *grad_q, long gq_bs, long gq_rs,
+                        float *grad_k, long gk_bs, long gk_rs, float *grad_v, long gv_bs, long gv_rs, void *stream) {
+    int rc = mha_check(q, k, v, B, H, L);
+    if (rc) return rc;
+    if ((long)B * L == 0) { g_err[0] = 0; return 0; }
+    if (!out || !lse || !grad_out || !grad_q || !grad_k || !grad_v) return fail(1, "clipops_mha_bwd_f32: null pointer");
+    const size_t lds_q = (size_t)2 * L * kPitch * sizeof(float);
+    const size_t lds_kv = lds_q + (size_t)2 * L * sizeof(float);
+    if ((rc = allow_lds(reinterpret_cast<const void *>(mha_bwd_q_kernel), lds_q, g_lds_bq))) return rc;
+    if ((rc = allow_lds(reinterpret_cast<const void *>(mha_bwd_kv_kernel), lds_kv, g_lds_bkv))) return rc;
+    const dim3 grid((L + 31) / 32, H, B);
+    hipLaunchKernelGGL(mha_bwd_q_kernel, grid, dim3(256), lds_q, (hipStream_t)stream, q, k, v, q_bs, q_rs, k_bs, k_rs,
+                       v_bs, v_rs, key_mask, out, lse, grad_out, H, L, scale, grad_q, gq_bs, gq_rs);
+    if ((rc = check_launch("mha_bwd_q_kernel"))) return rc;
+    hipLaunchKernelGGL(mha_bwd_kv_kernel, grid, dim3(256), lds_kv, (hipStream_t)stream, q, k, v, q_bs, q_rs, k_bs, k_rs,
+                       v_bs, v_rs, key_mask, out, lse, grad_out, H, L, scale, grad_k, gk_bs, gk_rs, grad_v, gv_bs, gv_rs);
+    return check_launch("mha_bwd_kv_kernel");
 }
 
 }  // extern "C"

@@ -297,3 +297,68 @@ def colsum(x: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
     L.check(L.lib.clipops_colsum_f32(x.data_ptr(), x.shape[0], x.shape[1], out.data_ptr(), _stream(x)),
             "clipops_colsum_f32")
     return out
+
+
+# --------------------------------------------------------------------------------------------------------------
+# self-attention over the decoder queries (head_dim 32)
+# --------------------------------------------------------------------------------------------------------------
+MHA_MAX_L = 512
+MHA_HEAD_DIM = 32
+
+
+class _SelfAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qk_p, v_p, key_mask, n_heads):
+        B, L, E2 = qk_p.shape
+        E = E2 // 2
+        out = torch.empty((B, L, E), dtype=torch.float32, device=qk_p.device)
+        lse = torch.empty((B, n_heads, L), dtype=torch.float32, device=qk_p.device)
+        scale = 1.0 / (E // n_heads) ** 0.5
+        mk = None if key_mask is None else key_mask.data_ptr()
+        L_ = _lib()
+        L_.check(L_.lib.clipops_mha_fwd_f32(qk_p.data_ptr(), qk_p.data_ptr() + 4 * E, v_p.data_ptr(), L * E2, E2, L * E2,
+                                            E2, L * E, E, mk, B, n_heads, L, scale, out.data_ptr(), lse.data_ptr(),
+                                            _stream(qk_p)), "clipops_mha_fwd_f32")
+        ctx.save_for_backward(qk_p, v_p, key_mask, out, lse)
+        ctx.n_heads, ctx.scale = n_heads, scale
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        qk_p, v_p, key_mask, out, lse = ctx.saved_tensors
+        B, L, E2 = qk_p.shape
+        E = E2 // 2
+        g = g.contiguous()
+        g_qk, g_v = torch.empty_like(qk_p), torch.empty_like(v_p)
+        mk = None if key_mask is None else key_mask.data_ptr()
+        L_ = _lib()
+        L_.check(L_.lib.clipops_mha_bwd_f32(qk_p.data_ptr(), qk_p.data_ptr() + 4 * E, v_p.data_ptr(), L * E2, E2, L * E2,
+                                            E2, L * E, E, mk, out.data_ptr(), lse.data_ptr(), g.data_ptr(), B, ctx.n_heads,
+                                            L, ctx.scale, g_qk.data_ptr(), L * E2, E2, g_qk.data_ptr() + 4 * E, L * E2,
+                                            E2, g_v.data_ptr(), L * E, E, _stream(qk_p)), "clipops_mha_bwd_f32")
+        return g_qk, g_v, None, None
+
+
+def self_attention_supported(qk_p: torch.Tensor, n_heads: int) -> bool:
+    B, L, E2 = qk_p.shape
+    return (fused(qk_p) and qk_p.dtype == torch.float32 and E2 % (2 * n_heads) == 0
+            and E2 // 2 // n_heads == MHA_HEAD_DIM and 0 < L <= MHA_MAX_L)
+
+
+def self_attention(qk_p: torch.Tensor, v_p: torch.Tensor, key_padding_mask, n_heads: int) -> torch.Tensor:
+    """softmax(q k^T / sqrt(d)) v per head from the packed projections: qk_p (B, L, 2E) = [q | k], v_p (B, L, E);
+    key_padding_mask (B, L) bool (True = ignore that key) or None.  Returns (B, L, E), heads concatenated -- the
+    layout the output projection takes, no transposes or copies either side."""
+    mask = None if key_padding_mask is None else key_padding_mask.contiguous()
+    return _SelfAttention.apply(qk_p.contiguous(), v_p.contiguous(), mask, int(n_heads))
+
+
+def self_attention_reference(qk_p, v_p, key_padding_mask, n_heads):
+    B, L, E2 = qk_p.shape
+    E, d = E2 // 2, E2 // 2 // n_heads
+    q, k = (t.transpose(1, 2) for t in qk_p.view(B, L, 2, n_heads, d).unbind(2))
+    v = v_p.view(B, L, n_heads, d).transpose(1, 2)
+    att = (q @ k.transpose(-1, -2)) / d ** 0.5
+    if key_padding_mask is not None:
+        att = att.masked_fill(key_padding_mask.view(B, 1, 1, L), float("-inf"))
+    return (att.softmax(-1) @ v).transpose(1, 2).reshape(B, L, E)

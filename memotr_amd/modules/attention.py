@@ -65,6 +65,14 @@ def self_attention(mha: nn.MultiheadAttention, qk: torch.Tensor, v: torch.Tensor
     if (torch.is_grad_enabled() and w.requires_grad and not torch.is_autocast_enabled() and qk.dtype == w.dtype
             and v.dtype == w.dtype):
         qk_p, v_p = _PackedInProj.apply(qk, v, w, b)
+        from ..functions import clip_ops
+        if clip_ops.self_attention_supported(qk_p, H) and not (mha.training and mha.dropout > 0):
+            # hand-written kernels (head_dim 32, K / V of a head in LDS) on the packed projections, heads come out
+            # concatenated: no unbind / transposes / copy, and no AOTriton kernels on the path
+            no_pad = key_padding_mask is None or getattr(key_padding_mask, "_no_padding", False)
+            out = clip_ops.self_attention(qk_p, v_p, None if no_pad else key_padding_mask, H)
+            from .linear import row_linear
+            return row_linear(out, mha.out_proj.weight, mha.out_proj.bias)
         q, k = (t.transpose(1, 2) for t in qk_p.view(B, L, 2, H, d).unbind(2))     # (B, H, L, d)
         vh = v_p.view(B, L, H, d).transpose(1, 2)
     else:

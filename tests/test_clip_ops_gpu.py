@@ -234,3 +234,60 @@ def test_row_linear_matches_f_linear():
             torch.testing.assert_close(a, b_, rtol=1e-5, atol=1e-4)
     with torch.no_grad():                                         # nothing to differentiate: plain F.linear
         assert row_linear(x, w, b).grad_fn is None
+
+
+@pytest.mark.parametrize("B,L,H,masked", [(1, 320, 8, 12), (2, 307, 8, 0), (1, 512, 8, 100), (1, 33, 4, 3), (1, 1, 8, 0),
+                                          (2, 64, 8, 63)])
+def test_self_attention_kernels_values_and_gradients(B, L, H, masked):
+    """The hand-written attention (packed projections in, concatenated heads out) against softmax(q k^T / sqrt d) v."""
+    from memotr_amd.functions import clip_ops
+    g = torch.Generator().manual_seed(B * 1000 + L)
+    E = H * 32
+    qk = (torch.randn(B, L, 2 * E, generator=g) * 1.5).cuda()
+    v = torch.randn(B, L, E, generator=g).cuda()
+    mask = None
+    if masked:
+        mask = torch.zeros(B, L, dtype=torch.bool)
+        mask[:, L - masked:] = True                      # padded track slots sit at the end
+        mask[-1, 0] = L > 1 and masked < L - 1           # and one in front
+        mask = mask.cuda()
+    up = torch.randn(B, L, E, generator=g).cuda()
+    assert clip_ops.self_attention_supported(qk, H)
+    res = {}
+    for name, fn in (("kernel", clip_ops.self_attention), ("torch", clip_ops.self_attention_reference)):
+        a, b_ = qk.clone().requires_grad_(True), v.clone().requires_grad_(True)
+        out = fn(a, b_, mask, H)
+        (out * up).sum().backward()
+        res[name] = (out.detach(), a.grad, b_.grad)
+    for x, y, what in zip(res["kernel"], res["torch"], ("out", "grad q|k", "grad v")):
+        torch.testing.assert_close(x, y, rtol=2e-4, atol=2e-5, msg=lambda m, what=what: f"{what}: {m}")
+    if mask is not None:                                 # masked keys receive no gradient
+        gk = res["kernel"][1][..., E:]
+        assert float(gk[mask].abs().max()) == 0.0 and float(res["kernel"][2][mask].abs().max()) == 0.0
+    assert not clip_ops.self_attention_supported(torch.zeros(1, 600, 2 * E).cuda(), H)      # L > 512: the library path
+    assert not clip_ops.self_attention_supported(torch.zeros(1, 64, 2 * 64).cuda(), 8)      # head_dim 8
+
+
+def test_decoder_self_attention_module_path_matches_nn_multiheadattention():
+    """modules.attention.self_attention (packed in-projection node + attention kernels + row linear) against the
+    module the reference calls, outputs and parameter gradients."""
+    import torch.nn as nn
+    from memotr_amd.modules.attention import self_attention
+    torch.manual_seed(0)
+    mha = nn.MultiheadAttention(256, 8, dropout=0.0, batch_first=True).cuda()
+    tgt, pos = torch.randn(1, 320, 256).cuda(), torch.randn(1, 320, 256).cuda()
+    mask = torch.zeros(1, 320, dtype=torch.bool).cuda()
+    mask[0, 310:] = True
+    up = torch.randn(1, 320, 256).cuda()
+    res = {}
+    for name in ("ours", "torch"):
+        mha.zero_grad()
+        x = tgt.clone().requires_grad_(True)
+        if name == "ours":
+            out = self_attention(mha, x + pos, x, key_padding_mask=mask)
+        else:
+            out = mha(x + pos, x + pos, x, key_padding_mask=mask, need_weights=False)[0]
+        (out * up)[:, :310].sum().backward()
+        res[name] = [out.detach()[:, :310], x.grad] + [p.grad.clone() for p in mha.parameters()]
+    for a, b_ in zip(res["ours"], res["torch"]):
+        torch.testing.assert_close(a, b_, rtol=2e-4, atol=2e-4)
