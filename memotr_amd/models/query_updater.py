@@ -12,6 +12,7 @@ import torch.nn as nn
 
 from ..structures.track_instances import TrackInstances
 from ..utils.box_ops import box_cxcywh_to_xyxy, box_iou_union
+from ..modules.attention import memory_attention
 from ..utils.utils import inverse_sigmoid
 from .ffn import FFN
 from .mlp import MLP
@@ -81,7 +82,7 @@ class QueryUpdater(nn.Module):
 
             q = (short_memory + query_pos)[None]
             k = (long_memory + query_pos)[None]
-            attn = self.memory_attn(q, k, out_embed[None], need_weights=False)[0][0]
+            attn = memory_attention(self.memory_attn, q, k, out_embed[None])[0]
             tgt = self.memory_ffn(self.memory_norm(out_embed + self.memory_dropout(attn)))
             query_feat = self.query_feat_ffn(self.query_feat_norm(long_memory + self.query_feat_dropout(tgt)))
 

@@ -87,3 +87,25 @@ def self_attention(mha: nn.MultiheadAttention, qk: torch.Tensor, v: torch.Tensor
     out = out.transpose(1, 2).reshape(B, L, E)
     from .linear import row_linear
     return row_linear(out, mha.out_proj.weight, mha.out_proj.bias)
+
+
+def memory_attention(mha: nn.MultiheadAttention, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+    """``mha(q, k, v, need_weights=False)[0]`` for batch-first (B, L, E) inputs of one length with three different
+    sources (the query updater: short memory + pos, long memory + pos, output embedding; reference
+    models/query_updater.py:123-125).  On CUDA fp32 with head_dim 32 the attention itself runs in the hand-written
+    kernels; anything else goes through the module."""
+    from ..functions import clip_ops
+    from .linear import row_linear
+    E, H = mha.embed_dim, mha.num_heads
+    ok = (mha.batch_first and mha._qkv_same_embed_dim and mha.in_proj_bias is not None and mha.bias_k is None
+          and not mha.add_zero_attn and not (mha.training and mha.dropout > 0) and not torch.is_autocast_enabled()
+          and q.dim() == 3 and q.shape == k.shape == v.shape and q.is_cuda and q.dtype == torch.float32
+          and E // H == clip_ops.MHA_HEAD_DIM and 0 < q.shape[1] <= clip_ops.MHA_MAX_L and clip_ops.fused(q, k, v))
+    if not ok:
+        return mha(q, k, v, need_weights=False)[0]
+    w, b = mha.in_proj_weight, mha.in_proj_bias
+    q_p = row_linear(q, w[:E], b[:E])
+    k_p = row_linear(k, w[E:2 * E], b[E:2 * E])
+    v_p = row_linear(v, w[2 * E:], b[2 * E:])
+    out = clip_ops.attention(q_p, k_p, v_p, H)
+    return row_linear(out, mha.out_proj.weight, mha.out_proj.bias)

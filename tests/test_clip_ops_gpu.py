@@ -291,3 +291,23 @@ def test_decoder_self_attention_module_path_matches_nn_multiheadattention():
         res[name] = [out.detach()[:, :310], x.grad] + [p.grad.clone() for p in mha.parameters()]
     for a, b_ in zip(res["ours"], res["torch"]):
         torch.testing.assert_close(a, b_, rtol=2e-4, atol=2e-4)
+
+
+def test_memory_attention_matches_nn_multiheadattention():
+    """The query updater's attention (three different inputs, a handful of tracks) through the kernels."""
+    import torch.nn as nn
+    from memotr_amd.modules.attention import memory_attention
+    torch.manual_seed(1)
+    mha = nn.MultiheadAttention(256, 8, batch_first=True).cuda()
+    for n in (1, 13, 40):
+        q, k, v = (torch.randn(1, n, 256).cuda() for _ in range(3))
+        up = torch.randn(1, n, 256).cuda()
+        res = {}
+        for name in ("ours", "torch"):
+            mha.zero_grad()
+            qi, ki, vi = (t.clone().requires_grad_(True) for t in (q, k, v))
+            out = memory_attention(mha, qi, ki, vi) if name == "ours" else mha(qi, ki, vi, need_weights=False)[0]
+            (out * up).sum().backward()
+            res[name] = [out.detach(), qi.grad, ki.grad, vi.grad] + [p.grad.clone() for p in mha.parameters()]
+        for a, b_ in zip(res["ours"], res["torch"]):
+            torch.testing.assert_close(a, b_, rtol=2e-4, atol=2e-4)
