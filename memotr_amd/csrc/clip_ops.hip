@@ -405,9 +405,13 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__rest
 // ----------------------------------------------------------------------------------------
 // multi-head self-attention over the decoder queries (head_dim 32, L <= 512): forward and backward
 // ----------------------------------------------------------------------------------------
-// One workgroup = 32 rows x 8 lanes (256 threads) of one (batch, head).  A lane of a row visits the rows of the
-// OTHER axis j = lane, lane + 8, ... : 32-float dot products against rows staged in LDS (pitch 36 floats: the eight
-// lanes of a row hit eight different bank groups, the eight rows of a wavefront read the same addresses = broadcast).
+// One workgroup = kRows rows x kLanes lanes (256 threads) of one (batch, head).  A lane of a row visits the rows of
+// the OTHER axis j = lane, lane + kLanes, ... : 32-float dot products against rows staged in LDS (pitch 36 floats: the
+// sixteen lanes of a row cover all 64 banks exactly once per ds_read_b128, the four rows of a wavefront read the same
+// addresses = broadcast).  16 lanes per row: a decoder call is only ~2,500 rows x 320 keys, so the per-lane chain
+// (20 keys) sets the kernel's latency, not throughput.
+constexpr int kLanes = 16;         // lanes per row
+constexpr int kRows = 256 / kLanes;  // rows per workgroup
 constexpr int kHd = 32;            // head dimension
 constexpr int kPitch = 36;         // LDS row pitch in floats
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
@@ -444,11 +448,15 @@ __device__ __forceinline__ void axpy32(float *acc, float w, const float *lds_row
     }
 }
 
-// sum over the 8 lanes of a row (lanes differ in bits 0..2 of the lane id)
+// sum / max over the kLanes lanes of a row (they differ in the low bits of the lane id)
 __device__ __forceinline__ float sum8l(float x) {
-    x += __shfl_xor(x, 1, 64);
-    x += __shfl_xor(x, 2, 64);
-    x += __shfl_xor(x, 4, 64);
+#pragma unroll
+    for (int o = 1; o < kLanes; o <<= 1) x += __shfl_xor(x, o, 64);
+    return x;
+}
+__device__ __forceinline__ float max8l(float x) {
+#pragma unroll
+    for (int o = 1; o < kLanes; o <<= 1) x = fmaxf(x, __shfl_xor(x, o, 64));
     return x;
 }
 
@@ -471,7 +479,7 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const float *__restrict__ 
     stage_rows(Ks, k + b * k_bs + h * kHd, k_rs, L);
     stage_rows(Vs, v + b * v_bs + h * kHd, v_rs, L);
     __syncthreads();
-    const int row = blockIdx.x * 32 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
+    const int row = blockIdx.x * kRows + threadIdx.x / kLanes, sub = threadIdx.x % kLanes;
     const bool row_ok = row < L;
     const int rowc = row_ok ? row : L - 1;
     float qr[kHd];
@@ -482,7 +490,7 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const float *__restrict__ 
     float m = -INFINITY, l = 0.f, acc[kHd];
 #pragma unroll
     for (int i = 0; i < kHd; ++i) acc[i] = 0.f;
-    for (int j = sub; j < L; j += 8) {
+    for (int j = sub; j < L; j += kLanes) {
         if (mk && mk[j]) continue;
         const float s = dot32(qr, Ks + j * kPitch);
         const float m_new = fmaxf(m, s);
@@ -493,11 +501,8 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const float *__restrict__ 
         axpy32(acc, p, Vs + j * kPitch);
         m = m_new;
     }
-    // merge the 8 lanes of the row
-    float M = m;
-    M = fmaxf(M, __shfl_xor(M, 1, 64));
-    M = fmaxf(M, __shfl_xor(M, 2, 64));
-    M = fmaxf(M, __shfl_xor(M, 4, 64));
+    // merge the lanes of the row
+    const float M = max8l(m);
     const float w = (m == -INFINITY) ? 0.f : expf(m - M);          // a lane may have seen no key at all
     const float Lsum = sum8l(l * w);
     const float inv = 1.f / Lsum;
@@ -510,7 +515,7 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const float *__restrict__ 
     if (row_ok && sub == 0) lse[((long)b * H + h) * L + row] = M + logf(Lsum);
 }
 
-// grad_q: same decomposition as the forward (a workgroup = 32 query rows; K and V of the head in LDS)
+// grad_q: same decomposition as the forward (a workgroup = kRows query rows; K and V of the head in LDS)
 __global__ __launch_bounds__(256) void mha_bwd_q_kernel(const float *__restrict__ q, const float *__restrict__ k,
                                                        const float *__restrict__ v, long q_bs, long q_rs, long k_bs,
                                                        long k_rs, long v_bs, long v_rs,
@@ -524,7 +529,7 @@ __global__ __launch_bounds__(256) void mha_bwd_q_kernel(const float *__restrict_
     stage_rows(Ks, k + b * k_bs + h * kHd, k_rs, L);
     stage_rows(Vs, v + b * v_bs + h * kHd, v_rs, L);
     __syncthreads();
-    const int row = blockIdx.x * 32 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
+    const int row = blockIdx.x * kRows + threadIdx.x / kLanes, sub = threadIdx.x % kLanes;
     const bool row_ok = row < L;
     const int rowc = row_ok ? row : L - 1;
     float qr[kHd], gr[kHd], acc[kHd];
@@ -542,7 +547,7 @@ __global__ __launch_bounds__(256) void mha_bwd_q_kernel(const float *__restrict_
     for (int i = 0; i < kHd; ++i) { qr[i] *= scale; acc[i] = 0.f; }
     const float ls = lse[((long)b * H + h) * L + rowc];
     const uint8_t *mk = key_mask ? key_mask + (long)b * L : nullptr;
-    for (int j = sub; j < L; j += 8) {
+    for (int j = sub; j < L; j += kLanes) {
         if (mk && mk[j]) continue;
         const float p = expf(dot32(qr, Ks + j * kPitch) - ls);
         const float ds = p * (dot32(gr, Vs + j * kPitch) - D);
@@ -556,7 +561,7 @@ __global__ __launch_bounds__(256) void mha_bwd_q_kernel(const float *__restrict_
     }
 }
 
-// grad_k, grad_v: a workgroup = 32 KEY rows; Q and dO of the head in LDS, lse and D = dO . O per query too
+// grad_k, grad_v: a workgroup = kRows KEY rows; Q and dO of the head in LDS, lse and D = dO . O per query too
 __global__ __launch_bounds__(256) void mha_bwd_kv_kernel(const float *__restrict__ q, const float *__restrict__ k,
                                                         const float *__restrict__ v, long q_bs, long q_rs, long k_bs,
                                                         long k_rs, long v_bs, long v_rs,
@@ -581,7 +586,7 @@ __global__ __launch_bounds__(256) void mha_bwd_kv_kernel(const float *__restrict
         s_D[i] = d;
     }
     __syncthreads();
-    const int row = blockIdx.x * 32 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
+    const int row = blockIdx.x * kRows + threadIdx.x / kLanes, sub = threadIdx.x % kLanes;
     const bool row_ok = row < L;
     const int rowc = row_ok ? row : L - 1;
     const bool dead = key_mask && key_mask[(long)b * L + rowc];     // a masked key receives no gradient
@@ -591,7 +596,7 @@ __global__ __launch_bounds__(256) void mha_bwd_kv_kernel(const float *__restrict
 #pragma unroll
     for (int i = 0; i < kHd; ++i) { kr[i] *= scale; ak[i] = 0.f; av[i] = 0.f; }
     if (!dead) {
-        for (int i = sub; i < L; i += 8) {
+        for (int i = sub; i < L; i += kLanes) {
             const float p = expf(dot32(kr, Qs + i * kPitch) - s_lse[i]);
             const float ds = p * (dot32(vr, Gs + i * kPitch) - s_D[i]);
             axpy32(av, p, Gs + i * kPitch);
@@ -800,7 +805,7 @@ int clipops_mha_fwd_f32(const float *q, const float *k, const float *v, long q_b
     if (!out || !lse) return fail(1, "clipops_mha_fwd_f32: null pointer");
     const size_t lds = (size_t)2 * L * kPitch * sizeof(float);
     if ((rc = allow_lds(reinterpret_cast<const void *>(mha_fwd_kernel), lds, g_lds_fwd))) return rc;
-    hipLaunchKernelGGL(mha_fwd_kernel, dim3((L + 31) / 32, H, B), dim3(256), lds, (hipStream_t)stream, q, k, v, q_bs,
+    hipLaunchKernelGGL(mha_fwd_kernel, dim3((L + kRows - 1) / kRows, H, B), dim3(256), lds, (hipStream_t)stream, q, k, v, q_bs,
                        q_rs, k_bs, k_rs, v_bs, v_rs, key_mask, H, L, scale, out, lse);
     return check_launch("mha_fwd_kernel");
 }
@@ -817,7 +822,7 @@ int clipops_mha_bwd_f32(const float *q, const float *k, const float *v, long q_b
     const size_t lds_kv = lds_q + (size_t)2 * L * sizeof(float);
     if ((rc = allow_lds(reinterpret_cast<const void *>(mha_bwd_q_kernel), lds_q, g_lds_bq))) return rc;
     if ((rc = allow_lds(reinterpret_cast<const void *>(mha_bwd_kv_kernel), lds_kv, g_lds_bkv))) return rc;
-    const dim3 grid((L + 31) / 32, H, B);
+    const dim3 grid((L + kRows - 1) / kRows, H, B);
     hipLaunchKernelGGL(mha_bwd_q_kernel, grid, dim3(256), lds_q, (hipStream_t)stream, q, k, v, q_bs, q_rs, k_bs, k_rs,
                        v_bs, v_rs, key_mask, out, lse, grad_out, H, L, scale, grad_q, gq_bs, gq_rs);
     if ((rc = check_launch("mha_bwd_q_kernel"))) return rc;

@@ -20,7 +20,8 @@ def fused(*tensors) -> bool:
 
 def config_key() -> tuple:
     """The environment switches that change which kernels a captured graph contains."""
-    return (os.environ.get("MEMOTR_FUSED_CLIP_OPS", "1"), os.environ.get("MEMOTR_COLSUM_TALL", "1"))
+    return (os.environ.get("MEMOTR_FUSED_CLIP_OPS", "1"), os.environ.get("MEMOTR_COLSUM_TALL", "1"),
+            os.environ.get("MEMOTR_ATTN_KERNELS", "1"))
 
 
 def _lib():
@@ -377,13 +378,14 @@ def attention(q_p: torch.Tensor, k_p: torch.Tensor, v_p: torch.Tensor, n_heads: 
 
 
 def attention_supported(q_p: torch.Tensor, k_p: torch.Tensor, n_heads: int) -> bool:
-    return (q_p.dim() == 3 and q_p.shape == k_p.shape and fused(q_p, k_p) and q_p.dtype == torch.float32
+    return (os.environ.get("MEMOTR_ATTN_KERNELS", "1") != "0" and q_p.dim() == 3 and q_p.shape == k_p.shape
+            and fused(q_p, k_p) and q_p.dtype == torch.float32
             and q_p.shape[2] % n_heads == 0 and q_p.shape[2] // n_heads == MHA_HEAD_DIM and 0 < q_p.shape[1] <= MHA_MAX_L)
 
 
 def self_attention_supported(qk_p: torch.Tensor, n_heads: int) -> bool:
     B, L, E2 = qk_p.shape
-    return (fused(qk_p) and qk_p.dtype == torch.float32 and E2 % (2 * n_heads) == 0
+    return (os.environ.get("MEMOTR_ATTN_KERNELS", "1") != "0" and fused(qk_p) and qk_p.dtype == torch.float32 and E2 % (2 * n_heads) == 0
             and E2 // 2 // n_heads == MHA_HEAD_DIM and 0 < L <= MHA_MAX_L)
 
 

@@ -100,7 +100,7 @@ def memory_attention(mha: nn.MultiheadAttention, q: torch.Tensor, k: torch.Tenso
     ok = (mha.batch_first and mha._qkv_same_embed_dim and mha.in_proj_bias is not None and mha.bias_k is None
           and not mha.add_zero_attn and not (mha.training and mha.dropout > 0) and not torch.is_autocast_enabled()
           and q.dim() == 3 and q.shape == k.shape == v.shape and q.is_cuda and q.dtype == torch.float32
-          and E // H == clip_ops.MHA_HEAD_DIM and 0 < q.shape[1] <= clip_ops.MHA_MAX_L and clip_ops.fused(q, k, v))
+          and clip_ops.attention_supported(q, k, H) and clip_ops.fused(v))
     if not ok:
         return mha(q, k, v, need_weights=False)[0]
     w, b = mha.in_proj_weight, mha.in_proj_bias

@@ -46,3 +46,15 @@ for name, fn in (("hand-written kernels", clip_ops.self_attention), ("scaled_dot
             qk.grad = v.grad = None
             (fn(qk, v, m, H) * up).sum().backward()
         print(f"{name:30s} mask={'yes' if m is not None else 'no ':3s}  forward {f:7.1f} us   forward+backward (incl. autograd) {timed(fb, 100):7.1f} us")
+
+# device time per kernel (torch.profiler), one forward + backward of each path
+from torch.profiler import ProfilerActivity, profile  # noqa: E402
+for name, fn in (("hand-written kernels", clip_ops.self_attention), ("scaled_dot_product_attention", sdpa)):
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        for _ in range(10):
+            qk.grad = v.grad = None
+            (fn(qk, v, mask, H) * up).sum().backward()
+        torch.cuda.synchronize()
+    print(name)
+    for e in sorted(prof.key_averages(), key=lambda e: -e.device_time_total)[:8]:
+        print(f"   {e.device_time_total / max(e.count, 1):7.1f} us x{e.count // 10:2d}  {e.key[:90]}")
