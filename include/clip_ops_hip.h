@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define CLIPOPS_ABI_VERSION 5
+#define CLIPOPS_ABI_VERSION 6
 
 int clipops_abi_version(void);
 const char *clipops_last_error(void);
@@ -109,6 +109,20 @@ int clipops_mha_bwd_f32(const float *q, const float *k, const float *v, long q_b
                         long v_bs, long v_rs, const uint8_t *key_mask, const float *out, const float *lse,
                         const float *grad_out, int B, int H, int L, float scale, float *grad_q, long gq_bs, long gq_rs,
                         float *grad_k, long gk_bs, long gk_rs, float *grad_v, long gv_bs, long gv_rs, void *stream);
+
+/* Residual add + LayerNorm over rows of 256 floats (the post-norm blocks of the encoder / decoder layers, reference
+ * models/deformable_encoder.py:104-106, :126-127, models/deformable_decoder.py:251-252, :271-272, :311-312):
+ *   sum = x + res;  y = (sum - mean) * rstd * gamma + beta   (mean / biased variance over the 256 columns, eps inside
+ *   the sqrt).  One wavefront per row, 4 floats per lane.  `sum` (rows,256) and `stats` (rows,2) = (mean, rstd) are
+ *   kept for the backward.  Replaces an element-wise add + native_layer_norm (2 kernels) forward. */
+#define CLIPOPS_LN_COLS 256
+int clipops_add_layer_norm_fwd_f32(const float *x, const float *res, const float *gamma, const float *beta, long rows,
+                                   float eps, float *sum, float *y, float *stats, void *stream);
+/* Backward: grad_sum (rows,256) = d/d(x) = d/d(res);  partial (ceil(rows/chunk_rows), 512) receives per-chunk column
+ * sums of [grad_y * xhat | grad_y]; clipops_colsum_f32 over it yields [grad_gamma | grad_beta].  Replaces
+ * layer_norm_grad_input + two gamma/beta kernels + the add's fan-out. */
+int clipops_add_layer_norm_bwd_f32(const float *grad_y, const float *sum, const float *stats, const float *gamma,
+                                   long rows, int chunk_rows, float *grad_sum, float *partial, void *stream);
 
 #ifdef __cplusplus
 }

@@ -639,6 +639,77 @@ int mha_check(const void *q, const void *k, const void *v, int B, int H, int L) 
     return 0;
 }
 
+// ----------------------------------------------------------------------------------------
+// residual add + LayerNorm over rows of 256 floats: one wavefront per row, 4 floats per lane
+// ----------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum64(float x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    return x;
+}
+
+__global__ __launch_bounds__(256) void add_layer_norm_fwd_kernel(const float *__restrict__ x,
+                                                                const float *__restrict__ res,
+                                                                const float *__restrict__ gamma,
+                                                                const float *__restrict__ beta, long rows, float eps,
+                                                                float *__restrict__ sum, float *__restrict__ y,
+                                                                float *__restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const long off = row * CLIPOPS_LN_COLS + lane * 4;
+    const f32x4_t a = *reinterpret_cast<const f32x4_t *>(x + off);
+    const f32x4_t b = *reinterpret_cast<const f32x4_t *>(res + off);
+    const f32x4_t s = a + b;
+    *reinterpret_cast<f32x4_t *>(sum + off) = s;
+    const float mean = wave_sum64((s.x + s.y) + (s.z + s.w)) * (1.f / CLIPOPS_LN_COLS);
+    const f32x4_t d = s - mean;
+    const float var = wave_sum64((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w)) * (1.f / CLIPOPS_LN_COLS);
+    const float rstd = rsqrtf(var + eps);
+    const f32x4_t g = *reinterpret_cast<const f32x4_t *>(gamma + lane * 4);
+    const f32x4_t be = *reinterpret_cast<const f32x4_t *>(beta + lane * 4);
+    *reinterpret_cast<f32x4_t *>(y + off) = (d * rstd) * g + be;
+    if (lane == 0) {
+        stats[2 * row] = mean;
+        stats[2 * row + 1] = rstd;
+    }
+}
+
+// a workgroup walks chunk_rows rows (4 at a time, one per wavefront) and keeps the column sums of its rows
+__global__ __launch_bounds__(256) void add_layer_norm_bwd_kernel(const float *__restrict__ gy,
+                                                                const float *__restrict__ sum,
+                                                                const float *__restrict__ stats,
+                                                                const float *__restrict__ gamma, long rows,
+                                                                int chunk_rows, float *__restrict__ gsum,
+                                                                float *__restrict__ partial) {
+    __shared__ f32x4_t s_acc[4][2][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const f32x4_t gm = *reinterpret_cast<const f32x4_t *>(gamma + lane * 4);
+    f32x4_t acc_g = {0.f, 0.f, 0.f, 0.f}, acc_b = {0.f, 0.f, 0.f, 0.f};
+    const long r0 = (long)blockIdx.x * chunk_rows;
+    const long r1 = r0 + chunk_rows < rows ? r0 + chunk_rows : rows;
+    for (long row = r0 + wave; row < r1; row += 4) {
+        const long off = row * CLIPOPS_LN_COLS + lane * 4;
+        const f32x4_t g = *reinterpret_cast<const f32x4_t *>(gy + off);
+        const f32x4_t s = *reinterpret_cast<const f32x4_t *>(sum + off);
+        const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+        const f32x4_t xh = (s - mean) * rstd;
+        const f32x4_t gh = g * gm;
+        const float c1 = wave_sum64((gh.x + gh.y) + (gh.z + gh.w)) * (1.f / CLIPOPS_LN_COLS);
+        const float c2 = wave_sum64((gh.x * xh.x + gh.y * xh.y) + (gh.z * xh.z + gh.w * xh.w)) * (1.f / CLIPOPS_LN_COLS);
+        *reinterpret_cast<f32x4_t *>(gsum + off) = (gh - c1 - xh * c2) * rstd;
+        acc_g += g * xh;
+        acc_b += g;
+    }
+    s_acc[wave][0][lane] = acc_g;
+    s_acc[wave][1][lane] = acc_b;
+    __syncthreads();
+    if (wave < 2) {                       // wave 0: gamma part, wave 1: beta part
+        const f32x4_t t = (s_acc[0][wave][lane] + s_acc[1][wave][lane]) + (s_acc[2][wave][lane] + s_acc[3][wave][lane]);
+        *reinterpret_cast<f32x4_t *>(partial + (long)blockIdx.x * 2 * CLIPOPS_LN_COLS + wave * CLIPOPS_LN_COLS + lane * 4) = t;
+    }
+}
+
 int grid_for(long total) {
     long g = (total + 255) / 256;
     if (g < 1) g = 1;
@@ -829,6 +900,27 @@ int clipops_mha_bwd_f32(const float *q, const float *k, const float *v, long q_b
     hipLaunchKernelGGL(mha_bwd_kv_kernel, grid, dim3(256), lds_kv, (hipStream_t)stream, q, k, v, q_bs, q_rs, k_bs, k_rs,
                        v_bs, v_rs, key_mask, out, lse, grad_out, H, L, scale, grad_k, gk_bs, gk_rs, grad_v, gv_bs, gv_rs);
     return check_launch("mha_bwd_kv_kernel");
+}
+
+int clipops_add_layer_norm_fwd_f32(const float *x, const float *res, const float *gamma, const float *beta, long rows,
+                                   float eps, float *sum, float *y, float *stats, void *stream) {
+    if (rows < 0) return fail(1, "clipops_add_layer_norm_fwd_f32: negative row count");
+    if (rows == 0) { g_err[0] = 0; return 0; }
+    if (!x || !res || !gamma || !beta || !sum || !y || !stats) return fail(1, "clipops_add_layer_norm_fwd_f32: null pointer");
+    hipLaunchKernelGGL(add_layer_norm_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x,
+                       res, gamma, beta, rows, eps, sum, y, stats);
+    return check_launch("add_layer_norm_fwd_kernel");
+}
+
+int clipops_add_layer_norm_bwd_f32(const float *grad_y, const float *sum, const float *stats, const float *gamma,
+                                   long rows, int chunk_rows, float *grad_sum, float *partial, void *stream) {
+    if (rows < 0 || chunk_rows <= 0) return fail(1, "clipops_add_layer_norm_bwd_f32: bad dimension");
+    if (rows == 0) { g_err[0] = 0; return 0; }
+    if (!grad_y || !sum || !stats || !gamma || !grad_sum || !partial)
+        return fail(1, "clipops_add_layer_norm_bwd_f32: null pointer");
+    hipLaunchKernelGGL(add_layer_norm_bwd_kernel, dim3((unsigned)((rows + chunk_rows - 1) / chunk_rows)), dim3(256), 0,
+                       (hipStream_t)stream, grad_y, sum, stats, gamma, rows, chunk_rows, grad_sum, partial);
+    return check_launch("add_layer_norm_bwd_kernel");
 }
 
 }  // extern "C"

@@ -21,7 +21,7 @@ def fused(*tensors) -> bool:
 def config_key() -> tuple:
     """The environment switches that change which kernels a captured graph contains."""
     return (os.environ.get("MEMOTR_FUSED_CLIP_OPS", "1"), os.environ.get("MEMOTR_COLSUM_TALL", "1"),
-            os.environ.get("MEMOTR_ATTN_KERNELS", "1"))
+            os.environ.get("MEMOTR_ATTN_KERNELS", "1"), os.environ.get("MEMOTR_FUSED_LN", "1"))
 
 
 def _lib():
@@ -406,3 +406,54 @@ def self_attention_reference(qk_p, v_p, key_padding_mask, n_heads):
     if key_padding_mask is not None:
         att = att.masked_fill(key_padding_mask.view(B, 1, 1, L), float("-inf"))
     return (att.softmax(-1) @ v).transpose(1, 2).reshape(B, L, E)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# residual add + LayerNorm (rows of 256)
+# --------------------------------------------------------------------------------------------------------------
+LN_COLS = 256
+
+
+class _AddLayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, res, weight, bias, eps):
+        rows = x.numel() // LN_COLS
+        s = torch.empty_like(x)
+        y = torch.empty_like(x)
+        stats = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+        L = _lib()
+        L.check(L.lib.clipops_add_layer_norm_fwd_f32(x.data_ptr(), res.data_ptr(), weight.data_ptr(), bias.data_ptr(),
+                                                     rows, eps, s.data_ptr(), y.data_ptr(), stats.data_ptr(), _stream(x)),
+                "clipops_add_layer_norm_fwd_f32")
+        ctx.save_for_backward(s, stats, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        s, stats, weight = ctx.saved_tensors
+        rows = s.numel() // LN_COLS
+        g = g.contiguous()
+        gs = torch.empty_like(s)
+        chunk = 16 if rows <= 4096 else 64
+        partial = torch.empty((-(-rows // chunk), 2 * LN_COLS), dtype=torch.float32, device=s.device)
+        L = _lib()
+        L.check(L.lib.clipops_add_layer_norm_bwd_f32(g.data_ptr(), s.data_ptr(), stats.data_ptr(), weight.data_ptr(), rows,
+                                                     chunk, gs.data_ptr(), partial.data_ptr(), _stream(s)),
+                "clipops_add_layer_norm_bwd_f32")
+        gwb = colsum(partial)                       # [grad_gamma | grad_beta]
+        return gs, gs, gwb[:LN_COLS], gwb[LN_COLS:], None
+
+
+def add_layer_norm_supported(x: torch.Tensor, res: torch.Tensor, norm) -> bool:
+    return (isinstance(norm, torch.nn.LayerNorm) and norm.elementwise_affine and norm.bias is not None
+            and tuple(norm.normalized_shape) == (LN_COLS,) and x.shape == res.shape and x.shape[-1] == LN_COLS
+            and fused(x, res) and x.dtype == torch.float32 and norm.weight.dtype == torch.float32
+            and not torch.is_autocast_enabled() and os.environ.get("MEMOTR_FUSED_LN", "1") != "0")
+
+
+def add_layer_norm(x: torch.Tensor, res: torch.Tensor, norm) -> torch.Tensor:
+    """norm(x + res) for an nn.LayerNorm over 256 features: one kernel forward (sum, statistics and output in one
+    pass), one + a column sum backward; other shapes / dtypes / devices go through the module."""
+    if add_layer_norm_supported(x, res, norm):
+        return _AddLayerNorm.apply(x.contiguous(), res.contiguous(), norm.weight, norm.bias, float(norm.eps))
+    return norm(x + res)

@@ -7,6 +7,7 @@ import torch.nn as nn
 from torch.utils.checkpoint import checkpoint
 
 from ..modules import MSDeformAttn
+from ..functions.clip_ops import add_layer_norm
 from ..modules.attention import self_attention
 from ..modules.linear import row_linear
 from ..utils.utils import inverse_sigmoid, refine_boxes
@@ -166,7 +167,7 @@ class DeformableDecoderLayer(nn.Module):
     def forward_self_attn(self, tgt, query_pos, query_mask):
         qk = self.with_pos_embed(tgt, query_pos)
         attn = self_attention(self.self_attn, qk, tgt, key_padding_mask=query_mask)
-        return self.norm2(tgt + self.dropout2(attn))
+        return add_layer_norm(tgt, self.dropout2(attn), self.norm2)
 
     def forward_track_attn(self, tgt, query_pos, query_mask):
         nd = self.n_det_queries
@@ -184,7 +185,7 @@ class DeformableDecoderLayer(nn.Module):
         # autograd rebase the graph (CopySlices + AsStrided backward nodes, six extra kernels per layer and frame)
         hidden = torch.relu(hidden) if isinstance(self.activation, nn.ReLU) else self.activation(hidden)
         hidden = self.dropout3(hidden)
-        return self.norm3(tgt + self.dropout4(row_linear(hidden, self.linear2.weight, self.linear2.bias)))
+        return add_layer_norm(tgt, self.dropout4(row_linear(hidden, self.linear2.weight, self.linear2.bias)), self.norm3)
 
     def forward(self, tgt, query_pos, reference_points, src, src_spatial_shapes, level_start_index, query_mask,
                 src_padding_mask=None, merge_det_track=False):
@@ -200,7 +201,7 @@ class DeformableDecoderLayer(nn.Module):
         tgt = self.forward_self_attn(tgt, query_pos, query_mask)
         cross = self.cross_attn(self.with_pos_embed(tgt, query_pos), reference_points, src, src_spatial_shapes,
                                 level_start_index, src_padding_mask)
-        tgt = self.norm1(tgt + self.dropout1(cross))
+        tgt = add_layer_norm(tgt, self.dropout1(cross), self.norm1)
         tgt = self.forward_ffn(tgt)
         if track_tgt is not None:
             tgt = torch.cat((tgt, track_tgt), dim=1)

@@ -7,6 +7,7 @@ import torch.nn as nn
 from torch.utils.checkpoint import checkpoint
 
 from ..modules import MSDeformAttn
+from ..functions.clip_ops import add_layer_norm
 from ..modules.linear import long_linear
 from .utils import get_activation_layer, get_clones
 
@@ -76,10 +77,10 @@ class DeformableEncoderLayer(nn.Module):
 
     def forward_ffn(self, src):
         hidden = self.dropout2(long_linear(src, self.linear1.weight, self.linear1.bias, activation=self.activation))
-        return self.norm2(src + self.dropout3(long_linear(hidden, self.linear2.weight, self.linear2.bias)))
+        return add_layer_norm(src, self.dropout3(long_linear(hidden, self.linear2.weight, self.linear2.bias)), self.norm2)
 
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None):
         attn = self.self_attn(self.with_pos_embed(src, pos), reference_points, src, spatial_shapes,
                               level_start_index, padding_mask)
-        src = self.norm1(src + self.dropout1(attn))
+        src = add_layer_norm(src, self.dropout1(attn), self.norm1)
         return self.forward_ffn(src)

@@ -311,3 +311,32 @@ def test_memory_attention_matches_nn_multiheadattention():
             res[name] = [out.detach(), qi.grad, ki.grad, vi.grad] + [p.grad.clone() for p in mha.parameters()]
         for a, b_ in zip(res["ours"], res["torch"]):
             torch.testing.assert_close(a, b_, rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("shape", [(1, 320, 256), (3, 22323, 256), (7, 256), (1, 4097, 256)])
+def test_add_layer_norm_values_and_gradients(shape):
+    import torch.nn as nn
+    from memotr_amd.functions import clip_ops
+    g = torch.Generator().manual_seed(shape[-2])
+    norm = nn.LayerNorm(256).cuda()
+    with torch.no_grad():
+        norm.weight.copy_(torch.rand(256, generator=g) + 0.5)
+        norm.bias.copy_(torch.randn(256, generator=g) * 0.2)
+    x = (torch.randn(*shape, generator=g) * 2 + 0.3).cuda()
+    r = torch.randn(*shape, generator=g).cuda()
+    up = torch.randn(*shape, generator=g).cuda()
+    assert clip_ops.add_layer_norm_supported(x, r, norm)
+    res = {}
+    for name in ("kernel", "torch"):
+        norm.zero_grad()
+        a, b_ = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
+        y = clip_ops.add_layer_norm(a, b_, norm) if name == "kernel" else norm(a + b_)
+        (y * up).sum().backward()
+        res[name] = (y.detach(), a.grad.clone(), b_.grad.clone(), norm.weight.grad.clone(), norm.bias.grad.clone())
+    names = ("y", "grad x", "grad res", "grad gamma", "grad beta")
+    rows = x.numel() // 256
+    for a, b_, what in zip(res["kernel"], res["torch"], names):
+        tol = dict(rtol=1e-4, atol=1e-4 * max(1.0, rows ** 0.5 / 16)) if "gamma" in what or "beta" in what else \
+            dict(rtol=1e-5, atol=2e-5)
+        torch.testing.assert_close(a, b_, msg=lambda m, what=what: f"{what}: {m}", **tol)
+    assert not clip_ops.add_layer_norm_supported(x[..., :128], r[..., :128], nn.LayerNorm(128).cuda())
