@@ -1,6 +1,8 @@
 """Post-norm feed-forward block: x -> LN(x + W2 relu(W1 x)) (reference models/ffn.py)."""
 import torch.nn as nn
 
+from ..functions.clip_ops import add_layer_norm
+
 
 class FFN(nn.Module):
     def __init__(self, d_model, d_ffn, dropout: float):
@@ -14,4 +16,4 @@ class FFN(nn.Module):
 
     def forward(self, tgt):
         hidden = self.dropout1(self.activation(self.linear1(tgt)))
-        return self.norm(tgt + self.dropout2(self.linear2(hidden)))
+        return add_layer_norm(tgt, self.dropout2(self.linear2(hidden)), self.norm)

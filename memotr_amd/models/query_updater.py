@@ -12,6 +12,7 @@ import torch.nn as nn
 
 from ..structures.track_instances import TrackInstances
 from ..utils.box_ops import box_cxcywh_to_xyxy, box_iou_union
+from ..functions.clip_ops import add_layer_norm
 from ..modules.attention import memory_attention
 from ..utils.utils import inverse_sigmoid
 from .ffn import FFN
@@ -83,8 +84,9 @@ class QueryUpdater(nn.Module):
             q = (short_memory + query_pos)[None]
             k = (long_memory + query_pos)[None]
             attn = memory_attention(self.memory_attn, q, k, out_embed[None])[0]
-            tgt = self.memory_ffn(self.memory_norm(out_embed + self.memory_dropout(attn)))
-            query_feat = self.query_feat_ffn(self.query_feat_norm(long_memory + self.query_feat_dropout(tgt)))
+            tgt = self.memory_ffn(add_layer_norm(out_embed, self.memory_dropout(attn), self.memory_norm))
+            query_feat = self.query_feat_ffn(add_layer_norm(long_memory, self.query_feat_dropout(tgt),
+                                                            self.query_feat_norm))
 
             new_long = (1 - lam) * long_memory + lam * out_embed
             t.long_memory = t.long_memory * ~pos_col + new_long * pos_col
