@@ -36,6 +36,11 @@ class DeformableDecoder(nn.Module):
             self.query_scale = MLP(d_model, d_model, d_model, 2)
             self.ref_point_head = MLP(d_model * 2, d_model, d_model, 2)
 
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state.pop("_decoder_graphs", None)        # captured hipGraphs are per-process objects: never pickled / deep-copied
+        return state
+
     def graphs(self) -> DecoderGraphs:
         g = self.__dict__.get("_decoder_graphs")
         if g is None:

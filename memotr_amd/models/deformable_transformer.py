@@ -63,6 +63,12 @@ class DeformableTransformer(nn.Module):
             constant_(self.reference_points.bias.data, 0.0)
         normal_(self.level_embed)
 
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        for k in ("_pyramids", "_mask_derived"):   # per-geometry device tensors, rebuilt on demand
+            state.pop(k, None)
+        return state
+
     @staticmethod
     def get_valid_ratio(mask):
         """(B, 2) = (valid_w / W, valid_h / H) from the first row / column of the padding mask."""

@@ -211,3 +211,28 @@ def test_position_embedding_cache_by_image_geometry():
     assert len(pe._cache) == 2
     import copy
     assert "_cache" not in copy.deepcopy(pe).__dict__
+
+
+def test_model_with_runtime_caches_can_be_deep_copied_and_pickled():
+    """Per-process / per-geometry caches (decoder graphs, pyramid tensors, mask-derived tensors, position embeddings)
+    stay out of copies and pickles; parameters do not."""
+    import copy
+    import io
+
+    import torch
+    from memotr_amd.configs import dancetrack_config
+    from memotr_amd.models.deformable_transformer import build as build_tr
+    cfg = dancetrack_config(DEVICE="cpu", HIDDEN_DIM=64, FFN_DIM=128, NUM_ENC_LAYERS=1, NUM_DEC_LAYERS=2)
+    tr = build_tr(cfg)
+    tr.decoder.graphs()                                   # creates the (empty) graph cache object
+    tr.__dict__["_mask_derived"] = {("k",): (torch.zeros(1),)}
+    tr._pyramid_tensors([(4, 6), (2, 3)], torch.device("cpu"))
+    twin = copy.deepcopy(tr)
+    assert "_decoder_graphs" not in twin.decoder.__dict__ and "_mask_derived" not in twin.__dict__
+    assert "_pyramids" not in twin.__dict__
+    buf = io.BytesIO()
+    torch.save(tr, buf)
+    buf.seek(0)
+    back = torch.load(buf, weights_only=False)
+    assert sorted(back.state_dict()) == sorted(tr.state_dict())
+    assert "_decoder_graphs" in tr.decoder.__dict__        # the original keeps its caches
