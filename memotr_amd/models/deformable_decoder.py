@@ -185,10 +185,13 @@ class DeformableDecoderLayer(nn.Module):
         return torch.cat([tgt[:, :nd], self.norm4(tgt[:, nd:] + self.dropout5(attn))], dim=1)
 
     def forward_ffn(self, tgt):
-        hidden = row_linear(tgt, self.linear1.weight, self.linear1.bias)
-        # out of place: nn.Linear on a (B, L, E) input returns a VIEW of its product, and an in-place op on a view makes
-        # autograd rebase the graph (CopySlices + AsStrided backward nodes, six extra kernels per layer and frame)
-        hidden = torch.relu(hidden) if isinstance(self.activation, nn.ReLU) else self.activation(hidden)
+        # ReLU in the GEMM epilogue, never in place: nn.Linear on a (B, L, E) input returns a VIEW of its product, and an
+        # in-place op on a view makes autograd rebase the graph (CopySlices + AsStrided backward nodes, six extra kernels
+        # per layer and frame)
+        if isinstance(self.activation, nn.ReLU):
+            hidden = row_linear(tgt, self.linear1.weight, self.linear1.bias, relu=True)
+        else:
+            hidden = self.activation(row_linear(tgt, self.linear1.weight, self.linear1.bias))
         hidden = self.dropout3(hidden)
         return add_layer_norm(tgt, self.dropout4(row_linear(hidden, self.linear2.weight, self.linear2.bias)), self.norm3)
 

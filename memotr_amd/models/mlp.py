@@ -1,7 +1,5 @@
 """ReLU MLP with parameters under ``layers.{i}`` (state-dict layout of the reference's models/mlp.py)."""
 import torch.nn as nn
-import torch.nn.functional as F
-
 from ..modules.linear import row_linear
 
 
@@ -15,7 +13,5 @@ class MLP(nn.Module):
     def forward(self, x):
         last = self.num_layers - 1
         for i, layer in enumerate(self.layers):
-            x = row_linear(x, layer.weight, layer.bias)
-            if i < last:
-                x = F.relu(x)
+            x = row_linear(x, layer.weight, layer.bias, relu=i < last)
         return x

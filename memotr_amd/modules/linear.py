@@ -119,39 +119,52 @@ class _SplitKLinear(torch.autograd.Function):
 
 
 class _RowLinear(torch.autograd.Function):
-    """F.linear over a few hundred rows (the decoder's query-sized linears) as one autograd node whose bias gradient
-    goes through the tiled column-sum kernel: torch's generic reduction takes 12-17 us for 310 x 256..2048, ~400
-    times per train step (tools/reduce_prof.py)."""
+    """F.linear (optionally + ReLU in the GEMM epilogue) over a few hundred rows -- the decoder's query-sized linears --
+    as one autograd node whose bias gradient goes through the tiled column-sum kernel: torch's generic reduction takes
+    12-17 us for 310 x 256..2048, ~400 times per train step (tools/reduce_prof.py)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, relu):
         x2 = x.reshape(-1, x.shape[-1])
-        y = torch.addmm(bias, x2, weight.t())
-        ctx.save_for_backward(x2, weight)
+        ctx.relu = bool(relu)
+        if ctx.relu:
+            y = torch._addmm_activation(bias, x2, weight.t(), use_gelu=False)      # relu(x W^T + b), one kernel
+            ctx.save_for_backward(x2, weight, y)
+        else:
+            y = torch.addmm(bias, x2, weight.t())
+            ctx.save_for_backward(x2, weight)
         ctx.x_shape = x.shape
         return y if x.dim() == 2 else y.view(*x.shape[:-1], weight.shape[0])
 
     @staticmethod
     def backward(ctx, grad_out):
         from ..functions import clip_ops
-        x2, weight = ctx.saved_tensors
-        g2 = grad_out.reshape(-1, weight.shape[0])
+        g2 = grad_out.reshape(-1, grad_out.shape[-1])
+        if ctx.relu:
+            x2, weight, y = ctx.saved_tensors
+            g2 = torch.ops.aten.threshold_backward(g2, y, 0.0)                     # the ReLU mask
+        else:
+            x2, weight = ctx.saved_tensors
         gx = (g2 @ weight).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
         gw = g2.t() @ x2 if ctx.needs_input_grad[1] else None
         gb = clip_ops.colsum(g2.contiguous()) if ctx.needs_input_grad[2] else None
-        return gx, gw, gb
+        return gx, gw, gb, None
 
 
-def row_linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor = None) -> torch.Tensor:
-    """F.linear; on CUDA fp32 tensors with up to COLSUM_MAX_ROWS rows and a gradient to compute it runs as
-    ``_RowLinear`` (same products, bias gradient through the column-sum kernel)."""
+def row_linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor = None, relu: bool = False) -> torch.Tensor:
+    """F.linear (``relu=True``: followed by ReLU); on CUDA fp32 tensors with up to COLSUM_MAX_ROWS rows and a gradient
+    to compute it runs as ``_RowLinear`` (same products, ReLU in the GEMM epilogue, bias gradient through the
+    column-sum kernel)."""
     from ..functions import clip_ops
     if (bias is not None and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32
             and torch.is_grad_enabled() and (weight.requires_grad or x.requires_grad)
             and not torch.is_autocast_enabled() and x.numel() // max(x.shape[-1], 1) <= clip_ops.COLSUM_MAX_ROWS
             and clip_ops.fused(x)):
-        return _RowLinear.apply(x, weight, bias)
-    return F.linear(x, weight, bias)
+        if relu and not FUSE_RELU_EPILOGUE:
+            return torch.relu(_RowLinear.apply(x, weight, bias, False))
+        return _RowLinear.apply(x, weight, bias, relu)
+    y = F.linear(x, weight, bias)
+    return torch.relu(y) if relu else y
 
 
 def long_linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor = None, min_rows: int = None,
@@ -171,9 +184,8 @@ def long_linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor = None
         if activation is not None and not fuse:
             y = activation(y)
         return y.view(*x.shape[:-1], weight.shape[0])
+    if isinstance(activation, torch.nn.ReLU):       # (never in place: an N-d linear returns a view of its product)
+        return row_linear(x, weight, bias, relu=True)
     y = row_linear(x, weight, bias)
-    if activation is None:
-        return y
-    # (out of place for ReLU: an in-place op on the view an N-d linear returns makes autograd rebase the graph)
-    return torch.relu(y) if isinstance(activation, torch.nn.ReLU) else activation(y)
+    return y if activation is None else activation(y)
 
