@@ -225,13 +225,15 @@ def test_row_linear_matches_f_linear():
         w, b = torch.randn(512, 256, generator=g).cuda(), torch.randn(512, generator=g).cuda()
         up = torch.randn(*shape[:-1], 512, generator=g).cuda()
         res = {}
-        for name, fn in (("row", row_linear), ("torch", F.linear)):
-            xi, wi, bi = (t.clone().requires_grad_(True) for t in (x, w, b))
-            y = fn(xi, wi, bi)
-            (y * up).sum().backward()
-            res[name] = (y.detach(), xi.grad, wi.grad, bi.grad)
-        for a, b_ in zip(res["row"], res["torch"]):
-            torch.testing.assert_close(a, b_, rtol=1e-5, atol=1e-4)
+        for relu in (False, True):
+            for name, fn in (("row", lambda *a: row_linear(*a, relu=relu)),
+                             ("torch", lambda *a: F.relu(F.linear(*a)) if relu else F.linear(*a))):
+                xi, wi, bi = (t.clone().requires_grad_(True) for t in (x, w, b))
+                y = fn(xi, wi, bi)
+                (y * up).sum().backward()
+                res[name] = (y.detach(), xi.grad, wi.grad, bi.grad)
+            for a, b_ in zip(res["row"], res["torch"]):
+                torch.testing.assert_close(a, b_, rtol=1e-5, atol=1e-4)
     with torch.no_grad():                                         # nothing to differentiate: plain F.linear
         assert row_linear(x, w, b).grad_fn is None
 
