@@ -154,18 +154,28 @@ class FusedCall(MsdaCall):
             raise RuntimeError(self._lib.last_error())
 
 
-def time_kernel(fn, iters=200, warmup=20):
-    """Average launch duration (ms) from HIP events on the launch stream."""
-    for _ in range(warmup):
-        fn()
+def time_kernel(fn, iters=200, warmup=20, min_warm_ms=40.0, batches=5):
+    """Average launch duration (ms) from HIP events on the launch stream, steady state.
+
+    The GPU drops its clocks within a few milliseconds of idling and takes milliseconds of continuous work to bring
+    them back: twenty warm-up launches (~1 ms) after the gap between the train loop and this measurement left the
+    timed loop on the ramp (60-82 us measured for a 55 us kernel, box dependent).  So: warm up for at least
+    ``min_warm_ms`` of back-to-back launches, then time ``batches`` batches and report the median batch average."""
     torch.cuda.synchronize()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    for _ in range(iters):
+    t0, n = time.perf_counter(), 0
+    while n < warmup or (time.perf_counter() - t0) * 1e3 < min_warm_ms:
         fn()
-    e.record()
+        n += 1
+    per = max(1, iters // batches)
+    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(batches)]
+    for s, e in pairs:                       # back to back: no host synchronisation between the batches
+        s.record()
+        for _ in range(per):
+            fn()
+        e.record()
     torch.cuda.synchronize()
-    return s.elapsed_time(e) / iters
+    times = sorted(s.elapsed_time(e) / per for s, e in pairs)
+    return times[len(times) // 2]
 
 
 def read_traffic(kernel_label):
