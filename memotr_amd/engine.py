@@ -82,12 +82,14 @@ def encode_chunks(core, clip_len: int):
     ``None`` (frame by frame in the reference's order) or a list of group sizes summing to clip_len; ``lazy``
     = each group is encoded right before its first frame is decoded (else: as early as possible).
 
-    ``core.encode_chunks`` or the environment variable MEMOTR_ENCODE_CHUNKS override the default "auto":
-    "0" (off), "all", "5", "1,4", "lazy:3,2", ... .  Measured on MI355X (DanceTrack clip of 5, tools/ab_step.py,
-    same process): reference order 235 ms per step, "all" 232, "lazy:3,2" (= auto) 219.  Batching divides the
-    number of backbone / encoder launches (the forward is bound by the host's launch rate); two groups instead of
-    one keep GPU-bound encoder backward work (group 2) queued while the host is busy with the launch-bound decoder
-    backward of the earlier frames.  Gradient checkpointing keeps the reference's order."""
+    ``core.encode_chunks`` or the environment variable MEMOTR_ENCODE_CHUNKS override the default "all":
+    "0" (off), "all", "auto" (two just-in-time groups, ~60 % of the clip first), "5", "1,4", "lazy:3,2", ... .
+    Measured on MI355X (DanceTrack clip of 5, tools/ab_step.py, same process).  Round 1, host-bound step: reference
+    order 235 ms, "all" 232, "lazy:3,2" 219 -- two groups kept GPU-bound encoder backward work queued while the host
+    was busy with the launch-bound decoder backward of the earlier frames.  End of round 2, GPU-bound step (decoder
+    graphs, fused small-tensor kernels): "auto" 157.6, "2,3" 155.3, "4,1" 152.7, "all" **147.3 ms** -- the largest
+    kernels and the fewest launches win once the host is out of the way.  Gradient checkpointing keeps the
+    reference's order."""
     if getattr(core, "use_checkpoint", False):
         return None, False
     spec = getattr(core, "encode_chunks", None)
@@ -119,7 +121,7 @@ def encode_chunks(core, clip_len: int):
     return out, lazy
 
 
-DEFAULT_ENCODE_CHUNKS = "auto"
+DEFAULT_ENCODE_CHUNKS = "all"
 
 _ENCODE_STREAMS = {}
 

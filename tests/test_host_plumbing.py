@@ -11,7 +11,7 @@ class _Core:
 
 
 @pytest.mark.parametrize("spec,clip_len,want", [
-    (None, 5, ([3, 2], True)), ("auto", 5, ([3, 2], True)), ("auto", 4, ([3, 1], True)), ("auto", 2, ([2], True)),
+    (None, 5, ([5], False)), ("auto", 5, ([3, 2], True)), ("auto", 4, ([3, 1], True)), ("auto", 2, ([2], True)),
     ("auto", 1, ([1], True)), ("all", 5, ([5], False)), ("0", 5, (None, False)), ("1", 3, ([1, 1, 1], False)),
     ("lazy:2", 5, ([2, 2, 1], True)), ("1,4", 5, ([1, 4], False)), ([1, 1, 3], 5, ([1, 1, 3], False)),
     (8, 5, ([5], False)), ("2,9", 5, ([2, 3], False)),
