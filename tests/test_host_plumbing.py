@@ -236,3 +236,74 @@ def test_model_with_runtime_caches_can_be_deep_copied_and_pickled():
     back = torch.load(buf, weights_only=False)
     assert sorted(back.state_dict()) == sorted(tr.state_dict())
     assert "_decoder_graphs" in tr.decoder.__dict__        # the original keeps its caches
+
+
+def test_packed_in_projection_node_matches_sliced_linears():
+    """_PackedInProj (one autograd node over in_proj_weight / in_proj_bias) against the sliced F.linear formulation,
+    values and all four gradients, in float64 on the CPU."""
+    from memotr_amd.modules.attention import _PackedInProj
+    g = torch.Generator().manual_seed(0)
+    E = 16
+    qk = torch.randn(2, 5, E, generator=g, dtype=torch.float64)
+    v = torch.randn(2, 5, E, generator=g, dtype=torch.float64)
+    w = torch.randn(3 * E, E, generator=g, dtype=torch.float64)
+    b = torch.randn(3 * E, generator=g, dtype=torch.float64)
+    up = torch.randn(2, 5, 3 * E, generator=g, dtype=torch.float64)
+    res = {}
+    for name in ("node", "sliced"):
+        a, c, wi, bi = (t.clone().requires_grad_(True) for t in (qk, v, w, b))
+        if name == "node":
+            y_qk, y_v = _PackedInProj.apply(a, c, wi, bi)
+        else:
+            y_qk, y_v = F.linear(a, wi[:2 * E], bi[:2 * E]), F.linear(c, wi[2 * E:], bi[2 * E:])
+        (torch.cat((y_qk, y_v), -1) * up).sum().backward()
+        res[name] = (y_qk.detach(), y_v.detach(), a.grad, c.grad, wi.grad, bi.grad)
+    for x, y in zip(res["node"], res["sliced"]):
+        torch.testing.assert_close(x, y, rtol=1e-12, atol=1e-12)
+
+
+def test_track_instances_row_gather_and_padded_stack():
+    """A 1-d index tensor gathers through index_select (same rows as advanced indexing); the (B, max_len, width) stack
+    of per-clip track tensors is zero-padded without in-place writes and keeps the gradient path."""
+    from memotr_amd.structures.track_instances import TrackInstances
+    t = TrackInstances(hidden_dim=8, num_classes=1, use_dab=True)
+    n = 6
+    t.ids = torch.arange(n)
+    t.query_embed = torch.randn(n, 8, requires_grad=True)
+    t.ref_pts = torch.randn(n, 4)
+    t.boxes, t.logits = torch.rand(n, 4), torch.randn(n, 1)
+    t.output_embed, t.last_output, t.long_memory = torch.randn(n, 8), torch.randn(n, 8), torch.randn(n, 8)
+    t.matched_idx, t.labels, t.iou = torch.zeros(n, dtype=torch.long), torch.zeros(n, dtype=torch.long), torch.zeros(n)
+    idx = torch.tensor([4, 0, 4])
+    picked = t[idx]
+    assert picked.ids.tolist() == [4, 0, 4] and torch.equal(picked.query_embed, t.query_embed[idx])
+    picked.query_embed.sum().backward()
+    assert t.query_embed.grad[4].tolist() == [2.0] * 8 and t.query_embed.grad[1].tolist() == [0.0] * 8
+    kept = t[torch.tensor([True, False, True, False, False, True])]
+    assert kept.ids.tolist() == [0, 2, 5]
+
+    from memotr_amd.models.memotr import MeMOTR
+
+    class _Stub:
+        det_query_embed = torch.zeros(3, 8)
+    parts = [torch.ones(2, 4, requires_grad=True), torch.full((3, 4), 2.0), torch.zeros(0, 4)]
+    out = MeMOTR._pad_stack(_Stub(), parts, 4)
+    assert out.shape == (3, 3, 4) and out[0, 2].abs().sum() == 0 and out[2].abs().sum() == 0
+    assert torch.equal(out[1], parts[1]) and out.requires_grad
+    single = MeMOTR._pad_stack(_Stub(), [parts[0]], 4)
+    assert single.shape == (1, 2, 4) and single._base is parts[0]          # a view, no copy
+    assert MeMOTR._pad_stack(_Stub(), [torch.zeros(0, 4)], 4).shape == (1, 0, 4)
+
+
+def test_decoder_graphs_flat_parameters_are_shared_within_a_clip_only():
+    from memotr_amd.models.decoder_graphs import DecoderGraphs
+    g = DecoderGraphs(decoder=None)
+    params = (nn.Parameter(torch.randn(3, 2)), nn.Parameter(torch.randn(5)))
+    clip_a, clip_b = object(), object()
+    f1 = g._flat_parameters(params, clip_a)
+    assert f1.shape == (11,) and f1.requires_grad
+    assert g._flat_parameters(tuple(params), clip_a) is f1               # same clip, same parameters: the same tensor
+    assert g._flat_parameters(params, clip_b) is not f1                   # a new clip re-reads the parameters
+    assert g._flat_parameters(params, None) is not g._flat_parameters(params, None)   # no key: never cached
+    f1.sum().backward()
+    assert torch.equal(params[0].grad, torch.ones(3, 2))
