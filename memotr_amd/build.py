@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(_HERE, "csrc", "msda_hip.hip")
 HDR = os.path.join(os.path.dirname(_HERE), "include", "msda_hip.h")
 COMMON = os.path.join(_HERE, "csrc", "msda_common.h")
+FWD_WIN = os.path.join(_HERE, "csrc", "msda_fwd_win.h")
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libmsda_hip.so")
 CLIP_SRC = os.path.join(_HERE, "csrc", "clip_ops.hip")
@@ -34,7 +35,7 @@ def source_hash() -> str:
     number taken on other kernels is recognised as stale."""
     import hashlib
     h = hashlib.sha256()
-    for p in (SRC, COMMON):
+    for p in (SRC, COMMON, FWD_WIN):
         with open(p, "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -48,7 +49,7 @@ def _stale(lib: str, deps) -> bool:
 
 
 def needs_build() -> bool:
-    return _stale(LIB, (SRC, HDR, COMMON))
+    return _stale(LIB, (SRC, HDR, COMMON, FWD_WIN))
 
 
 def _compile(src: str, lib: str, verbose: bool) -> str:

@@ -1,0 +1,631 @@
+// msda_fwd_win.h -- forward for self-attention over the pyramid (one query per pixel, Lq == S), round 3.
+// Included by msda_hip.hip inside its anonymous namespace (shares msda_common.h and the host-side option state).
+//
+// Semantics: models/ops/src/cuda/ms_deform_im2col_cuda.cuh:237-299 (+ bilinear :33-84); fused prologue
+// models/ops/modules/ms_deform_attn.py:104-123.
+//
+// What binds the direct gather (msda_fwd_d32_gather) is the vector-L1 request rate: every (query, head) row reads
+// 64 corner rows of 128 B, 11.4 M requests per encoder call at ~0.45 requests/clk/CU = 41 us.
+// This kernel moves the three coarse levels (75 % of the requests, 25 % of `value`) to LDS:
+//
+//   * a workgroup owns (batch, head, region); a region is the set of queries whose pixels fall in one cell of a
+//     2^rlog-pixel grid on the finest level (8 x 8 + 4 x 4 + 2 x 2 + 1 queries for rlog = 3) -- all of them sample the
+//     same neighbourhood of every level;
+//   * blocks are numbered head-major and block i runs on XCD i % 8, so each XCD's 4 MiB L2 holds ONE head's slab of
+//     `value` (2.9 MB at 800 x 1333): the slab is fetched from the fabric once instead of ~3.6 times;
+//   * per windowed level one window of this head's rows (128 B per pixel, zero outside the level / on padded
+//     pixels) is filled with `buffer_load ... lds` (no VGPR round trip) around the mean sampling position measured
+//     on the workgroup's first rows; the finest level keeps going through the vector L1, so both pipes work;
+//   * 16 lanes own a (query, head) row: lanes of one half read pixel w0, the other half pixel w0 + 1 -- one
+//     ds_read_b128 covers 256 contiguous bytes per row, and the lane -> (row, chunk) map follows the four 16-lane
+//     groups the LDS services a b128 read in, so the read is bank-conflict free (256 B/clk/CU instead of ~110 for
+//     independent 128-B rows);
+//   * one lane stages one (row, point) record: [addr_top, addr_bot, w_top, w_bot] per half, LDS byte addresses for
+//     points inside their window, `value` byte offsets (out of range = zero padding) otherwise; a point outside
+//     its window takes the global path, so results never depend on the window placement -- only the speed does.
+#pragma once
+
+constexpr int kWinMaxL = 4;
+
+struct WinPlan {
+    int N, S, M, L, P, Lq;
+    int RY, RX;                    // regions per image
+    int rows;                      // queries per region
+    int steps;                     // ceil(rows / 4)
+    int lwin0;                     // first level served from an LDS window
+    int rlogx, rlogy;              // log2 of the region width / height on level 0
+    int H[kWinMaxL], W[kWinMaxL];
+    int qstart[kWinMaxL];          // first query of level l
+    int shx[kWinMaxL], shy[kWinMaxL];   // log2 of the region width / height on level l
+    int row0[kWinMaxL + 1];        // first region-row of level l
+    int ww[kWinMaxL], wh[kWinMaxL];  // window width / height in pixels (0: no window)
+    int wmagic[kWinMaxL];          // (x * magic) >> 16 == x / ww for x < ww * wh
+    int wbase[kWinMaxL + 1];       // first window pixel of level l (multiples of 8); [kWinMaxL] = the zero row
+    float ratw[kWinMaxL][kWinMaxL], rath[kWinMaxL][kWinMaxL];   // [lq][l] = W_l / W_lq, H_l / H_lq
+    int groups;                    // 8-pixel fill groups (window pixels + the zero row, rounded up)
+    float rcpH[kWinMaxL], rcpW[kWinMaxL], rcpP;   // correctly rounded 1/H, 1/W, 1/P (div_small)
+    unsigned value_bytes;
+    int n_blocks;
+    int ablate;                    // profiling only (msda_set_option "fwd_win_ablate"): 1 stop after the prologue, 2 no gather
+};
+
+struct WinTables {
+    int H[kWinMaxL], W[kWinMaxL], qstart[kWinMaxL], shx[kWinMaxL], shy[kWinMaxL], row0[kWinMaxL + 1];
+    int ww[kWinMaxL], wh[kWinMaxL], wmagic[kWinMaxL], wbase[kWinMaxL + 1], lstart[kWinMaxL];
+    int ox[kWinMaxL], oy[kWinMaxL];
+    int lvl[16];                   // level of point t
+};
+
+struct WinRow {
+    bool ok;
+    int lq, py, px;
+    unsigned qrow, pm;
+};
+
+__device__ __forceinline__ WinRow win_row(const WinTables &tb, int L, int rows, int r, int b, int ry, int rx, int m,
+                                          int M, int Lq) {
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < kWinMaxL; ++i)
+        if (i < L && r >= tb.row0[i]) l = i;
+    const int local = r - tb.row0[l], sx = tb.shx[l], sy = tb.shy[l];
+    WinRow o;
+    o.lq = l;
+    o.py = (ry << sy) + (local >> sx);
+    o.px = (rx << sx) + (local & ((1 << sx) - 1));
+    o.ok = (r < rows) && (o.py < tb.H[l]) && (o.px < tb.W[l]);
+    const int q = o.ok ? tb.qstart[l] + o.py * tb.W[l] + o.px : 0;
+    o.qrow = (unsigned)b * (unsigned)Lq + (unsigned)q;
+    o.pm = o.qrow * (unsigned)M + (unsigned)m;
+    return o;
+}
+
+// raw inputs of one (row, point): what a lane prefetches one step ahead
+struct WinRaw {
+    f32x2 a;       // plain: location (x, y); fused: offset (x, y)
+    float w;       // plain: attention weight; fused: logit
+    f32x4 r;       // fused: reference point (x, y[, w, h])
+};
+
+template <bool FUSED>
+__device__ __forceinline__ WinRaw win_load_raw(const PointSrc &src, unsigned qrow, unsigned pm, int m, int L, int LP,
+                                               int t, int l) {
+    WinRaw w;
+    w.a = f32x2{0.f, 0.f};
+    w.w = FUSED ? -INFINITY : 0.f;
+    w.r = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (t < LP) {      // rows that do not exist read query 0: always a legal address
+        if (FUSED) {
+            const float *off = src.proj + (qrow * (unsigned)src.proj_stride + (unsigned)((m * LP + t) * 2));
+            w.a = *reinterpret_cast<const f32x2 *>(off);
+            w.w = src.proj[qrow * (unsigned)src.proj_stride + (unsigned)(src.n_off + m * LP + t)];
+            const float *rp = src.ref + (qrow * (unsigned)L + (unsigned)l) * (unsigned)src.ref_dim;
+            if (src.ref_dim == 2) {
+                const f32x2 r2 = *reinterpret_cast<const f32x2 *>(rp);
+                w.r.x = r2.x;
+                w.r.y = r2.y;
+            } else {
+                w.r = *reinterpret_cast<const f32x4 *>(rp);
+            }
+        } else {
+            w.a = *reinterpret_cast<const f32x2 *>(src.loc + (pm * (unsigned)LP + (unsigned)t) * 2u);
+            w.w = src.attn[pm * (unsigned)LP + (unsigned)t];
+        }
+    }
+    return w;
+}
+
+// x / d for a small positive integer d held as a float, with rd = RN(1 / d) from the host: q0 = x * rd,
+// q = fma(fma(-d, q0, x), rd, q0) is the correctly rounded quotient (Markstein) whenever nothing under- or overflows;
+// outside that range (and for zeros, whose sign the correction loses) the IEEE division runs.  Same bits as x / d.
+__device__ __forceinline__ float div_small(float x, float d, float rd) {
+#pragma clang fp contract(off)
+    const float ax = fabsf(x);
+    if (ax >= 0x1p-40f && ax <= 0x1p40f) {
+        const float q0 = x * rd;
+        const float r = __builtin_fmaf(-d, q0, x);
+        return __builtin_fmaf(r, rd, q0);
+    }
+    return x / d;
+}
+
+// sampling location from the raw inputs; the fused form repeats fused_location()'s IEEE operation order
+template <bool FUSED>
+__device__ __forceinline__ f32x2 win_location(const WinRaw &w, int ref_dim, float fP, float rP, float fH, float rH,
+                                              float fW, float rW) {
+#pragma clang fp contract(off)
+    if (!FUSED) return w.a;
+    f32x2 xy;
+    if (ref_dim == 2) {
+        const float dx = div_small(w.a.x, fW, rW), dy = div_small(w.a.y, fH, rH);
+        xy.x = w.r.x + dx;
+        xy.y = w.r.y + dy;
+    } else {
+        const float px = div_small(w.a.x, fP, rP), py = div_small(w.a.y, fP, rP);
+        const float qx = px * w.r.z, qy = py * w.r.w;
+        const float hx = qx * 0.5f, hy = qy * 0.5f;
+        xy.x = w.r.x + hx;
+        xy.y = w.r.y + hy;
+    }
+    return xy;
+}
+
+// reductions over the 16 lanes of a staging row (one lane per point), DPP only
+__device__ __forceinline__ float row16_max(float x) {
+    x = fmaxf(x, MSDA_DPP(x, 0xB1));
+    x = fmaxf(x, MSDA_DPP(x, 0x4E));
+    x = fmaxf(x, MSDA_DPP(x, 0x141));
+    x = fmaxf(x, MSDA_DPP(x, 0x140));
+    return x;
+}
+__device__ __forceinline__ float row16_sum(float x) {
+    x += MSDA_DPP(x, 0xB1);
+    x += MSDA_DPP(x, 0x4E);
+    x += MSDA_DPP(x, 0x141);
+    x += MSDA_DPP(x, 0x140);
+    return x;
+}
+
+// One point whose record may be an LDS address (inside its window) or a `value` byte offset (bit 0 of word 0 set),
+// lane by lane: loads and FMAs in one place.
+__device__ __forceinline__ f32x4 win_mixed_point(const u32x4 r, const unsigned char *s_dyn, unsigned zero_off,
+                                                 __amdgpu_buffer_rsrc_t vr, unsigned sub16, f32x4 acc) {
+    const bool g = (r.x & 1u) != 0u;
+    f32x4 v0 = *reinterpret_cast<const f32x4 *>(s_dyn + ((g ? zero_off : r.x) + sub16));
+    f32x4 v1 = *reinterpret_cast<const f32x4 *>(s_dyn + ((g ? zero_off : r.y) + sub16));
+    if (g) {
+        v0 = buf_load_f4(vr, (r.x & ~1u) + sub16);
+        v1 = buf_load_f4(vr, r.y + sub16);
+    }
+    acc += __uint_as_float(r.z) * v0;
+    acc += __uint_as_float(r.w) * v1;
+    return acc;
+}
+
+typedef __attribute__((address_space(3))) void lds_void;
+
+// WPS = wavefronts per SIMD the register budget is sized for (4: 128 VGPRs -- 512-thread workgroups, or four 256-thread
+// workgroups per CU; 3: 168 VGPRs -- three 256-thread workgroups per CU, what 40-53 KB of LDS admits)
+// EARLY: the corner rows of the first four global points are requested before the LDS-served points and used after
+// them (their latency hides behind the LDS phase at the price of 40 registers held across it).
+template <bool FUSED, bool DMA, int WPS, bool EARLY>
+__global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(const float *__restrict__ value,
+                                                           const int64_t *__restrict__ lstart, const PointSrc src,
+                                                           float *__restrict__ out, const WinPlan pl) {
+    __shared__ WinTables tb;
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+
+    // ---- block -> (head, batch, region); head-major numbering, one contiguous run of ids per XCD ----
+    const int chunk = (int)(gridDim.x >> 3);
+    const int sw = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    if (sw >= pl.n_blocks) return;
+    const int nreg = pl.RY * pl.RX;
+    const int reg = sw % nreg;
+    const int hb = sw / nreg;
+    const int b = hb % pl.N, m = hb / pl.N;
+    const int ry = reg / pl.RX, rx = reg - ry * pl.RX;
+
+    const int L = pl.L, P = pl.P, LP = L * P, M = pl.M;
+    const int tid = threadIdx.x, lane = tid & 63, nw = (int)(blockDim.x >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform, and known to be
+    if (tid < kWinMaxL) {
+        tb.H[tid] = pl.H[tid];
+        tb.W[tid] = pl.W[tid];
+        tb.qstart[tid] = pl.qstart[tid];
+        tb.shx[tid] = pl.shx[tid];
+        tb.shy[tid] = pl.shy[tid];
+        tb.ww[tid] = pl.ww[tid];
+        tb.wh[tid] = pl.wh[tid];
+        tb.wmagic[tid] = pl.wmagic[tid];
+        tb.lstart[tid] = tid < L ? (int)lstart[tid] : 0;
+        tb.ox[tid] = tb.oy[tid] = 0;
+    }
+    if (tid <= kWinMaxL) {
+        tb.row0[tid] = pl.row0[tid];
+        tb.wbase[tid] = pl.wbase[tid];
+    }
+    if (tid >= 64 && tid < 80) tb.lvl[tid - 64] = (tid - 64) < LP ? (tid - 64) / P : 0;
+    __syncthreads();
+
+    // staging layout: lane -> (row slot, point)
+    const int s_rs = lane >> 4, s_t = lane & 15;
+    const int s_l = tb.lvl[s_t];
+    // gather layout: lane -> (row slot = LDS service group of a b128 read, pixel half, 16-byte chunk)
+    const int g_j = lane & 15, g_odd = (lane >> 4) & 1;
+    const int g_jq = g_j >> 2;
+    const bool g_inner = (g_jq == 1) || (g_jq == 2);
+    const int g_row = ((lane >> 5) << 1) + ((g_inner == (g_odd != 0)) ? 0 : 1);
+    const int g_half = g_j >> 3;
+    const int g_chunk = (g_half ? 3 - (g_j & 3) : (g_j & 3)) + 4 * g_odd;
+    const unsigned sub16 = (unsigned)g_chunk * 16u;
+
+    const __amdgpu_buffer_rsrc_t vr = make_rsrc(value, pl.value_bytes);
+    const unsigned zero_off = (unsigned)tb.wbase[kWinMaxL] * 128u;
+    const unsigned win_bytes = (unsigned)pl.groups * 1024u;
+    u32x4 *rec_w = reinterpret_cast<u32x4 *>(s_dyn + win_bytes) + wave * 128;     // 64 records of 32 bytes
+    const u32x4 *rec_g = rec_w + g_row * 32 + g_half;                               // + 2 * t
+    int *s_rowq = reinterpret_cast<int *>(s_dyn + win_bytes + (unsigned)nw * 2048u);   // query of region row r, -1: none
+    // sampled (dx, dy, count) per level of every first-step row: lives in wave 0's record space until the steps start
+    float *s_part = reinterpret_cast<float *>(s_dyn + win_bytes);
+    const unsigned pix_stride = (unsigned)M * 128u;
+    const unsigned row_base = ((unsigned)b * (unsigned)pl.S * (unsigned)M + (unsigned)m) * 128u;
+    const unsigned q_base = (unsigned)b * (unsigned)pl.Lq;
+    const int lwin0 = pl.lwin0;
+
+    // the region's rows -> query indices, once
+    for (int r = tid; r < pl.steps * 4; r += (int)blockDim.x) {
+        const WinRow w = win_row(tb, L, pl.rows, r, b, ry, rx, m, M, pl.Lq);
+        s_rowq[r] = w.ok ? (int)(w.qrow - q_base) : -1;
+    }
+
+    // ---- first step's inputs; the mean sampling offset of every windowed level, measured on them ----
+    int step = wave;
+    bool row_ok;
+    WinRaw raw;
+    {
+        const WinRow row = win_row(tb, L, pl.rows, step * 4 + s_rs, b, ry, rx, m, M, pl.Lq);
+        row_ok = row.ok;
+        raw = win_load_raw<FUSED>(src, row.qrow, row.pm, m, L, LP, s_t, s_l);
+        if (lwin0 < L) {
+            // placement only: approximate arithmetic is fine here (the records repeat it exactly)
+            float dx = 0.f, dy = 0.f, dc = 0.f;
+            if (step < pl.steps && row.ok && s_t < LP && s_l >= lwin0) {
+                const float fW = (float)tb.W[s_l], fH = (float)tb.H[s_l];
+                f32x2 xy = raw.a;
+                if (FUSED) {
+                    if (src.ref_dim == 2) {
+                        xy.x = raw.r.x + raw.a.x * pl.rcpW[s_l];
+                        xy.y = raw.r.y + raw.a.y * pl.rcpH[s_l];
+                    } else {
+                        xy.x = raw.r.x + raw.a.x * pl.rcpP * raw.r.z * 0.5f;
+                        xy.y = raw.r.y + raw.a.y * pl.rcpP * raw.r.w * 0.5f;
+                    }
+                }
+                const float w_im = xy.x * fW - 0.5f, h_im = xy.y * fH - 0.5f;
+                if ((h_im > -1.f) & (w_im > -1.f) & (h_im < fH) & (w_im < fW)) {
+                    // minus where the query's own pixel centre lands on level s_l
+                    dx = w_im - (((float)row.px + 0.5f) * pl.ratw[row.lq][s_l] - 0.5f);
+                    dy = h_im - (((float)row.py + 0.5f) * pl.rath[row.lq][s_l] - 0.5f);
+                    dc = 1.f;
+                }
+            }
+            for (int l = lwin0; l < L; ++l) {
+                const bool mine = s_l == l;
+                const float sx = row16_sum(mine ? dx : 0.f), sy = row16_sum(mine ? dy : 0.f);
+                const float sc = row16_sum(mine ? dc : 0.f);
+                if (s_t == 0) {
+                    float *pp = s_part + ((wave * 4 + s_rs) * kWinMaxL + l) * 3;
+                    pp[0] = sx;
+                    pp[1] = sy;
+                    pp[2] = sc;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (lwin0 < L) {
+        if (tid >= lwin0 && tid < L) {
+            const int l = tid;
+            float sx = 0.f, sy = 0.f, cnt = 0.f;
+            for (int i = 0; i < nw * 4; ++i) {
+                sx += s_part[(i * kWinMaxL + l) * 3];
+                sy += s_part[(i * kWinMaxL + l) * 3 + 1];
+                cnt += s_part[(i * kWinMaxL + l) * 3 + 2];
+            }
+            const float rc = cnt > 0.f ? __builtin_amdgcn_rcpf(cnt) : 0.f;
+            // centre of the region in level-l sampling coordinates + the measured mean offset
+            const float cx = ((float)(rx << pl.rlogx) + 0.5f * (float)(1 << pl.rlogx)) * pl.ratw[0][l] - 0.5f + sx * rc;
+            const float cy = ((float)(ry << pl.rlogy) + 0.5f * (float)(1 << pl.rlogy)) * pl.rath[0][l] - 0.5f + sy * rc;
+            const int ww = tb.ww[l], wh = tb.wh[l];
+            int ox = (int)floorf(cx - 0.5f * (float)(ww - 1) + 0.5f);
+            int oy = (int)floorf(cy - 0.5f * (float)(wh - 1) + 0.5f);
+            // keep the window on the level plus its one-pixel zero border
+            const int max_x = tb.W[l] + 1 - ww, max_y = tb.H[l] + 1 - wh;
+            ox = ox > max_x ? max_x : ox;
+            oy = oy > max_y ? max_y : oy;
+            tb.ox[l] = ox < -1 ? -1 : ox;
+            tb.oy[l] = oy < -1 ? -1 : oy;
+        }
+        __syncthreads();
+
+        // ---- fill the windows: 8 pixels (1 KiB) per wave instruction; cells outside the level / padded read 0.
+        //      Every level's window starts on a group boundary, so the level is uniform per instruction ----
+        const unsigned char *mk = (FUSED && src.mask != nullptr) ? src.mask + (size_t)b * pl.S : nullptr;
+        for (int l = lwin0; l <= L; ++l) {        // l == L: the group that holds the zero row
+            const int g0 = tb.wbase[l < L ? l : kWinMaxL] >> 3;
+            const int g1 = l < L ? (tb.wbase[l + 1 < L ? l + 1 : kWinMaxL] >> 3) : pl.groups;
+            const int lc = l < L ? l : L - 1;
+            const int ww = tb.ww[lc], npx = l < L ? ww * tb.wh[lc] : 0, magic = tb.wmagic[lc];
+            const int oy = tb.oy[lc], ox = tb.ox[lc], H = tb.H[lc], W = tb.W[lc];
+            const unsigned lbase = row_base + (unsigned)tb.lstart[lc] * pix_stride + (unsigned)(lane & 7) * 16u;
+            for (int g = g0 + wave; g < g1; g += nw) {
+                const int local = (g - g0) * 8 + (lane >> 3);
+                const int wy = (local * magic) >> 16, wx = local - wy * ww;
+                const int gy = oy + wy, gx = ox + wx;
+                bool inside = (local < npx) & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
+                const int cell = gy * W + gx;
+                if (mk != nullptr && inside) inside = !mk[tb.lstart[lc] + cell];
+                const unsigned off = inside ? lbase + (unsigned)cell * pix_stride : kOobOffset;
+                if (DMA) {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(vr, (lds_void *)(s_dyn + (size_t)g * 1024), 16, (int)off, 0, 0, 0);
+                } else {
+                    reinterpret_cast<f32x4 *>(s_dyn)[(size_t)g * 64 + lane] = buf_load_f4(vr, off);
+                }
+            }
+        }
+    }
+
+    // ---- this lane's point sits on one level for the whole kernel: its constants ----
+    const bool c_pt = s_t < LP;
+    const int cH = tb.H[s_l], cW = tb.W[s_l];
+    const float fH = (float)cH, fW = (float)cW, fP = (float)P;
+    const float rH = pl.rcpH[s_l], rW = pl.rcpW[s_l], rP = pl.rcpP;
+    const bool c_windowed = c_pt && s_l >= lwin0;
+    const int c_ww = tb.ww[s_l];
+    const unsigned c_wwm1 = c_windowed ? (unsigned)(c_ww - 1) : 0u, c_whm1 = c_windowed ? (unsigned)(tb.wh[s_l] - 1) : 0u;
+    const int c_ox = tb.ox[s_l], c_oy = tb.oy[s_l];
+    const unsigned c_wbase = (unsigned)tb.wbase[s_l] * 128u;
+    const unsigned c_wrow = (unsigned)c_ww * 128u;
+    const unsigned c_wps = (unsigned)cW * pix_stride;
+    const unsigned c_lbase = row_base + (unsigned)tb.lstart[s_l] * pix_stride;     // pixel 0 of the level, this head
+    const unsigned c_flag = c_windowed ? 1u : 0u;          // word 0 of a windowed level's record: bit 0 = global path
+    const unsigned c_dead = c_windowed ? zero_off : kOobOffset;
+    const unsigned char *c_mask = (FUSED && src.mask != nullptr) ? src.mask + ((size_t)b * pl.S + tb.lstart[s_l]) : nullptr;
+    const int T0 = lwin0 * P < LP ? lwin0 * P : LP;
+    const bool early = EARLY && T0 >= 4;
+
+    // ---- the steps: stage 64 (row, point) records, gather, store ----
+    if (pl.ablate & 1) {
+        if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+    const int iters = (pl.steps + nw - 1) / nw;
+    for (int it = 0; it < iters; ++it, step += nw) {
+        const bool have = step < pl.steps;       // wave-uniform
+        unsigned gmask = 0u;
+        if (have) {
+            // -- staging: this lane's point, straight-line --
+            float a_in;
+            if (FUSED) {
+                // exp2 / rcp approximations (<= 2 ulp on a weight): the forward's tolerance is 1e-3, the backward
+                // recomputes its own weights (msda_fused_points16_kernel)
+                const float mx = row16_max(raw.w);
+                const float e = __builtin_amdgcn_exp2f((raw.w - mx) * 1.4426950408889634f);
+                a_in = e * __builtin_amdgcn_rcpf(row16_sum(e));
+            } else {
+                a_in = raw.w;
+            }
+            const f32x2 xy = win_location<FUSED>(raw, src.ref_dim, fP, rP, fH, rH, fW, rW);
+            float h_im, w_im;
+            {
+#pragma clang fp contract(off)
+                const float ph = xy.y * fH, pw = xy.x * fW;      // the reference's rounding points (.cuh:285-288)
+                h_im = ph - 0.5f;
+                w_im = pw - 0.5f;
+            }
+            const bool gate = (h_im > -1.f) & (w_im > -1.f) & (h_im < fH) & (w_im < fW);
+            const float fh = floorf(h_im), fw = floorf(w_im);
+            const int h0 = (int)fh, w0 = (int)fw;
+            const bool live = gate & row_ok & c_pt;
+            const float lh = gate ? h_im - fh : 0.f, lw = gate ? w_im - fw : 0.f;
+            const float a = live ? a_in : 0.f;
+            const float hh = 1.f - lh, hw = 1.f - lw;
+            u32x4 ra, rb;
+            ra.z = __float_as_uint((hh * hw) * a);
+            ra.w = __float_as_uint((lh * hw) * a);
+            rb.z = __float_as_uint((hh * lw) * a);
+            rb.w = __float_as_uint((lh * lw) * a);
+            // inside its window: LDS byte addresses (the window holds zeros outside the level / on padded pixels)
+            const int wx = w0 - c_ox, wy = h0 - c_oy;
+            const bool inwin = live & ((unsigned)wx < c_wwm1) & ((unsigned)wy < c_whm1);
+            const unsigned lbase = c_wbase + (unsigned)(wy * c_ww + wx) * 128u;
+            // otherwise: byte offsets into `value`, out of range for corners that do not exist
+            const bool need = live & !inwin;
+            bool ok00 = need & ((unsigned)h0 < (unsigned)cH) & ((unsigned)w0 < (unsigned)cW);
+            bool ok01 = need & ((unsigned)h0 < (unsigned)cH) & ((unsigned)(w0 + 1) < (unsigned)cW);
+            bool ok10 = need & ((unsigned)(h0 + 1) < (unsigned)cH) & ((unsigned)w0 < (unsigned)cW);
+            bool ok11 = need & ((unsigned)(h0 + 1) < (unsigned)cH) & ((unsigned)(w0 + 1) < (unsigned)cW);
+            const int cell = h0 * cW + w0;
+            if (FUSED && c_mask != nullptr && need) {
+                ok00 = ok00 && !c_mask[ok00 ? cell : 0];
+                ok01 = ok01 && !c_mask[ok01 ? cell + 1 : 0];
+                ok10 = ok10 && !c_mask[ok10 ? cell + cW : 0];
+                ok11 = ok11 && !c_mask[ok11 ? cell + cW + 1 : 0];
+            }
+            const unsigned o00 = c_lbase + (unsigned)cell * pix_stride;
+            ra.x = inwin ? lbase : (need ? (ok00 ? o00 : kOobOffset) | c_flag : c_dead);
+            ra.y = inwin ? lbase + c_wrow : (need ? (ok10 ? o00 + c_wps : kOobOffset) : c_dead);
+            rb.x = inwin ? lbase + 128u : (need ? (ok01 ? o00 + pix_stride : kOobOffset) | c_flag : c_dead);
+            rb.y = inwin ? lbase + c_wrow + 128u : (need ? (ok11 ? o00 + c_wps + pix_stride : kOobOffset) : c_dead);
+            if (c_pt) {
+                rec_w[2 * lane] = ra;
+                rec_w[2 * lane + 1] = rb;
+            }
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(need & c_windowed);
+            const unsigned fold = (unsigned)(bal | (bal >> 32));
+            gmask = (fold | (fold >> 16)) & 0xffffu;
+        }
+        // -- prefetch the next step's inputs --
+        if (step + nw < pl.steps) {
+            const int q = s_rowq[(step + nw) * 4 + s_rs];
+            row_ok = q >= 0;
+            const unsigned qrow = q_base + (unsigned)(q < 0 ? 0 : q);
+            raw = win_load_raw<FUSED>(src, qrow, qrow * (unsigned)M + (unsigned)m, m, L, LP, s_t, s_l);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        // -- levels read through the vector L1: issue the first four points' corner rows now, use them after the
+        //    LDS-served points (fewer than four such points: they all go through the late loop) --
+        u32x4 gr[4];
+        f32x4 gv[4][2];
+        if (have && early && !(pl.ablate & 2)) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) gr[i] = rec_g[2 * i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                gv[i][0] = buf_load_f4(vr, gr[i].x + sub16);
+                gv[i][1] = buf_load_f4(vr, gr[i].y + sub16);
+            }
+        }
+        if (it == 0 && lwin0 < L) {            // the windows must have landed before the first LDS-served point
+            if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        if (have && !(pl.ablate & 2)) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            // -- levels read from the LDS windows, four points per batch.  A point some row of the wave could not
+            //    serve from its window (bit in gmask) is handled on the spot, loads and FMAs, so that the common path
+            //    holds no register a vector-memory instruction writes --
+            int t0 = T0;
+            for (; t0 + 4 <= LP; t0 += 4) {
+                const u32x4 *rp = rec_g + 2 * t0;
+                if (((gmask >> t0) & 15u) == 0u) {
+                    u32x4 r[4];
+                    f32x4 v[4][2];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) r[i] = rp[2 * i];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        v[i][0] = *reinterpret_cast<const f32x4 *>(s_dyn + (r[i].x + sub16));
+                        v[i][1] = *reinterpret_cast<const f32x4 *>(s_dyn + (r[i].y + sub16));
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        acc += __uint_as_float(r[i].z) * v[i][0];
+                        acc += __uint_as_float(r[i].w) * v[i][1];
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const u32x4 r = rp[2 * i];
+                        if ((gmask >> (t0 + i)) & 1u) {
+                            acc = win_mixed_point(r, s_dyn, zero_off, vr, sub16, acc);
+                        } else {
+                            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(s_dyn + (r.x + sub16));
+                            const f32x4 v1 = *reinterpret_cast<const f32x4 *>(s_dyn + (r.y + sub16));
+                            acc += __uint_as_float(r.z) * v0;
+                            acc += __uint_as_float(r.w) * v1;
+                        }
+                    }
+                }
+            }
+            for (; t0 < LP; ++t0) acc = win_mixed_point(rec_g[2 * t0], s_dyn, zero_off, vr, sub16, acc);
+            // -- consume the global points issued above, then any that were not --
+            if (early) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc += __uint_as_float(gr[i].z) * gv[i][0];
+                    acc += __uint_as_float(gr[i].w) * gv[i][1];
+                }
+            }
+            int tg = early ? 4 : 0;
+            for (; tg + 4 <= T0; tg += 4) {          // eight corner rows in flight per lane
+                u32x4 r[4];
+                f32x4 v[4][2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) r[i] = rec_g[2 * (tg + i)];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v[i][0] = buf_load_f4(vr, r[i].x + sub16);
+                    v[i][1] = buf_load_f4(vr, r[i].y + sub16);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc += __uint_as_float(r[i].z) * v[i][0];
+                    acc += __uint_as_float(r[i].w) * v[i][1];
+                }
+            }
+            for (; tg < T0; ++tg) {
+                const u32x4 r = rec_g[2 * tg];
+                const f32x4 v0 = buf_load_f4(vr, r.x + sub16), v1 = buf_load_f4(vr, r.y + sub16);
+                acc += __uint_as_float(r.z) * v0;
+                acc += __uint_as_float(r.w) * v1;
+            }
+            // -- the two pixel halves of a row sit on row_mirror partners --
+            // (scalars: __builtin_bit_cast of a vector ELEMENT reads element 0 with this compiler)
+            const float a0 = acc.x, a1 = acc.y, a2 = acc.z, a3 = acc.w;
+            acc.x = a0 + MSDA_DPP(a0, 0x140);
+            acc.y = a1 + MSDA_DPP(a1, 0x140);
+            acc.z = a2 + MSDA_DPP(a2, 0x140);
+            acc.w = a3 + MSDA_DPP(a3, 0x140);
+            const int q = s_rowq[step * 4 + g_row];
+            if (g_half == 0 && q >= 0) {
+                const unsigned pm = (q_base + (unsigned)q) * (unsigned)M + (unsigned)m;
+                *reinterpret_cast<f32x4 *>(out + ((size_t)pm * 32u + (unsigned)g_chunk * 4u)) = acc;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// Plan the region tiling from the HOST copy of the level shapes; false when this kernel does not apply.
+// margins[l]: window side on level l = region side + 2 * margin + 1.
+inline bool make_win_plan(WinPlan &pl, const int64_t *shapes_host, int N, int S, int M, int D, int L, int Lq, int P,
+                          long value_bytes, int rlogx, int rlogy, int lwin0, const int *margins, int threads,
+                          size_t &lds) {
+    if (!shapes_host || D != 32 || L < 1 || L > kWinMaxL || Lq != S || L * P > 16) return false;
+    if (rlogy < L - 1) rlogy = L - 1;
+    if (rlogx < rlogy) rlogx = rlogy;
+    if (rlogx > 5 || rlogy > 5 || threads < 64 || threads > 512 || (threads & 63)) return false;
+    if (lwin0 < 0) lwin0 = 0;
+    if (lwin0 > L) lwin0 = L;
+    memset(&pl, 0, sizeof(pl));
+    pl.N = N; pl.S = S; pl.M = M; pl.L = L; pl.P = P; pl.Lq = Lq; pl.lwin0 = lwin0; pl.rlogx = rlogx; pl.rlogy = rlogy;
+    pl.value_bytes = (unsigned)value_bytes;
+    long q = 0;
+    int rows = 0, px = 0, RY = 0, RX = 0;
+    for (int l = 0; l < kWinMaxL; ++l) {
+        if (l < L) {
+            const long H = shapes_host[2 * l], W = shapes_host[2 * l + 1];
+            if (H <= 0 || W <= 0 || H > 32767 || W > 32767 || W * M >= (1L << 23)) return false;
+            const int sx = rlogx - l, sy = rlogy - l, side_x = 1 << sx, side_y = 1 << sy;
+            int ww = 0, wh = 0;
+            if (l >= lwin0) {
+                int mg = margins ? margins[l] : 3;
+                if (mg < 0) mg = 0;
+                ww = side_x + 2 * mg + 1;
+                wh = side_y + 2 * mg + 1;
+                if (ww > (int)W + 2) ww = (int)W + 2;      // never larger than the level and its zero border
+                if (wh > (int)H + 2) wh = (int)H + 2;
+                if (ww < 2) ww = 2;
+                if (wh < 2) wh = 2;
+            }
+            pl.H[l] = (int)H; pl.W[l] = (int)W; pl.qstart[l] = (int)q; pl.shx[l] = sx; pl.shy[l] = sy; pl.row0[l] = rows;
+            pl.rcpH[l] = (float)(1.0 / (double)H); pl.rcpW[l] = (float)(1.0 / (double)W);
+            pl.ww[l] = ww; pl.wh[l] = wh; pl.wbase[l] = px;
+            int magic = 65537;
+            if (ww > 0) {
+                if (ww * wh >= 32768) return false;
+                magic = 65536 / ww + 1;
+                for (int x = 0; x < ww * wh; ++x)
+                    if (((x * magic) >> 16) != x / ww) return false;
+            }
+            pl.wmagic[l] = magic;
+            q += H * W; rows += side_x * side_y; px += (ww * wh + 7) & ~7;     // windows start on 8-pixel groups
+            const int ry = (int)((H + side_y - 1) / side_y), rx = (int)((W + side_x - 1) / side_x);
+            RY = ry > RY ? ry : RY;
+            RX = rx > RX ? rx : RX;
+        } else {
+            pl.H[l] = 1; pl.W[l] = 1; pl.qstart[l] = (int)q; pl.shx[l] = 0; pl.shy[l] = 0; pl.row0[l] = rows;
+            pl.rcpH[l] = pl.rcpW[l] = 1.f;
+            pl.ww[l] = 0; pl.wh[l] = 0; pl.wmagic[l] = 65537; pl.wbase[l] = px;
+        }
+    }
+    if (q != S) return false;      // the host shapes do not describe this value tensor
+    for (int l = L; l <= kWinMaxL; ++l) { pl.row0[l] = rows; pl.wbase[l] = px; }
+    pl.rows = rows; pl.steps = (rows + 3) / 4; pl.RY = RY; pl.RX = RX;
+    pl.rcpP = (float)(1.0 / (double)P);
+    for (int a = 0; a < kWinMaxL; ++a)
+        for (int c = 0; c < kWinMaxL; ++c) {
+            pl.ratw[a][c] = (float)((double)pl.W[c] / (double)pl.W[a]);
+            pl.rath[a][c] = (float)((double)pl.H[c] / (double)pl.H[a]);
+        }
+    pl.groups = lwin0 < L ? px / 8 + 1 : 0;
+    const long nb = (long)N * RY * RX * M;
+    if (nb > (1L << 30)) return false;
+    pl.n_blocks = (int)nb;
+    lds = (size_t)pl.groups * 1024 + (size_t)(threads / 64) * 2048 + (size_t)pl.steps * 16;
+    return lds <= 160 * 1024 - 4096;
+}

@@ -506,7 +506,8 @@ __device__ __forceinline__ void fwd_gather_chunk(const u32x4 *rec, int t0, __amd
 template <int PTS, typename TV, bool FUSED>
 __global__ __launch_bounds__(256) void msda_fwd_d32_gather(
     const TV *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ lstart,
-    const PointSrc src, int N, int S, int M, int L, int Lq, int P, TV *__restrict__ out, unsigned value_bytes) {
+    const PointSrc src, int N, int S, int M, int L, int Lq, int P, TV *__restrict__ out, unsigned value_bytes,
+    int head_major) {
     constexpr int D = 32;
     constexpr int LANES = RowGeom<TV>::kLanes, ROWS = RowGeom<TV>::kRows, CH = RowGeom<TV>::kCh;
     __shared__ int s_H[kMaxLevels], s_W[kMaxLevels], s_start[kMaxLevels];
@@ -524,13 +525,24 @@ __global__ __launch_bounds__(256) void msda_fwd_d32_gather(
     u32x4 *rec = reinterpret_cast<u32x4 *>(s_dyn) + (size_t)(wave * ROWS + grp) * rec_stride;
     // 32-bit row arithmetic: the launch envelope (check_dims) keeps every element index below 2^31
     const unsigned n_rows = (unsigned)N * (unsigned)Lq * (unsigned)M;
-    const unsigned n_tasks = (n_rows + ROWS - 1) / ROWS;
+    // head-major walk (option fwd_head_major): a wavefront owns ROWS consecutive queries of ONE head and the XCDs split
+    // the heads, so each XCD's L2 holds one head's slab of `value` instead of a band of all heads
+    const unsigned n_q = (unsigned)N * (unsigned)Lq, q_tasks = (n_q + ROWS - 1) / ROWS;
+    const unsigned n_tasks = head_major ? q_tasks * (unsigned)M : (n_rows + ROWS - 1) / ROWS;
     const __amdgpu_buffer_rsrc_t vr = make_rsrc(value, value_bytes);
     const unsigned lane_off = (unsigned)sub * 16u;
     const TaskWalk tw = xcd_walk(n_tasks, wpb);
     for (long task = tw.begin; task < tw.end; task += tw.step) {
-        const unsigned pm = (unsigned)task * ROWS + grp;
-        const bool row_ok = pm < n_rows;
+        unsigned pm;
+        bool row_ok;
+        if (head_major) {
+            const unsigned hm = (unsigned)task / q_tasks, qq = ((unsigned)task - hm * q_tasks) * ROWS + grp;
+            row_ok = qq < n_q;
+            pm = (row_ok ? qq : n_q - 1) * (unsigned)M + hm;
+        } else {
+            pm = (unsigned)task * ROWS + grp;
+            row_ok = pm < n_rows;
+        }
         const unsigned pmc = row_ok ? pm : n_rows - 1;
         const unsigned qrow = pmc / (unsigned)M;
         const int m = (int)(pmc - qrow * (unsigned)M);
@@ -1930,6 +1942,8 @@ __global__ __launch_bounds__(256) void msda_fused_finish16_kernel(const int64_t 
     }
 }
 
+#include "msda_fwd_win.h"
+
 // ----------------------------------------------------------------------------------------
 // host side
 // ----------------------------------------------------------------------------------------
@@ -1943,7 +1957,17 @@ std::atomic<int> opt_fwd_tile_margin{3}, opt_bwd_tile_margin{3};
 std::atomic<int> opt_fwd_tile_l0{1};      // hybrid forward: first level served from LDS windows
 std::atomic<int> opt_bwd_split{1};        // fused backward with a workspace: prologue kernel + plain tiled kernel + finish kernel
 std::atomic<int> opt_bwd_wide_log2{12};   // tiled backward: row-magnitude range (log2) that makes a region "wide"; 0 = off
-std::atomic<int> opt_bwd_ablate{0};       // profiling only: drop parts of the tiled backward (results are then wrong)
+std::atomic<int> opt_bwd_ablate{0};
+std::atomic<int> opt_fwd_head_major{0};    // gather forward: head-major task walk (one head per XCD)
+std::atomic<int> opt_fwd_win_rlog{3};       // windowed forward: log2 of the region height on level 0
+std::atomic<int> opt_fwd_win_rlogx{4};      // log2 of the region width (at least the height)
+std::atomic<int> opt_fwd_win_block{256};    // threads per workgroup (256 / 512)
+std::atomic<int> opt_fwd_win_l0{1};         // first level served from an LDS window
+std::atomic<int> opt_fwd_win_margins{0x3333};  // window margin per level, 4 bits each (level 0 in the low nibble)
+std::atomic<int> opt_fwd_win_ablate{0};     // profiling only
+std::atomic<int> opt_fwd_win_wps{0};        // 3 / 4: force the 168- / 128-register build
+std::atomic<int> opt_fwd_win_early{2};      // 0 / 1: global points after / around the LDS phase (2: by register budget)
+std::atomic<int> opt_fwd_win_dma{1};        // fill the windows with buffer_load ... lds       // profiling only: drop parts of the tiled backward (results are then wrong)
 
 int fail(int code, const char *msg) {
     snprintf(g_err, sizeof(g_err), "%s", msg);
@@ -2116,6 +2140,52 @@ int forward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart, 
     if constexpr (kD32Type) {
         const PointSrc src = make_src(loc, attn, fa, M, L, P);
         if constexpr (sizeof(TV) == 4) {
+            if (variant == 12) {
+                WinPlan wp;
+                size_t lds = 0;
+                const int mgs = opt_fwd_win_margins.load();
+                const int margins[kWinMaxL] = {mgs & 15, (mgs >> 4) & 15, (mgs >> 8) & 15, (mgs >> 12) & 15};
+                int threads = opt_fwd_win_block.load();
+                if (threads != 512 && threads != 384 && threads != 128) threads = 256;
+                if (make_win_plan(wp, shapes_host, N, S, M, D, L, Lq, P, value_bytes, opt_fwd_win_rlogx.load(),
+                                  opt_fwd_win_rlog.load(), opt_fwd_win_l0.load(), margins, threads, lds)) {
+                    const int grid = (wp.n_blocks + 7) & ~7;
+                    const bool dma = opt_fwd_win_dma.load() != 0;
+#define MSDA_LAUNCH_WIN(FU, DM, WPS, EA, NAME)                                                                       \
+    do {                                                                                                             \
+        rc = allow_big_lds(msda_fwd_d32_win<FU, DM, WPS, EA>, lds);                                                  \
+        if (rc) return rc;                                                                                           \
+        g_kernel = NAME;                                                                                             \
+        hipLaunchKernelGGL((msda_fwd_d32_win<FU, DM, WPS, EA>), dim3(grid), dim3(threads), lds, stream,              \
+                           (const float *)value, lstart, src, (float *)out, wp);                                     \
+    } while (0)
+                    wp.ablate = opt_fwd_win_ablate.load();
+                    // register budget by what the LDS footprint admits: four 256-thread workgroups per CU (<= 40 KB
+                    // each) -> 128 registers and the global points after the LDS phase; three -> 168 registers
+                    int wps = opt_fwd_win_wps.load();
+                    if (wps != 3 && wps != 4) wps = (threads <= 256 && lds + 640 > 40 * 1024) ? 3 : 4;
+                    if (threads > 256) wps = 4;
+                    int early = opt_fwd_win_early.load();
+                    if (early > 1) early = wps == 3 ? 1 : 0;
+                    if (!dma) {       // the register-staged fill is a debugging aid: one build
+                        if (fused) MSDA_LAUNCH_WIN(true, false, 4, false, "msda_fwd_d32_win<fused,nodma>");
+                        else MSDA_LAUNCH_WIN(false, false, 4, false, "msda_fwd_d32_win<nodma>");
+                    } else if (fused) {
+                        if (wps == 3 && early) MSDA_LAUNCH_WIN(true, true, 3, true, "msda_fwd_d32_win<fused,w3,early>");
+                        else if (wps == 3) MSDA_LAUNCH_WIN(true, true, 3, false, "msda_fwd_d32_win<fused,w3>");
+                        else if (early) MSDA_LAUNCH_WIN(true, true, 4, true, "msda_fwd_d32_win<fused,w4,early>");
+                        else MSDA_LAUNCH_WIN(true, true, 4, false, "msda_fwd_d32_win<fused,w4>");
+                    } else {
+                        if (wps == 3 && early) MSDA_LAUNCH_WIN(false, true, 3, true, "msda_fwd_d32_win<w3,early>");
+                        else if (wps == 3) MSDA_LAUNCH_WIN(false, true, 3, false, "msda_fwd_d32_win<w3>");
+                        else if (early) MSDA_LAUNCH_WIN(false, true, 4, true, "msda_fwd_d32_win<w4,early>");
+                        else MSDA_LAUNCH_WIN(false, true, 4, false, "msda_fwd_d32_win<w4>");
+                    }
+#undef MSDA_LAUNCH_WIN
+                    return check_launch(g_kernel);
+                }
+                variant = 3;  // the windowed kernel does not apply to this call
+            }
             if (variant == 8 || variant == 9) {
                 TilePlan pl;
                 size_t lds = 0;
@@ -2150,7 +2220,8 @@ int forward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart, 
         int block = opt_fwd_block.load();
         if (block < 64 || block > 256 || (block & 63)) block = 256;  // kernels carry __launch_bounds__(256)
         const int wpb = block / 64;
-        const long n_tasks = ((long)N * Lq * M + ROWS - 1) / ROWS;
+        const int head_major = opt_fwd_head_major.load() != 0 && (long)N * Lq >= 4096 ? 1 : 0;
+        const long n_tasks = head_major ? (((long)N * Lq + ROWS - 1) / ROWS) * M : ((long)N * Lq * M + ROWS - 1) / ROWS;
         // small problems: one wave per block so every task gets its own CU slot
         int use_block = block;
         if (n_tasks < (long)kNumCU * wpb) use_block = 64;
@@ -2162,7 +2233,7 @@ int forward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart, 
     do {                                                                                                             \
         g_kernel = NAME;                                                                                             \
         hipLaunchKernelGGL((msda_fwd_d32_gather<PTS, TV, FU>), dim3(grid), dim3(use_block), lds, stream, value,      \
-                           shapes, lstart, src, N, S, M, L, Lq, P, out, (unsigned)value_bytes);                      \
+                           shapes, lstart, src, N, S, M, L, Lq, P, out, (unsigned)value_bytes, head_major);          \
     } while (0)
         if (fused) {
             if (variant == 3) MSDA_LAUNCH_FWD(4, true, sizeof(TV) == 2 ? "msda_fwd_d32_gather<4,bf16,fused>" : "msda_fwd_d32_gather<4,fused>");
@@ -2535,6 +2606,16 @@ static std::atomic<int> *find_opt(const char *key) {
     if (!strcmp(key, "bwd_ablate")) return &opt_bwd_ablate;
     if (!strcmp(key, "bwd_wide_log2")) return &opt_bwd_wide_log2;
     if (!strcmp(key, "bwd_split")) return &opt_bwd_split;
+    if (!strcmp(key, "fwd_win_rlog")) return &opt_fwd_win_rlog;
+    if (!strcmp(key, "fwd_win_rlogx")) return &opt_fwd_win_rlogx;
+    if (!strcmp(key, "fwd_head_major")) return &opt_fwd_head_major;
+    if (!strcmp(key, "fwd_win_block")) return &opt_fwd_win_block;
+    if (!strcmp(key, "fwd_win_l0")) return &opt_fwd_win_l0;
+    if (!strcmp(key, "fwd_win_margins")) return &opt_fwd_win_margins;
+    if (!strcmp(key, "fwd_win_dma")) return &opt_fwd_win_dma;
+    if (!strcmp(key, "fwd_win_ablate")) return &opt_fwd_win_ablate;
+    if (!strcmp(key, "fwd_win_wps")) return &opt_fwd_win_wps;
+    if (!strcmp(key, "fwd_win_early")) return &opt_fwd_win_early;
     return nullptr;
 }
 

@@ -1,0 +1,197 @@
+"""GPU parity of the windowed forward (msda_fwd_d32_win, memotr_amd/csrc/msda_fwd_win.h) against the C oracle.
+
+The kernel serves the coarse pyramid levels from per-head LDS windows (pair reads, buffer_load ... lds fill) and
+sends every point that leaves its window through the global path, so its results must not depend on the region
+size, the window margins, the workgroup size, the fill method or on which levels are windowed -- every such
+configuration is checked against the oracle (not against another kernel):
+
+  * BASELINE shapes: S = Lq = 22323 (800x1333) and the BDD100K pyramid, encoder-like and uniform locations;
+  * clip-batched calls (N = 2 / 5);
+  * the fused-prologue entry (raw projection rows + reference points + padding mask), 2-d and 4-d reference points,
+    odd / non-halving / two-level pyramids with partial regions;
+  * non-finite values: NaN / Inf pixels reach exactly the rows the oracle says they reach.
+"""
+import numpy as np
+import pytest
+import torch
+
+from fused_helpers import expected, make_case
+
+pytestmark = pytest.mark.gpu
+
+WIN_DEFAULTS = dict(fwd_win_rlog=3, fwd_win_rlogx=4, fwd_win_block=256, fwd_win_l0=1, fwd_win_margins=0x3333, fwd_win_dma=1)
+
+
+@pytest.fixture(scope="module")
+def msda(hip_lib):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from memotr_amd import MultiScaleDeformableAttention as MSDA
+    return MSDA
+
+
+@pytest.fixture(autouse=True)
+def _force_win(hip_lib):
+    hip_lib.set_option("fwd_variant", 12)
+    yield
+    hip_lib.set_option("fwd_variant", 0)
+    for k, v in WIN_DEFAULTS.items():
+        hip_lib.set_option(k, v)
+
+
+def _cpu(x):
+    return {k: v.detach().cpu().numpy() for k, v in x.items() if isinstance(v, torch.Tensor)}
+
+
+def _oracle_fwd(c):
+    from oracle import msda_oracle as oracle
+    return oracle.forward(c["value"], c["shapes"], c["level_start"], c["loc"], c["attn"])
+
+
+def _hip_fwd(msda, x):
+    from memotr_amd.MultiScaleDeformableAttention import tag_host_shapes
+    tag_host_shapes(x["shapes"], x["shapes_list"])
+    out = msda.ms_deform_attn_forward(x["value"], x["shapes"], x["level_start"], x["loc"], x["attn"], 64)
+    return out.cpu().numpy()
+
+
+PYRAMIDS = {"dancetrack_800x1333": (800, 1333), "bdd100k_720x1280": (720, 1280)}
+
+
+@pytest.mark.parametrize("pyr", list(PYRAMIDS))
+@pytest.mark.parametrize("dist", ["encoder_like", "uniform"])
+def test_win_forward_full_size_matches_oracle(msda, hip_lib, pyr, dist):
+    from memotr_amd.synth import make_inputs
+    h, w = PYRAMIDS[pyr]
+    x = make_inputs(height=h, width=w, dist=dist, device="cuda", seed=11)
+    got = _hip_fwd(msda, x)
+    assert "msda_fwd_d32_win" in hip_lib.last_kernel(), hip_lib.last_kernel()
+    # 16 points x 4 corners of O(1) values; 2e-5 abs is 50x inside north_star's 1e-3
+    np.testing.assert_allclose(got, _oracle_fwd(_cpu(x)), rtol=1e-4, atol=2e-5)
+    again = _hip_fwd(msda, x)
+    assert np.array_equal(got, again), "the forward has no atomics: run-to-run identical"
+
+
+CONFIGS = [
+    dict(),                                                    # defaults: 16 x 8 pixel regions, windows on levels 1-3
+    dict(fwd_win_dma=0),                                       # fill through registers
+    dict(fwd_win_rlogx=3),                                     # square 8-pixel regions (85 rows per workgroup)
+    dict(fwd_win_rlog=4),                                      # 16-pixel regions (340 rows per workgroup)
+    dict(fwd_win_rlogx=5, fwd_win_margins=0x2222),             # 32 x 8 regions
+    dict(fwd_win_rlog=4, fwd_win_block=512),
+    dict(fwd_win_block=512),
+    dict(fwd_win_block=128),
+    dict(fwd_win_l0=0),                                        # every level windowed
+    dict(fwd_win_l0=2),                                        # levels 0-1 through the L1 (8 global points per row)
+    dict(fwd_win_l0=3),
+    dict(fwd_win_l0=4),                                        # no window at all
+    dict(fwd_win_margins=0x0000),                              # windows barely cover the region: most points fall out
+    dict(fwd_win_margins=0x1111),
+    dict(fwd_win_margins=0x5432),
+    dict(fwd_win_margins=0x7777, fwd_win_rlog=4),
+    dict(fwd_win_rlog=5, fwd_win_block=512, fwd_win_margins=0x2222),
+]
+
+
+@pytest.mark.parametrize("cfg", CONFIGS, ids=lambda c: ",".join(f"{k[8:]}={v:x}" for k, v in c.items()) or "default")
+@pytest.mark.parametrize("dist", ["encoder_like", "uniform"])
+def test_win_forward_is_independent_of_its_tiling_options(msda, hip_lib, cfg, dist):
+    from memotr_amd.synth import make_inputs
+    for k, v in cfg.items():
+        hip_lib.set_option(k, v)
+    x = make_inputs(height=400, width=667, batch=2, dist=dist, device="cuda", seed=21)
+    x["loc"] = (x["loc"] + 0.002 * torch.randn_like(x["loc"])).contiguous()     # the two frames differ
+    got = _hip_fwd(msda, x)
+    assert "msda_fwd_d32_win" in hip_lib.last_kernel(), hip_lib.last_kernel()
+    np.testing.assert_allclose(got, _oracle_fwd(_cpu(x)), rtol=1e-4, atol=2e-5)
+
+
+def test_win_forward_clip_batch_of_five(msda, hip_lib):
+    from memotr_amd.synth import make_inputs
+    x = make_inputs(height=400, width=667, batch=5, dist="encoder_like", device="cuda", seed=22)
+    x["value"] = torch.randn_like(x["value"])
+    x["loc"] = (x["loc"] + 0.003 * torch.randn_like(x["loc"])).contiguous()
+    got = _hip_fwd(msda, x)
+    assert "msda_fwd_d32_win" in hip_lib.last_kernel()
+    np.testing.assert_allclose(got, _oracle_fwd(_cpu(x)), rtol=1e-4, atol=2e-5)
+
+
+def test_win_forward_large_offsets(msda, hip_lib):
+    """Trained models sample far from the reference point: 8 and 16 pixel jitter (most points leave their windows)."""
+    from memotr_amd.synth import make_inputs
+    for jitter in (4.0, 8.0, 16.0):
+        x = make_inputs(height=320, width=448, dist="encoder_like", jitter=jitter, device="cuda", seed=5)
+        got = _hip_fwd(msda, x)
+        assert "msda_fwd_d32_win" in hip_lib.last_kernel()
+        np.testing.assert_allclose(got, _oracle_fwd(_cpu(x)), rtol=1e-4, atol=2e-5, err_msg=f"jitter {jitter}")
+
+
+def test_win_forward_propagates_non_finite_values_like_the_oracle(msda, hip_lib):
+    from memotr_amd.synth import make_inputs
+    x = make_inputs(height=256, width=352, dist="encoder_like", device="cuda", seed=9)
+    v = x["value"]
+    S = v.shape[1]
+    g = torch.Generator().manual_seed(4)
+    idx = torch.randint(0, S, (40,), generator=g)
+    v[0, idx[:20], 3, 5] = float("nan")
+    v[0, idx[20:30], 1, :] = float("inf")
+    v[0, idx[30:], 6, 17] = float("-inf")
+    got = _hip_fwd(msda, x)
+    want = _oracle_fwd(_cpu(x))
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.array_equal(np.isposinf(got), np.isposinf(want)) and np.array_equal(np.isneginf(got), np.isneginf(want))
+    fin = np.isfinite(want)
+    np.testing.assert_allclose(got[fin], want[fin], rtol=1e-4, atol=2e-5)
+
+
+# ----------------------------------------------------------------------------- fused prologue entry
+def _run_fused_fwd(msda, c):
+    from memotr_amd.MultiScaleDeformableAttention import tag_host_shapes
+    d = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in c.items()}
+    tag_host_shapes(d["shapes"], c["shapes_list"])
+    out = msda.ms_deform_attn_fused_forward(d["value"], d["shapes"], d["level_start"], d["proj"], d["ref"], d["mask"],
+                                            c["M"], c["P"])
+    return out.cpu().numpy()
+
+
+FUSED_PYRAMIDS = [
+    # (seed, N, M, P, shapes, ref_dim)
+    (11, 2, 8, 4, [(20, 28), (10, 14), (5, 7), (3, 4)], 2),
+    (12, 1, 8, 4, [(20, 28), (10, 14), (5, 7), (3, 4)], 4),
+    (13, 2, 3, 2, [(13, 9), (7, 5), (4, 3)], 2),                 # L = 3, M = 3, partial regions
+    (14, 1, 8, 4, [(6, 8), (3, 4)], 2),                          # L = 2
+    (15, 1, 8, 3, [(17, 23), (9, 12), (5, 6), (3, 3)], 2),       # LP = 12, non-halving pyramid
+    (16, 1, 8, 4, [(50, 84), (25, 42), (13, 21), (7, 11)], 2),
+    (17, 1, 5, 1, [(9, 9), (5, 5), (3, 3), (2, 2)], 2),          # one point per level
+]
+
+
+@pytest.mark.parametrize("case", FUSED_PYRAMIDS, ids=lambda c: f"seed{c[0]}")
+@pytest.mark.parametrize("cfg", [dict(), dict(fwd_win_dma=0, fwd_win_rlog=4), dict(fwd_win_l0=0),
+                                 dict(fwd_win_margins=0x1111, fwd_win_block=512)],
+                         ids=["default", "nodma_r4", "all_levels", "m1_b512"])
+def test_win_fused_forward_matches_checker(msda, hip_lib, case, cfg):
+    seed, N, M, P, shapes, ref_dim = case
+    for k, v in cfg.items():
+        hip_lib.set_option(k, v)
+    c = make_case(seed, N, M, 32, len(shapes), P, shapes, ref_dim=ref_dim, pyramid=True, off_px=2.5)
+    got = _run_fused_fwd(msda, c)
+    assert "msda_fwd_d32_win<fused" in hip_lib.last_kernel(), hip_lib.last_kernel()
+    np.testing.assert_allclose(got, expected(c)["out"], rtol=1e-4, atol=4e-5)
+
+
+def test_win_fused_forward_full_size_with_the_padding_mask(msda, hip_lib):
+    """The model's encoder call: 800x1333 frame, the mask of its 1344-wide padding, reference points per level."""
+    shapes = [(100, 168), (50, 84), (25, 42), (13, 21)]
+    c = make_case(3, 1, 8, 32, 4, 4, shapes, ref_dim=2, pyramid=True, off_px=3.0, with_mask=False)
+    mask = torch.zeros(1, sum(h * w for h, w in shapes), dtype=torch.bool)
+    start = 0
+    for (h, w), valid_w in zip(shapes, (167, 84, 42, 21)):
+        m = torch.zeros(h, w, dtype=torch.bool)
+        m[:, valid_w:] = True
+        mask[0, start:start + h * w] = m.reshape(-1)
+        start += h * w
+    c["mask"] = mask
+    got = _run_fused_fwd(msda, c)
+    assert "msda_fwd_d32_win<fused" in hip_lib.last_kernel()
+    np.testing.assert_allclose(got, expected(c)["out"], rtol=1e-4, atol=4e-5)

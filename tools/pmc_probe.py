@@ -1,21 +1,28 @@
 #!/usr/bin/env python
-"""Launch one MSDeformAttn kernel variant a few times (encoder shape, fused-prologue entry points -- what the model
-issues) -- the target of tools/pmc_probe.sh.   usage: pmc_probe.py fwd|bwd <variant> [margin]"""
+"""Launch one MSDeformAttn kernel configuration a few times (encoder shape; fused-prologue entry points -- what the
+model issues -- unless `plain` is given) -- the target of tools/pmc_probe.sh.
+
+    pmc_probe.py fwd|bwd [plain] [uniform] key=value ...      e.g.  pmc_probe.py fwd fwd_variant=12 fwd_win_rlog=4
+"""
 import os
 import sys
 
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from bench import FusedCall  # noqa: E402
+from bench import FusedCall, MsdaCall  # noqa: E402
 from memotr_amd import _lib  # noqa: E402
 from memotr_amd.synth import make_inputs  # noqa: E402
 
-op, variant = sys.argv[1], int(sys.argv[2])
-margin = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-call = FusedCall(make_inputs(dist="encoder_like", device="cuda"))
-_lib.set_option(f"{op}_variant", variant)
-_lib.set_option(f"{op}_tile_margin", margin)
+op = sys.argv[1]
+words = sys.argv[2:]
+dist = "uniform" if "uniform" in words else "encoder_like"
+x = make_inputs(dist=dist, device="cuda")
+call = MsdaCall(x) if "plain" in words else FusedCall(x)
+for w in words:
+    if "=" in w:
+        k, v = w.split("=")
+        _lib.set_option(k, int(v, 0))
 fn = call.fwd if op == "fwd" else call.bwd
 for _ in range(6):
     fn()

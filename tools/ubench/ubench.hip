@@ -63,6 +63,42 @@ __global__ __launch_bounds__(256) void k_lds_read(float* out, int iters) {
     if (acc.x + acc.y + acc.z + acc.w == 12345.f) out[0] = 1;
 }
 
+// Pair reads: the 16 lanes that own a (query, head) row read the two horizontally adjacent pixels of a bilinear
+// sample = 256 contiguous bytes at a random 128-byte-aligned LDS address.
+//   MODE 0: a row = 16 consecutive lanes
+//   MODE 1: a row = one of the four 16-lane groups the LDS services a ds_read_b128 in
+//           ({0-3,12-15,20-27}, {4-11,16-19,28-31}, {32-35,44-47,52-59}, {36-43,48-51,60-63}) -> conflict free
+template <int MODE>
+__global__ __launch_bounds__(256) void k_lds_pair(float* out, int iters) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < 8192 + 32; i += 256) lds[i] = (float)i;      // 257 pixels of 128 B
+    __syncthreads();
+    const f4* lds4 = reinterpret_cast<const f4*>(lds);
+    int row, chunk;                    // chunk 0..15 of the 256-byte pair
+    if (MODE == 0) { row = lane >> 4; chunk = lane & 15; }
+    else {
+        const int j = lane & 15, odd = (lane >> 4) & 1, jq = j >> 2;
+        const bool inner = jq == 1 || jq == 2;
+        row = ((lane >> 5) << 1) + ((inner == (odd != 0)) ? 0 : 1);
+        const int half = j >> 3;
+        chunk = half * 8 + (half ? 3 - (j & 3) : (j & 3)) + 4 * odd;
+    }
+    unsigned idx[8];
+    unsigned x = (unsigned)((tid >> 6) * 4 + row) * 2654435761u + blockIdx.x * 977u;   // same for the lanes of a row
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { x = x * 1664525u + 1013904223u; idx[j] = ((x >> 8) & 255u) * 8 + chunk; }
+    f4 acc = {0, 0, 0, 0};
+    for (int it = 0; it < iters; it += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            acc += lds4[idx[j]];
+            idx[j] = ((idx[j] + 8 * 37) & 2047) ;
+        }
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 12345.f) out[0] = 1;
+}
+
 __global__ __launch_bounds__(256) void k_gatomic(float* buf, unsigned n_rows, int iters, int mode) {
     const int tid = threadIdx.x, lane = tid & 63, grp = lane >> 3, sub = lane & 7;
     unsigned x = (blockIdx.x * 256 + tid) * 2654435761u;
@@ -165,6 +201,14 @@ int main() {
         float ms = time_ms([&] { hipLaunchKernelGGL(k_lds_read, dim3(blocks), dim3(256), 16384, 0, out, iters); });
         double bytes = (double)blocks * 256 * iters * 16;
         printf("lds_read_b128 rows: %.3f ms  %.1f TB/s  (%.1f B/clk/CU)\n", ms, bytes / ms / 1e9, bytes / ms / 1e6 / 256 / 2.4);
+    }
+    for (int mode = 0; mode < 2; ++mode) {
+        const int iters = 4096;
+        float ms = mode == 0 ? time_ms([&] { hipLaunchKernelGGL(k_lds_pair<0>, dim3(blocks), dim3(256), 33024, 0, out, iters); })
+                             : time_ms([&] { hipLaunchKernelGGL(k_lds_pair<1>, dim3(blocks), dim3(256), 33024, 0, out, iters); });
+        double bytes = (double)blocks * 256 * iters * 16;
+        printf("lds_read_b128 pixel pairs, %s: %.3f ms  %.1f TB/s  (%.1f B/clk/CU)\n",
+               mode == 0 ? "16 consecutive lanes per row" : "LDS service groups as rows  ", ms, bytes / ms / 1e9, bytes / ms / 1e6 / 256 / 2.4);
     }
     printf("== global atomic add f32 ==\n");
     const unsigned n_rows = 22323 * 8;  // 22.9 MB like value
