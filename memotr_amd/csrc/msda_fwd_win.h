@@ -20,7 +20,8 @@
 //     ds_read_b128 covers 256 contiguous bytes per row, and the lane -> (row, chunk) map follows the four 16-lane
 //     groups the LDS services a b128 read in, so the read is bank-conflict free (256 B/clk/CU instead of ~110 for
 //     independent 128-B rows);
-//   * one lane stages one (row, point) record: [addr_top, addr_bot, w_top, w_bot] per half, LDS byte addresses for
+//   * one lane stages one (row, point) record: [w_top, addr_top, w_bot, addr_bot] per half (each weight in the low
+//     register of an aligned pair: v_pk_fma broadcasts it without a move), LDS byte addresses for
 //     points inside their window, `value` byte offsets (out of range = zero padding) otherwise; a point outside
 //     its window takes the global path, so results never depend on the window placement -- only the speed does.
 #pragma once
@@ -40,7 +41,7 @@ struct WinPlan {
     int row0[kWinMaxL + 1];        // first region-row of level l
     int ww[kWinMaxL], wh[kWinMaxL];  // window width / height in pixels (0: no window)
     int wmagic[kWinMaxL];          // (x * magic) >> 16 == x / ww for x < ww * wh
-    int wbase[kWinMaxL + 1];       // first window pixel of level l (multiples of 8); [kWinMaxL] = the zero row
+    int wbase[kWinMaxL + 1];       // first window pixel of level l; [kWinMaxL] = all window pixels = the zero row
     float ratw[kWinMaxL][kWinMaxL], rath[kWinMaxL][kWinMaxL];   // [lq][l] = W_l / W_lq, H_l / H_lq
     int groups;                    // 8-pixel fill groups (window pixels + the zero row, rounded up)
     float rcpH[kWinMaxL], rcpW[kWinMaxL], rcpP;   // correctly rounded 1/H, 1/W, 1/P (div_small)
@@ -115,18 +116,22 @@ __device__ __forceinline__ WinRaw win_load_raw(const PointSrc &src, unsigned qro
     return w;
 }
 
-// x / d for a small positive integer d held as a float, with rd = RN(1 / d) from the host: q0 = x * rd,
+// (x / dx, y / dy) for small positive integers dx, dy held as floats, with rdx = RN(1 / dx) from the host: q0 = x * rd,
 // q = fma(fma(-d, q0, x), rd, q0) is the correctly rounded quotient (Markstein) whenever nothing under- or overflows;
-// outside that range (and for zeros, whose sign the correction loses) the IEEE division runs.  Same bits as x / d.
-__device__ __forceinline__ float div_small(float x, float d, float rd) {
+// outside that range (and for zeros, whose sign the correction loses) the IEEE divisions run.  Same bits as x / d.
+__device__ __forceinline__ f32x2 div_small2(f32x2 v, float dx, float rdx, float dy, float rdy) {
 #pragma clang fp contract(off)
-    const float ax = fabsf(x);
-    if (ax >= 0x1p-40f && ax <= 0x1p40f) {
-        const float q0 = x * rd;
-        const float r = __builtin_fmaf(-d, q0, x);
-        return __builtin_fmaf(r, rd, q0);
+    const float ax = fabsf(v.x), ay = fabsf(v.y);
+    f32x2 q;
+    if (fminf(ax, ay) >= 0x1p-40f && fmaxf(ax, ay) <= 0x1p40f) {
+        const float qx = v.x * rdx, qy = v.y * rdy;
+        q.x = __builtin_fmaf(__builtin_fmaf(-dx, qx, v.x), rdx, qx);
+        q.y = __builtin_fmaf(__builtin_fmaf(-dy, qy, v.y), rdy, qy);
+    } else {
+        q.x = v.x / dx;
+        q.y = v.y / dy;
     }
-    return x / d;
+    return q;
 }
 
 // sampling location from the raw inputs; the fused form repeats fused_location()'s IEEE operation order
@@ -137,12 +142,12 @@ __device__ __forceinline__ f32x2 win_location(const WinRaw &w, int ref_dim, floa
     if (!FUSED) return w.a;
     f32x2 xy;
     if (ref_dim == 2) {
-        const float dx = div_small(w.a.x, fW, rW), dy = div_small(w.a.y, fH, rH);
-        xy.x = w.r.x + dx;
-        xy.y = w.r.y + dy;
+        const f32x2 d = div_small2(w.a, fW, rW, fH, rH);
+        xy.x = w.r.x + d.x;
+        xy.y = w.r.y + d.y;
     } else {
-        const float px = div_small(w.a.x, fP, rP), py = div_small(w.a.y, fP, rP);
-        const float qx = px * w.r.z, qy = py * w.r.w;
+        const f32x2 p = div_small2(w.a, fP, rP, fP, rP);
+        const float qx = p.x * w.r.z, qy = p.y * w.r.w;
         const float hx = qx * 0.5f, hy = qy * 0.5f;
         xy.x = w.r.x + hx;
         xy.y = w.r.y + hy;
@@ -166,19 +171,19 @@ __device__ __forceinline__ float row16_sum(float x) {
     return x;
 }
 
-// One point whose record may be an LDS address (inside its window) or a `value` byte offset (bit 0 of word 0 set),
+// One point whose record may be an LDS address (inside its window) or a `value` byte offset (bit 0 of word 1 set),
 // lane by lane: loads and FMAs in one place.
 __device__ __forceinline__ f32x4 win_mixed_point(const u32x4 r, const unsigned char *s_dyn, unsigned zero_off,
                                                  __amdgpu_buffer_rsrc_t vr, unsigned sub16, f32x4 acc) {
-    const bool g = (r.x & 1u) != 0u;
-    f32x4 v0 = *reinterpret_cast<const f32x4 *>(s_dyn + ((g ? zero_off : r.x) + sub16));
-    f32x4 v1 = *reinterpret_cast<const f32x4 *>(s_dyn + ((g ? zero_off : r.y) + sub16));
+    const bool g = (r.y & 1u) != 0u;
+    f32x4 v0 = *reinterpret_cast<const f32x4 *>(s_dyn + ((g ? zero_off : r.y) + sub16));
+    f32x4 v1 = *reinterpret_cast<const f32x4 *>(s_dyn + ((g ? zero_off : r.w) + sub16));
     if (g) {
-        v0 = buf_load_f4(vr, (r.x & ~1u) + sub16);
-        v1 = buf_load_f4(vr, r.y + sub16);
+        v0 = buf_load_f4(vr, (r.y & ~1u) + sub16);
+        v1 = buf_load_f4(vr, r.w + sub16);
     }
-    acc += __uint_as_float(r.z) * v0;
-    acc += __uint_as_float(r.w) * v1;
+    acc += __uint_as_float(r.x) * v0;
+    acc += __uint_as_float(r.z) * v1;
     return acc;
 }
 
@@ -329,7 +334,9 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
         __syncthreads();
 
         // ---- fill the windows: 8 pixels (1 KiB) per wave instruction; cells outside the level / padded read 0.
-        //      Every level's window starts on a group boundary, so the level is uniform per instruction ----
+        //      Every level's window starts on a group boundary, so the level is uniform per instruction.  (One
+        //      instruction per window ROW needs a third of the address arithmetic but 40 % more, partly filled,
+        //      DMA instructions: measured slower, 16.6 vs 14.7 us for the start-up phase alone) ----
         const unsigned char *mk = (FUSED && src.mask != nullptr) ? src.mask + (size_t)b * pl.S : nullptr;
         for (int l = lwin0; l <= L; ++l) {        // l == L: the group that holds the zero row
             const int g0 = tb.wbase[l < L ? l : kWinMaxL] >> 3;
@@ -403,28 +410,27 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
                 h_im = ph - 0.5f;
                 w_im = pw - 0.5f;
             }
-            const bool gate = (h_im > -1.f) & (w_im > -1.f) & (h_im < fH) & (w_im < fW);
+            const bool gate = h_im > -1.f && w_im > -1.f && h_im < fH && w_im < fW;
             const float fh = floorf(h_im), fw = floorf(w_im);
             const int h0 = (int)fh, w0 = (int)fw;
-            const bool live = gate & row_ok & c_pt;
+            const bool live = gate && row_ok && c_pt;
             const float lh = gate ? h_im - fh : 0.f, lw = gate ? w_im - fw : 0.f;
             const float a = live ? a_in : 0.f;
             const float hh = 1.f - lh, hw = 1.f - lw;
             u32x4 ra, rb;
-            ra.z = __float_as_uint((hh * hw) * a);
-            ra.w = __float_as_uint((lh * hw) * a);
-            rb.z = __float_as_uint((hh * lw) * a);
-            rb.w = __float_as_uint((lh * lw) * a);
+            ra.x = __float_as_uint((hh * hw) * a);
+            ra.z = __float_as_uint((lh * hw) * a);
+            rb.x = __float_as_uint((hh * lw) * a);
+            rb.z = __float_as_uint((lh * lw) * a);
             // inside its window: LDS byte addresses (the window holds zeros outside the level / on padded pixels)
             const int wx = w0 - c_ox, wy = h0 - c_oy;
-            const bool inwin = live & ((unsigned)wx < c_wwm1) & ((unsigned)wy < c_whm1);
+            const bool inwin = live && (unsigned)wx < c_wwm1 && (unsigned)wy < c_whm1;
             const unsigned lbase = c_wbase + (unsigned)(wy * c_ww + wx) * 128u;
             // otherwise: byte offsets into `value`, out of range for corners that do not exist
-            const bool need = live & !inwin;
-            bool ok00 = need & ((unsigned)h0 < (unsigned)cH) & ((unsigned)w0 < (unsigned)cW);
-            bool ok01 = need & ((unsigned)h0 < (unsigned)cH) & ((unsigned)(w0 + 1) < (unsigned)cW);
-            bool ok10 = need & ((unsigned)(h0 + 1) < (unsigned)cH) & ((unsigned)w0 < (unsigned)cW);
-            bool ok11 = need & ((unsigned)(h0 + 1) < (unsigned)cH) & ((unsigned)(w0 + 1) < (unsigned)cW);
+            const bool need = live && !inwin;
+            const bool okh0 = (unsigned)h0 < (unsigned)cH, okh1 = (unsigned)(h0 + 1) < (unsigned)cH;
+            const bool okw0 = (unsigned)w0 < (unsigned)cW, okw1 = (unsigned)(w0 + 1) < (unsigned)cW;
+            bool ok00 = okh0 && okw0, ok01 = okh0 && okw1, ok10 = okh1 && okw0, ok11 = okh1 && okw1;
             const int cell = h0 * cW + w0;
             if (FUSED && c_mask != nullptr && need) {
                 ok00 = ok00 && !c_mask[ok00 ? cell : 0];
@@ -433,15 +439,15 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
                 ok11 = ok11 && !c_mask[ok11 ? cell + cW + 1 : 0];
             }
             const unsigned o00 = c_lbase + (unsigned)cell * pix_stride;
-            ra.x = inwin ? lbase : (need ? (ok00 ? o00 : kOobOffset) | c_flag : c_dead);
-            ra.y = inwin ? lbase + c_wrow : (need ? (ok10 ? o00 + c_wps : kOobOffset) : c_dead);
-            rb.x = inwin ? lbase + 128u : (need ? (ok01 ? o00 + pix_stride : kOobOffset) | c_flag : c_dead);
-            rb.y = inwin ? lbase + c_wrow + 128u : (need ? (ok11 ? o00 + c_wps + pix_stride : kOobOffset) : c_dead);
+            ra.y = inwin ? lbase : (need ? (ok00 ? o00 : kOobOffset) | c_flag : c_dead);
+            ra.w = inwin ? lbase + c_wrow : (need ? (ok10 ? o00 + c_wps : kOobOffset) : c_dead);
+            rb.y = inwin ? lbase + 128u : (need ? (ok01 ? o00 + pix_stride : kOobOffset) | c_flag : c_dead);
+            rb.w = inwin ? lbase + c_wrow + 128u : (need ? (ok11 ? o00 + c_wps + pix_stride : kOobOffset) : c_dead);
             if (c_pt) {
                 rec_w[2 * lane] = ra;
                 rec_w[2 * lane + 1] = rb;
             }
-            const unsigned long long bal = __builtin_amdgcn_ballot_w64(need & c_windowed);
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(need && c_windowed);
             const unsigned fold = (unsigned)(bal | (bal >> 32));
             gmask = (fold | (fold >> 16)) & 0xffffu;
         }
@@ -464,8 +470,8 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
             for (int i = 0; i < 4; ++i) gr[i] = rec_g[2 * i];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                gv[i][0] = buf_load_f4(vr, gr[i].x + sub16);
-                gv[i][1] = buf_load_f4(vr, gr[i].y + sub16);
+                gv[i][0] = buf_load_f4(vr, gr[i].y + sub16);
+                gv[i][1] = buf_load_f4(vr, gr[i].w + sub16);
             }
         }
         if (it == 0 && lwin0 < L) {            // the windows must have landed before the first LDS-served point
@@ -487,26 +493,35 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
                     for (int i = 0; i < 4; ++i) r[i] = rp[2 * i];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        v[i][0] = *reinterpret_cast<const f32x4 *>(s_dyn + (r[i].x + sub16));
-                        v[i][1] = *reinterpret_cast<const f32x4 *>(s_dyn + (r[i].y + sub16));
+                        v[i][0] = *reinterpret_cast<const f32x4 *>(s_dyn + (r[i].y + sub16));
+                        v[i][1] = *reinterpret_cast<const f32x4 *>(s_dyn + (r[i].w + sub16));
                     }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        acc += __uint_as_float(r[i].z) * v[i][0];
-                        acc += __uint_as_float(r[i].w) * v[i][1];
+                        acc += __uint_as_float(r[i].x) * v[i][0];
+                        acc += __uint_as_float(r[i].z) * v[i][1];
                     }
                 } else {
+                    // some row's point left its window: those lanes read `value` itself, the others their window;
+                    // all eight rows of the batch are requested before the first is used
+                    u32x4 r[4];
+                    f32x4 v[4][2];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) r[i] = rp[2 * i];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const u32x4 r = rp[2 * i];
-                        if ((gmask >> (t0 + i)) & 1u) {
-                            acc = win_mixed_point(r, s_dyn, zero_off, vr, sub16, acc);
-                        } else {
-                            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(s_dyn + (r.x + sub16));
-                            const f32x4 v1 = *reinterpret_cast<const f32x4 *>(s_dyn + (r.y + sub16));
-                            acc += __uint_as_float(r.z) * v0;
-                            acc += __uint_as_float(r.w) * v1;
+                        const bool g = (r[i].y & 1u) != 0u;
+                        v[i][0] = *reinterpret_cast<const f32x4 *>(s_dyn + ((g ? zero_off : r[i].y) + sub16));
+                        v[i][1] = *reinterpret_cast<const f32x4 *>(s_dyn + ((g ? zero_off : r[i].w) + sub16));
+                        if (g) {
+                            v[i][0] = buf_load_f4(vr, (r[i].y & ~1u) + sub16);
+                            v[i][1] = buf_load_f4(vr, r[i].w + sub16);
                         }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        acc += __uint_as_float(r[i].x) * v[i][0];
+                        acc += __uint_as_float(r[i].z) * v[i][1];
                     }
                 }
             }
@@ -515,8 +530,8 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
             if (early) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    acc += __uint_as_float(gr[i].z) * gv[i][0];
-                    acc += __uint_as_float(gr[i].w) * gv[i][1];
+                    acc += __uint_as_float(gr[i].x) * gv[i][0];
+                    acc += __uint_as_float(gr[i].z) * gv[i][1];
                 }
             }
             int tg = early ? 4 : 0;
@@ -527,20 +542,20 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
                 for (int i = 0; i < 4; ++i) r[i] = rec_g[2 * (tg + i)];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    v[i][0] = buf_load_f4(vr, r[i].x + sub16);
-                    v[i][1] = buf_load_f4(vr, r[i].y + sub16);
+                    v[i][0] = buf_load_f4(vr, r[i].y + sub16);
+                    v[i][1] = buf_load_f4(vr, r[i].w + sub16);
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    acc += __uint_as_float(r[i].z) * v[i][0];
-                    acc += __uint_as_float(r[i].w) * v[i][1];
+                    acc += __uint_as_float(r[i].x) * v[i][0];
+                    acc += __uint_as_float(r[i].z) * v[i][1];
                 }
             }
             for (; tg < T0; ++tg) {
                 const u32x4 r = rec_g[2 * tg];
-                const f32x4 v0 = buf_load_f4(vr, r.x + sub16), v1 = buf_load_f4(vr, r.y + sub16);
-                acc += __uint_as_float(r.z) * v0;
-                acc += __uint_as_float(r.w) * v1;
+                const f32x4 v0 = buf_load_f4(vr, r.y + sub16), v1 = buf_load_f4(vr, r.w + sub16);
+                acc += __uint_as_float(r.x) * v0;
+                acc += __uint_as_float(r.z) * v1;
             }
             // -- the two pixel halves of a row sit on row_mirror partners --
             // (scalars: __builtin_bit_cast of a vector ELEMENT reads element 0 with this compiler)

@@ -1960,7 +1960,8 @@ std::atomic<int> opt_bwd_wide_log2{12};   // tiled backward: row-magnitude range
 std::atomic<int> opt_bwd_ablate{0};
 std::atomic<int> opt_fwd_head_major{0};    // gather forward: head-major task walk (one head per XCD)
 std::atomic<int> opt_fwd_win_rlog{3};       // windowed forward: log2 of the region height on level 0
-std::atomic<int> opt_fwd_win_rlogx{4};      // log2 of the region width (at least the height)
+std::atomic<int> opt_fwd_win_rlogx{3};      // log2 of the region width (at least the height)
+std::atomic<int> opt_fwd_win_auto{1};       // 0: never pick the windowed forward on its own
 std::atomic<int> opt_fwd_win_block{256};    // threads per workgroup (256 / 512)
 std::atomic<int> opt_fwd_win_l0{1};         // first level served from an LDS window
 std::atomic<int> opt_fwd_win_margins{0x3333};  // window margin per level, 4 bits each (level 0 in the low nibble)
@@ -2118,7 +2119,13 @@ int forward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart, 
     const long value_bytes = value_elems * (long)sizeof(TV);
     constexpr bool kD32Type = sizeof(TC) == 4 && (sizeof(TV) == 4 || sizeof(TV) == 2);
     const bool can32 = kD32Type && d32_ok(D, L, value_elems);
-    if (variant == 0) variant = can32 ? 3 : 1;  // 4 points (16 rows) in flight: best of the sweep in profiles/
+    if (variant == 0) {
+        // self-attention over the pyramid (one query per pixel): coarse levels from per-head LDS windows; every
+        // other D = 32 call: direct gather with 4 points (16 rows) in flight -- best of the sweeps in profiles/
+        const bool pyramid = can32 && sizeof(TV) == 4 && shapes_host != nullptr && Lq == S && L <= kWinMaxL &&
+                             L * P <= 16 && opt_fwd_win_auto.load() != 0;
+        variant = pyramid ? 12 : (can32 ? 3 : 1);
+    }
     if (variant >= 2 && !can32) variant = 1;
     if (variant == 1) {
         const long total = (long)N * Lq * M * D;
@@ -2608,6 +2615,7 @@ static std::atomic<int> *find_opt(const char *key) {
     if (!strcmp(key, "bwd_split")) return &opt_bwd_split;
     if (!strcmp(key, "fwd_win_rlog")) return &opt_fwd_win_rlog;
     if (!strcmp(key, "fwd_win_rlogx")) return &opt_fwd_win_rlogx;
+    if (!strcmp(key, "fwd_win_auto")) return &opt_fwd_win_auto;
     if (!strcmp(key, "fwd_head_major")) return &opt_fwd_head_major;
     if (!strcmp(key, "fwd_win_block")) return &opt_fwd_win_block;
     if (!strcmp(key, "fwd_win_l0")) return &opt_fwd_win_l0;

@@ -19,7 +19,7 @@ from fused_helpers import expected, make_case
 
 pytestmark = pytest.mark.gpu
 
-WIN_DEFAULTS = dict(fwd_win_rlog=3, fwd_win_rlogx=4, fwd_win_block=256, fwd_win_l0=1, fwd_win_margins=0x3333, fwd_win_dma=1)
+WIN_DEFAULTS = dict(fwd_win_rlog=3, fwd_win_rlogx=3, fwd_win_block=256, fwd_win_l0=1, fwd_win_margins=0x3333, fwd_win_dma=1)
 
 
 @pytest.fixture(scope="module")
@@ -73,9 +73,9 @@ def test_win_forward_full_size_matches_oracle(msda, hip_lib, pyr, dist):
 
 
 CONFIGS = [
-    dict(),                                                    # defaults: 16 x 8 pixel regions, windows on levels 1-3
+    dict(),                                                    # defaults: 8 x 8 pixel regions, windows on levels 1-3
     dict(fwd_win_dma=0),                                       # fill through registers
-    dict(fwd_win_rlogx=3),                                     # square 8-pixel regions (85 rows per workgroup)
+    dict(fwd_win_rlogx=4),                                     # 16 x 8 pixel regions (170 rows per workgroup)
     dict(fwd_win_rlog=4),                                      # 16-pixel regions (340 rows per workgroup)
     dict(fwd_win_rlogx=5, fwd_win_margins=0x2222),             # 32 x 8 regions
     dict(fwd_win_rlog=4, fwd_win_block=512),

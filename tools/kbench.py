@@ -23,8 +23,9 @@ from memotr_amd.synth import make_inputs  # noqa: E402
 def reset():
     for k, v in (("fwd_variant", 0), ("bwd_variant", 0), ("fwd_tile_margin", 3), ("bwd_tile_margin", 3),
                  ("fwd_tile_l0", 1), ("fwd_block", 256), ("fwd_grid_mult", 32), ("bwd_split", 1),
-                 ("fwd_win_rlog", 3), ("fwd_win_rlogx", 4), ("fwd_win_block", 256), ("fwd_win_l0", 1), ("fwd_win_margins", 0x3333),
-                 ("fwd_win_dma", 1), ("fwd_head_major", 0)):
+                 ("fwd_win_rlog", 3), ("fwd_win_rlogx", 3), ("fwd_win_block", 256), ("fwd_win_l0", 1), ("fwd_win_margins", 0x3333),
+                 ("fwd_win_dma", 1), ("fwd_head_major", 0), ("fwd_win_early", 2), ("fwd_win_wps", 0),
+                 ("fwd_win_ablate", 0)):
         _lib.set_option(k, v)
 
 
