@@ -9,6 +9,9 @@ Prints ONE JSON line on rank 0 (contract in the task description).  Workloads:
          6 encoder calls (Lq = S = 22323) + 6 decoder calls (Lq = 300 + n_track), forward and
          backward, fp32, inputs resident in HBM.  value = frames/s of that path.
   train  (default) one step = one clip train step of train_dancetrack.yaml (clip of 5 frames, 800x1333).
+  infer  one step = one video frame through the online tracker (the frame loop of the reference's
+         submit_engine.py:58-120: model forward under no_grad -> RuntimeTracker -> query updater), 800x1333,
+         ~n-track live tracks.  value = frames/s.
 
 Every rank works on its own synthetic frame (clips shard by rank; no data-path collective), so
 scaling is "weak".  The JSON carries
@@ -324,6 +327,68 @@ def run_msda(args, rank, world):
     return result
 
 
+def run_infer(args, rank, world):
+    """Online tracking throughput: SequenceTracker.step on random 800x1333 frames resident in HBM.  Random-init weights
+    score every detection ~0.01, so the birth threshold is set from the first frame's scores to start `n_track`
+    tracks, after which no track is born or retired (thresholds 1 / 0): the decoder runs with 300 + n_track queries
+    and the query updater with n_track tracks on every timed frame."""
+    from memotr_amd import configs as C
+    from memotr_amd.inference import SequenceTracker
+    from memotr_amd.models import build_model
+    from memotr_amd.models.utils import logits_to_scores
+    from memotr_amd.utils.utils import set_seed
+    dev = torch.device("cuda", torch.cuda.current_device())
+    cfg = {"dancetrack": C.dancetrack_config, "mot17": C.mot17_config, "bdd100k": C.bdd100k_config}[args.config]()
+    hw = (720, 1280) if args.config == "bdd100k" else (800, 1333)
+    torch.backends.cuda.matmul.allow_tf32 = False
+    torch.backends.cudnn.allow_tf32 = False
+    set_seed(cfg["SEED"] + rank)
+    model = build_model(dict(cfg, DEVICE="cuda", AVAILABLE_GPUS="0")).to(dev).eval()
+    tracker = SequenceTracker.from_config(model, cfg)
+    tracker.result_score_thresh = 0.0
+    g = torch.Generator().manual_seed(cfg["SEED"] + rank)
+    frames = [torch.randn(3, hw[0], hw[1], generator=g).to(dev) for _ in range(4)]
+    # frame 0: find the score of the n_track-th best detection and give birth to exactly those
+    from memotr_amd.utils.nested_tensor import tensor_list_to_nested_tensor
+    with torch.no_grad():
+        res = model(frame=tensor_list_to_nested_tensor([frames[0]]).to(dev), tracks=tracker.tracks)
+        best = logits_to_scores(res["pred_logits"])[0, :len(res["det_query_embed"])].max(-1).values
+    n_track = max(1, min(args.n_track, best.numel()))
+    tracker.tracker.det_score_thresh = float(best.topk(n_track).values[-1])
+    tracker.tracker.track_score_thresh = 0.0
+    tracker.step(frames[0], hw[0], hw[1])
+    tracker.tracker.det_score_thresh = 2.0            # no further births: the live set stays at n_track
+
+    def step(i):
+        return tracker.step(frames[i % len(frames)], hw[0], hw[1])
+
+    for i in range(args.warmup):
+        step(i)
+    barrier(world)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(i)
+    barrier(world)
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    if rank != 0:
+        return None
+    return {
+        "metric": "infer_frames_per_sec", "value": world * args.steps / dt, "unit": "frames/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"online tracking (submit_engine.py frame loop), {cfg['DATASET']} config, "
+                               f"{hw[0]}x{hw[1]} frames, one sequence per GPU, R50 + 6-enc/6-dec, random-init weights",
+                   "live_tracks": int(len(tracker.tracks[0])), "reported_tracks": int(len(out)),
+                   "parallelism": f"dp{world} (sequences shard by rank, no collective)"},
+        "max_memory_MB": torch.cuda.max_memory_allocated() // (1024 ** 2),
+    }
+
+
 def run_msda_kernels_only(args):
     """Roofline numbers for the dominant kernel + a thunk for the CPU baseline (used by the train workload)."""
     from memotr_amd.synth import make_inputs
@@ -354,6 +419,14 @@ def main():
     rank, _, world = init_dist(args.gpus)
     if args.workload == "msda":
         result = run_msda(args, rank, world)
+    elif args.workload == "infer":
+        result = run_infer(args, rank, world)
+        if rank == 0:
+            k = run_msda_kernels_only(args)
+            result["roofline"] = k["roofline"]
+            result["kernels"] = k["kernels"]
+            if world == 1 and not args.no_cpu_baseline:
+                result["cpu_baseline"] = k["cpu_baseline_fn"]()
     elif args.workload == "train":
         from memotr_amd import configs as C
         from memotr_amd.train_bench import run_train

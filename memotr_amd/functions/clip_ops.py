@@ -30,6 +30,13 @@ def _lib():
 
 
 def _stream(t: torch.Tensor) -> int:
+    """Launch stream of ``t``'s device.  The kernels launch on the CURRENT device (one device per process, as under
+    DistributedDataParallel); tensors of another device would get that device's stream handle with the wrong device
+    current, so that case is refused loudly instead of launching somewhere else."""
+    idx = t.device.index
+    if idx is not None and idx != torch.cuda.current_device():
+        raise RuntimeError(f"clip_ops: tensor on cuda:{idx} but cuda:{torch.cuda.current_device()} is current; "
+                           "call torch.cuda.set_device(tensor.device) (one device per process)")
     return torch.cuda.current_stream(t.device).cuda_stream
 
 

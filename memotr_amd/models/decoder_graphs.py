@@ -36,6 +36,17 @@ from .utils import pos_to_pos_embed
 
 BUCKET = 32
 MAX_GRAPHS = 24          # (frame slots x geometries x buckets) kept alive; least recently used go first
+# Multi-scale / random-crop training gives almost every clip its own pyramid: capturing (two warm-up runs + the capture,
+# forward and backward, ~3x an eager decoder pass, plus a private memory pool) per clip would cost more than the graphs
+# save.  After this many consecutive NEW keys without one replay in between the cache stops capturing; replays of
+# what is already captured continue, and a later recurrence of a geometry (`RETRY_AFTER` eager calls) re-arms it.
+MISS_LIMIT = 12
+RETRY_AFTER = 200
+
+
+def require_graphs() -> bool:
+    """MEMOTR_REQUIRE_GRAPHS=1 (set by bench.py): a capture failure is an error, not a silent eager fallback."""
+    return os.environ.get("MEMOTR_REQUIRE_GRAPHS", "0") == "1"
 
 
 class DecoderLoop(nn.Module):
@@ -113,13 +124,21 @@ class DecoderGraphs:
         self.decoder = decoder
         self.slots: "OrderedDict[tuple, object]" = OrderedDict()
         self.failed = False
-        self.captures = 0
+        self.captures = 0        # graphs captured so far
+        self.replays = 0         # decoder loops served from a graph
+        self.eager = 0           # decoder loops that were eligible but ran eagerly (thrash guard / failed capture)
+        self._misses = 0         # consecutive new keys
+        self._paused_at = None   # eager count when the thrash guard tripped
 
     def usable(self, output, src) -> bool:
         d = self.decoder
+        # extra_track_attn: a frame without tracks still carries one masked (padded) track slot in the graphed path,
+        # and attention over keys that are ALL masked is 0 * inf -- its rows are sliced away, but the NaN reaches the
+        # parameter gradients through the norms; those models keep the eager loop
         return (enabled() and not self.failed and output.is_cuda and d.use_dab and d.bbox_embed is not None
                 and not d.use_checkpoint and torch.is_grad_enabled() and src.requires_grad
-                and not torch.is_autocast_enabled() and output.dtype == torch.float32)
+                and not torch.is_autocast_enabled() and output.dtype == torch.float32
+                and not any(getattr(layer, "extra_track_attn", False) for layer in d.layers))
 
     @staticmethod
     def bucket(n_queries: int, n_det: int) -> int:
@@ -130,20 +149,40 @@ class DecoderGraphs:
 
     def run(self, frame_slot: int, args, shapes, lsi, clip_key=None):
         """The decoder loop of frame ``frame_slot`` through its graph (captured on first use); None if capture failed."""
-        key = (frame_slot, tuple(a.shape for a in args), tuple(bool(a.requires_grad) for a in args), id(shapes),
-               clip_ops.config_key())                                  # (a capture bakes the kernel choice in)
+        key = (frame_slot, tuple(a.shape for a in args), tuple(bool(a.requires_grad) for a in args),
+               self._geometry(shapes), clip_ops.config_key())          # (a capture bakes the kernel choice in)
         slot = self.slots.get(key)
         if slot is None:
+            if self._paused_at is not None:
+                if self.eager - self._paused_at < RETRY_AFTER:
+                    self.eager += 1
+                    return None
+                self._paused_at, self._misses = None, 0        # try again: the input sizes may have settled
+            self._misses += 1
+            if self._misses > MISS_LIMIT and not require_graphs():
+                self._paused_at = self.eager       # every clip brings a new geometry: capturing costs more than it saves
+                self.eager += 1
+                return None
             slot = self._capture(args, shapes, lsi)
             if slot is None:
+                self.eager += 1
                 return None
             self.slots[key] = slot
             while len(self.slots) > MAX_GRAPHS:
                 self.slots.popitem(last=False)
         else:
+            self._misses = 0
             self.slots.move_to_end(key)
         fn, params = slot
+        self.replays += 1
         return fn(*args, self._flat_parameters(params, clip_key))
+
+    @staticmethod
+    def _geometry(shapes):
+        """The pyramid as a hashable value ((H, W), ...): the identity of the tensor object is not a key -- an id can
+        be recycled once the geometry cache evicts the tensor."""
+        from ..MultiScaleDeformableAttention import host_shapes
+        return tuple(map(tuple, host_shapes(shapes).tolist()))
 
     def _flat_parameters(self, params, clip_key):
         """All decoder parameters as ONE tensor, made once per clip and read by the graphs of all its frames.
@@ -192,6 +231,9 @@ class DecoderGraphs:
             with _thread_local_capture():
                 fn = torch.cuda.make_graphed_callables(run, sample, num_warmup_iters=2, allow_unused_input=True)
         except Exception as exc:  # noqa: BLE001 -- capture is an optimisation; eager stays valid
+            if require_graphs():
+                raise RuntimeError(f"decoder graph capture failed and MEMOTR_REQUIRE_GRAPHS=1: "
+                                   f"{type(exc).__name__}: {exc}") from exc
             import warnings
             warnings.warn(f"decoder graph capture failed ({type(exc).__name__}: {exc}); running eager")
             self.failed = True

@@ -62,13 +62,16 @@ def self_attention(mha: nn.MultiheadAttention, qk: torch.Tensor, v: torch.Tensor
     d = E // H
     B, L, _ = qk.shape
     w, b = mha.in_proj_weight, mha.in_proj_bias
-    if (torch.is_grad_enabled() and w.requires_grad and not torch.is_autocast_enabled() and qk.dtype == w.dtype
-            and v.dtype == w.dtype):
-        qk_p, v_p = _PackedInProj.apply(qk, v, w, b)
+    if not torch.is_autocast_enabled() and qk.dtype == w.dtype and v.dtype == w.dtype:
+        if torch.is_grad_enabled() and w.requires_grad:
+            qk_p, v_p = _PackedInProj.apply(qk, v, w, b)
+        else:       # inference (torch.no_grad): the same two GEMMs without the autograd node
+            qk_p, v_p = F.linear(qk, w[:2 * E], b[:2 * E]), F.linear(v, w[2 * E:], b[2 * E:])
         from ..functions import clip_ops
         if clip_ops.self_attention_supported(qk_p, H) and not (mha.training and mha.dropout > 0):
             # hand-written kernels (head_dim 32, K / V of a head in LDS) on the packed projections, heads come out
-            # concatenated: no unbind / transposes / copy, and no AOTriton kernels on the path
+            # concatenated: no unbind / transposes / copy, and no AOTriton kernels on the path -- training and
+            # inference alike
             no_pad = key_padding_mask is None or getattr(key_padding_mask, "_no_padding", False)
             out = clip_ops.self_attention(qk_p, v_p, None if no_pad else key_padding_mask, H)
             from .linear import row_linear

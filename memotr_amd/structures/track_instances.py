@@ -83,7 +83,13 @@ class TrackInstances:
         res = self._blank_like()
         for k, v in vars(self).items():
             if hasattr(v, "__getitem__") and v.shape[0] != 0:
-                setattr(res, k, v.index_select(0, item) if rows and torch.is_tensor(v) else v[item])
+                if rows and torch.is_tensor(v):
+                    # index_select wants the index on the field's device (advanced indexing did not: the query
+                    # updater's drop / insert masks are built on the CPU, reference models/query_updater.py:148-150)
+                    idx = item if item.device == v.device else item.to(v.device)
+                    setattr(res, k, v.index_select(0, idx))
+                else:
+                    setattr(res, k, v[item])
             else:
                 setattr(res, k, v)
         return res

@@ -47,6 +47,8 @@ def run_train(args, rank: int, world: int, clip_len: int = None, height: int = 8
     from .models.criterion import build as build_criterion
     from .utils.utils import set_seed
 
+    # a decoder-graph capture that fails is an error in the benchmark, not a silent eager run (models/decoder_graphs.py)
+    os.environ.setdefault("MEMOTR_REQUIRE_GRAPHS", "1")
     clip_len = clip_len or int(os.environ.get("MEMOTR_BENCH_CLIP_LEN", "5"))
     cfg = config or dancetrack_config()
     torch.backends.cuda.matmul.allow_tf32 = False     # main.py:96-97 of the reference: strict fp32
@@ -117,5 +119,10 @@ def run_train(args, rank: int, world: int, clip_len: int = None, height: int = 8
                    "frames_per_gpu_per_sec": clip_len * args.steps / dt, "final_loss": float(loss.detach())},
         "max_memory_MB": torch.cuda.max_memory_allocated() // (1024 ** 2),
         "per_rank_ms_per_step": per_rank, "process_group": backend,
-        "decoder_graphs": getattr(getattr(getattr(model, "module", model).transformer.decoder, "graphs")(), "captures", 0),
+        "decoder_graphs": _graph_stats(model)["captures"], "decoder_graph_stats": _graph_stats(model),
     }
+
+
+def _graph_stats(model) -> dict:
+    g = getattr(model, "module", model).transformer.decoder.graphs()
+    return {"captures": g.captures, "replays": g.replays, "eager": g.eager, "failed": bool(g.failed)}

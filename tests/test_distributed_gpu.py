@@ -82,3 +82,63 @@ def test_two_rank_nccl_replicas_stay_in_sync(tmp_path):
     r0, r1 = _run(2, tmp_path)
     assert r0["world"] == 2 and torch.equal(r0["flat"], r1["flat"]), "replicas diverged"
     assert r0["losses"][0] != r1["losses"][0]
+
+
+# ----------------------------------------------------------------------------- two ranks, ONE device, gloo
+def _worker_shared_device(rank, world, port, out_path):
+    """Both ranks drive cuda:0 and exchange over gloo: every N > 1 code path of the train step (DDP bucket hooks on
+    device tensors with gradient_as_bucket_view, the decoder graphs' flat-parameter cat under the hooks, the
+    ground-truth-count all-reduce, T partial forwards per backward) meets real device tensors without a second GPU."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", MEMOTR_REQUIRE_GRAPHS="1")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from memotr_amd.configs import dancetrack_config
+    from memotr_amd.engine import (build_optimizer, clip_forward_backward, clip_to_device, make_synthetic_clip,
+                                   optimizer_step)
+    from memotr_amd.models import build_model
+    from memotr_amd.models.criterion import build as build_criterion
+    cfg = dancetrack_config(DEVICE="cuda", AVAILABLE_GPUS="0", NUM_ENC_LAYERS=1, NUM_DEC_LAYERS=2, FFN_DIM=256)
+    torch.manual_seed(100 + rank)                    # DDP must broadcast rank 0's weights
+    from memotr_amd.models.memotr import build as build_memotr      # build_model() would pick cuda:<rank>
+    from memotr_amd.modules.linear import configure_blas
+    configure_blas()
+    model = build_memotr(config=cfg).to(dev).train()
+    ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], find_unused_parameters=False,
+                                                    gradient_as_bucket_view=True, broadcast_buffers=False)
+    criterion = build_criterion(cfg)
+    opt = build_optimizer(cfg, ddp)
+    batch = clip_to_device(make_synthetic_clip(clip_len=3, height=192, width=256, n_gts=3 + 2 * rank, seed=7 + rank), dev)
+    losses, counts = [], None
+    for _ in range(2):                               # a second step raises if a bucket was left unreduced
+        loss, _ = clip_forward_backward(ddp, criterion, batch, dev)
+        assert all(p.grad is not None for p in ddp.parameters() if p.requires_grad)
+        counts = list(criterion.n_gts)
+        optimizer_step(ddp, opt, cfg["CLIP_MAX_NORM"])
+        losses.append(float(loss))
+    torch.cuda.synchronize()
+    g = model.transformer.decoder.graphs()
+    flat = torch.cat([p.detach().reshape(-1) for p in ddp.parameters()]).cpu()
+    torch.save({"flat": flat, "losses": losses, "captures": g.captures, "replays": g.replays, "eager": g.eager,
+                "n_gts": counts, "backend": dist.get_backend(), "world": dist.get_world_size()}, f"{out_path}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_device_over_gloo_stay_in_sync(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    port = _free_port()
+    out = str(tmp_path / "shared")
+    mp.spawn(_worker_shared_device, args=(2, port, out), nprocs=2, join=True)
+    r0, r1 = (torch.load(f"{out}.{r}") for r in range(2))
+    assert r0["world"] == 2 and r0["backend"] == "gloo"
+    assert torch.equal(r0["flat"], r1["flat"]), "replicas diverged"
+    assert torch.isfinite(r0["flat"]).all()
+    assert r0["losses"][0] != r1["losses"][0]              # the ranks saw different clips
+    for r in (r0, r1):                                     # decoder graphs active under DDP: 3 frames x 2 steps
+        assert r["captures"] == 3 and r["replays"] == 6 and r["eager"] == 0, r

@@ -295,3 +295,101 @@ def test_fused_bias_relu_epilogue_is_bit_identical():
     assert torch.equal(res[0][0], res[1][0]) and float(res[0][0].min()) == 0.0
     for a, c in zip(res[0][1:], res[1][1:]):
         torch.testing.assert_close(a, c, rtol=1e-5, atol=1e-5)
+
+
+# ----------------------------------------------------------------------------- decoder hipGraphs
+def _d32_clip_step(monkeypatch, graphs: bool, clip_len=3, seed=0, **cfg_over):
+    """One clip train step of a D = 32 model (specialised kernels) with the decoder graphs on or off; returns
+    (loss, {param: grad}, decoder graph cache)."""
+    from memotr_amd.engine import clip_forward_backward, make_synthetic_clip, clip_to_device
+    from memotr_amd.models.criterion import build as build_criterion
+    import memotr_amd.modules.ms_deform_attn as mod
+    monkeypatch.setenv("MEMOTR_DECODER_GRAPHS", "1" if graphs else "0")
+    monkeypatch.setenv("MEMOTR_REQUIRE_GRAPHS", "1" if graphs else "0")
+    torch.manual_seed(seed)
+    model = build_memotr_cuda(None, hidden=256, ffn=256, NUM_ENC_LAYERS=1, NUM_DEC_LAYERS=2, **cfg_over).train()
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, mod.MSDeformAttn):
+                m.sampling_offsets.weight.normal_(0, 0.02)
+                m.attention_weights.weight.normal_(0, 0.05)
+    cfg = small_config()
+    cfg.update(HIDDEN_DIM=256, FFN_DIM=256, NUM_ENC_LAYERS=1, NUM_DEC_LAYERS=2, MATCH_COST_CLASS=2, MATCH_COST_BBOX=5,
+               MATCH_COST_GIOU=2, LOSS_WEIGHT_FOCAL=2, LOSS_WEIGHT_L1=5, LOSS_WEIGHT_GIOU=2, AUX_LOSS_WEIGHT=[1.0],
+               SAMPLE_LENGTHS=[2, 3, 4, 5], **cfg_over)
+    criterion = build_criterion(cfg)
+    batch = clip_to_device(make_synthetic_clip(clip_len=clip_len, height=192, width=256, n_gts=5, seed=3),
+                           torch.device("cuda"))
+    loss, _ = clip_forward_backward(model, criterion, batch, torch.device("cuda"))
+    grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    return float(loss), grads, model.transformer.decoder.graphs()
+
+
+def test_decoder_graphs_are_captured_and_match_the_eager_loop(monkeypatch):
+    """With MEMOTR_REQUIRE_GRAPHS=1 a capture failure raises; every frame of the clip is served from its own graph
+    (captures == replays == T) and loss / per-parameter gradients equal the eager decoder's."""
+    T = 3
+    loss_g, grads_g, cache = _d32_clip_step(monkeypatch, True, clip_len=T)
+    assert cache.captures == T and cache.replays == T and cache.eager == 0 and not cache.failed
+    loss_e, grads_e, cache_e = _d32_clip_step(monkeypatch, False, clip_len=T)
+    assert cache_e.captures == 0 and cache_e.replays == 0
+    assert abs(loss_g - loss_e) <= 2e-4 * abs(loss_e), (loss_g, loss_e)
+    assert grads_g.keys() == grads_e.keys()
+    for n in grads_e:
+        denom = float(grads_e[n].norm()) + 1e-6
+        # float atomics in the operator backward make both runs order-dependent at the 1e-3 level
+        assert float((grads_g[n] - grads_e[n]).norm()) / denom < 2e-2, n
+
+
+def test_decoder_graph_key_is_the_geometry_not_the_tensor_object(monkeypatch):
+    """Two shape tensors describing the same pyramid share a capture; a different pyramid does not."""
+    from memotr_amd.models.decoder_graphs import DecoderGraphs
+    from memotr_amd.MultiScaleDeformableAttention import tag_host_shapes
+    a = tag_host_shapes(torch.tensor([[24, 32], [12, 16]]), [(24, 32), (12, 16)])
+    b = tag_host_shapes(torch.tensor([[24, 32], [12, 16]]), [(24, 32), (12, 16)])
+    c = tag_host_shapes(torch.tensor([[24, 36], [12, 18]]), [(24, 36), (12, 18)])
+    assert DecoderGraphs._geometry(a) == DecoderGraphs._geometry(b) != DecoderGraphs._geometry(c)
+
+
+def test_decoder_graph_cache_stops_capturing_when_every_clip_has_a_new_geometry(monkeypatch):
+    from memotr_amd.models import decoder_graphs as dg
+
+    class _Dec:       # stands in for the decoder: only the capture counter matters here
+        pass
+
+    cache = dg.DecoderGraphs(_Dec())
+    calls = []
+    monkeypatch.setattr(cache, "_capture", lambda args, shapes, lsi: calls.append(1) or (lambda *a: "ran", ()))
+    monkeypatch.setattr(cache, "_flat_parameters", lambda params, clip_key: None)
+    monkeypatch.setattr(dg.DecoderGraphs, "_geometry", staticmethod(lambda s: s))
+    x = (torch.zeros(1),)
+    for i in range(dg.MISS_LIMIT + 5):          # a new geometry every time
+        cache.run(0, x, ("geo", i), None)
+    assert len(calls) == dg.MISS_LIMIT and cache.eager == 5
+    assert cache.run(0, x, ("geo", 0), None) == "ran"       # what was captured still replays
+    for i in range(dg.RETRY_AFTER):
+        cache.run(0, x, ("other", i), None)
+    assert len(calls) > dg.MISS_LIMIT                         # ... and the cache re-arms after RETRY_AFTER eager calls
+
+
+def test_track_augmentation_masks_built_on_the_cpu_index_cuda_tracks(monkeypatch):
+    """TP_DROP_RATE / FP_INSERT_RATE > 0 (reference models/query_updater.py:146-159): the drop / insert masks are
+    CPU tensors, the tracks live on the GPU."""
+    loss, grads, _ = _d32_clip_step(monkeypatch, False, clip_len=3, TP_DROP_RATE=0.3, FP_INSERT_RATE=0.5)
+    assert np.isfinite(loss) and all(torch.isfinite(g).all() for g in grads.values())
+    from memotr_amd.structures.track_instances import TrackInstances
+    tr = TrackInstances(hidden_dim=256, num_classes=1, use_dab=True)
+    tr.ref_pts = torch.rand(6, 4)
+    tr.query_embed = torch.rand(6, 256)
+    for k in ("ids", "labels", "matched_idx", "disappear_time"):
+        setattr(tr, k, torch.arange(6))
+    for k, shape in (("boxes", (6, 4)), ("logits", (6, 1)), ("output_embed", (6, 256)), ("scores", (6,)),
+                     ("area", (6,)), ("iou", (6,)), ("last_output", (6, 256)), ("long_memory", (6, 256)),
+                     ("last_appear_boxes", (6, 4))):
+        setattr(tr, k, torch.rand(*shape))
+    tr = tr.to("cuda")
+    keep = torch.tensor([True, False, True, True, False, True])            # on the CPU
+    sub = tr[keep]
+    assert len(sub) == 4 and sub.ids.is_cuda and sub.ids.tolist() == [0, 2, 3, 5]
+    sub2 = tr[torch.tensor([5, 1])]
+    assert sub2.ids.tolist() == [5, 1]
