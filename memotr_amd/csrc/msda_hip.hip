@@ -15,7 +15,8 @@
 // Variant numbers (msda_set_option "fwd_variant" / "bwd_variant"; 0 = auto):
 //   forward : 1 generic | 2,3,4 d32 gather with 2,4,1 points in flight | 8,9 region-tiled hybrid
 //             (level 0 through the vector L1, coarser levels from LDS windows; 4 / 2 global points in flight)
-//   backward: 1 generic | 8,9 region-tiled fixed-point windows, all levels of a region per workgroup (2 / 4 points
+//   backward: 0 auto (pyramid self-attention: 10; other D = 32 calls: msda_bwd_d32_rows, 32 lanes per row) | 1 generic |
+//             8,9 region-tiled fixed-point windows, all levels of a region per workgroup (2 / 4 points
 //             in flight) | 10,11 region-tiled fixed-point windows, one pyramid level per workgroup, inputs loaded once
 //
 // Kernel families
@@ -1943,6 +1944,7 @@ __global__ __launch_bounds__(256) void msda_fused_finish16_kernel(const int64_t 
 }
 
 #include "msda_fwd_win.h"
+#include "msda_bwd_rows.h"
 
 // ----------------------------------------------------------------------------------------
 // host side
@@ -1958,6 +1960,8 @@ std::atomic<int> opt_fwd_tile_l0{1};      // hybrid forward: first level served 
 std::atomic<int> opt_bwd_split{1};        // fused backward with a workspace: prologue kernel + plain tiled kernel + finish kernel
 std::atomic<int> opt_bwd_wide_log2{12};   // tiled backward: row-magnitude range (log2) that makes a region "wide"; 0 = off
 std::atomic<int> opt_bwd_ablate{0};
+std::atomic<int> opt_bwd_rows_block{0};   // threads per workgroup of msda_bwd_d32_rows (0: by problem size)
+std::atomic<int> opt_bwd_rows{1};         // 0: few-query D = 32 calls keep the generic row-per-block backward
 std::atomic<int> opt_fwd_head_major{0};    // gather forward: head-major task walk (one head per XCD)
 std::atomic<int> opt_fwd_win_rlog{3};       // windowed forward: log2 of the region height on level 0
 std::atomic<int> opt_fwd_win_rlogx{3};      // log2 of the region width (at least the height)
@@ -2401,9 +2405,38 @@ int backward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart,
             variant = 1;
         }
     }
+    const long n_rows = (long)N * Lq * M;
+    if constexpr (kD32Type) {
+        // few-query calls at D = 32 (the decoder's cross-attention): 32 lanes per row, grad_value atomics in whole
+        // 128-byte rows, four points in flight (msda_bwd_rows.h)
+        const int requested = opt_bwd_variant.load();      // 1 = the generic kernel, explicitly
+        if (d32_ok(D, L, value_elems) && L * P <= kRowsMaxLP && opt_bwd_rows.load() != 0 && n_rows < (1L << 31) &&
+            requested != 1) {
+            const PointSrc src = make_src(loc, attn, fa, M, L, P);
+            // a row is a chain of dependent round trips (stage -> loads -> atomics -> reductions): small calls get one
+            // wavefront (two rows) per workgroup so that every CU holds several chains
+            int threads = opt_bwd_rows_block.load();
+            if (threads != 64 && threads != 128 && threads != 256) threads = n_rows <= 16384 ? 64 : 256;
+            const int per = threads / 32;
+            const int grid = clamp_grid((n_rows + per - 1) / per, 64);
+            const unsigned gv_bytes = (unsigned)(value_elems * 4);
+            const bool b16 = sizeof(TV) == 2;
+            if (fused) {
+                g_kernel = b16 ? "msda_bwd_d32_rows<bf16,fused>" : "msda_bwd_d32_rows<fused>";
+                hipLaunchKernelGGL((msda_bwd_d32_rows<TV, true>), dim3(grid), dim3(threads), 0, stream, value, shapes, lstart,
+                                   src, grad_out, N, S, M, L, Lq, P, (float *)grad_value, (float *)nullptr,
+                                   (float *)nullptr, grad_proj, grad_ref_part, (unsigned)value_bytes, gv_bytes);
+            } else {
+                g_kernel = b16 ? "msda_bwd_d32_rows<bf16>" : "msda_bwd_d32_rows";
+                hipLaunchKernelGGL((msda_bwd_d32_rows<TV, false>), dim3(grid), dim3(threads), 0, stream, value, shapes, lstart,
+                                   src, grad_out, N, S, M, L, Lq, P, (float *)grad_value, (float *)grad_loc,
+                                   (float *)grad_attn, (float *)nullptr, (float *)nullptr, (unsigned)value_bytes, gv_bytes);
+            }
+            return check_launch(g_kernel);
+        }
+    }
     int block = ((D + 63) / 64) * 64;
     if (block > 1024) block = 1024;
-    const long n_rows = (long)N * Lq * M;
     const int grid = (int)(n_rows < 65536L * 16 ? n_rows : 65536L * 16);
     if constexpr (sizeof(TC) == 4) {
         if (fused) {
@@ -2613,6 +2646,8 @@ static std::atomic<int> *find_opt(const char *key) {
     if (!strcmp(key, "bwd_ablate")) return &opt_bwd_ablate;
     if (!strcmp(key, "bwd_wide_log2")) return &opt_bwd_wide_log2;
     if (!strcmp(key, "bwd_split")) return &opt_bwd_split;
+    if (!strcmp(key, "bwd_rows")) return &opt_bwd_rows;
+    if (!strcmp(key, "bwd_rows_block")) return &opt_bwd_rows_block;
     if (!strcmp(key, "fwd_win_rlog")) return &opt_fwd_win_rlog;
     if (!strcmp(key, "fwd_win_rlogx")) return &opt_fwd_win_rlogx;
     if (!strcmp(key, "fwd_win_auto")) return &opt_fwd_win_auto;

@@ -88,9 +88,10 @@ def encode_chunks(core, clip_len: int):
     order 235 ms, "all" 232, "lazy:3,2" 219 -- two groups kept GPU-bound encoder backward work queued while the host
     was busy with the launch-bound decoder backward of the earlier frames.  End of round 2, GPU-bound step (decoder
     graphs, fused small-tensor kernels): "auto" 157.6, "2,3" 155.3, "4,1" 152.7, "all" **147.3 ms** -- the largest
-    kernels and the fewest launches win once the host is out of the way.  Gradient checkpointing keeps the
-    reference's order."""
-    if getattr(core, "use_checkpoint", False):
+    kernels and the fewest launches win once the host is out of the way.  Gradient checkpointing (round 3) groups the
+    same way: the checkpointed backbone / encoder segments then recompute per group instead of per frame
+    (MEMOTR_CHECKPOINT_REFERENCE_ORDER=1 restores the reference's frame order)."""
+    if getattr(core, "use_checkpoint", False) and os.environ.get("MEMOTR_CHECKPOINT_REFERENCE_ORDER", "0") == "1":
         return None, False
     spec = getattr(core, "encode_chunks", None)
     if spec is None:

@@ -390,9 +390,12 @@ def attention_supported(q_p: torch.Tensor, k_p: torch.Tensor, n_heads: int) -> b
             and q_p.shape[2] % n_heads == 0 and q_p.shape[2] // n_heads == MHA_HEAD_DIM and 0 < q_p.shape[1] <= MHA_MAX_L)
 
 
-def self_attention_supported(qk_p: torch.Tensor, n_heads: int) -> bool:
+def self_attention_supported(qk_p: torch.Tensor, n_heads: int, any_float: bool = False) -> bool:
+    """``any_float``: the caller casts a bf16 / fp16 projection to float32 first (autocast island)."""
     B, L, E2 = qk_p.shape
-    return (os.environ.get("MEMOTR_ATTN_KERNELS", "1") != "0" and fused(qk_p) and qk_p.dtype == torch.float32 and E2 % (2 * n_heads) == 0
+    dtype_ok = qk_p.is_floating_point() if any_float else qk_p.dtype == torch.float32
+    return (os.environ.get("MEMOTR_ATTN_KERNELS", "1") != "0" and os.environ.get("MEMOTR_FUSED_CLIP_OPS", "1") != "0"
+            and qk_p.is_cuda and dtype_ok and E2 % (2 * n_heads) == 0
             and E2 // 2 // n_heads == MHA_HEAD_DIM and 0 < L <= MHA_MAX_L)
 
 
@@ -452,15 +455,23 @@ class _AddLayerNorm(torch.autograd.Function):
 
 
 def add_layer_norm_supported(x: torch.Tensor, res: torch.Tensor, norm) -> bool:
+    """fp32 CUDA tensors; under autocast also bf16 / fp16 ones (see add_layer_norm)."""
+    island = torch.is_autocast_enabled()
+    ok_dtype = (lambda t: t.is_floating_point()) if island else (lambda t: t.dtype == torch.float32)
     return (isinstance(norm, torch.nn.LayerNorm) and norm.elementwise_affine and norm.bias is not None
             and tuple(norm.normalized_shape) == (LN_COLS,) and x.shape == res.shape and x.shape[-1] == LN_COLS
-            and fused(x, res) and x.dtype == torch.float32 and norm.weight.dtype == torch.float32
-            and not torch.is_autocast_enabled() and os.environ.get("MEMOTR_FUSED_LN", "1") != "0")
+            and x.is_cuda and res.is_cuda and ok_dtype(x) and ok_dtype(res) and norm.weight.dtype == torch.float32
+            and os.environ.get("MEMOTR_FUSED_CLIP_OPS", "1") != "0" and os.environ.get("MEMOTR_FUSED_LN", "1") != "0")
 
 
 def add_layer_norm(x: torch.Tensor, res: torch.Tensor, norm) -> torch.Tensor:
     """norm(x + res) for an nn.LayerNorm over 256 features: one kernel forward (sum, statistics and output in one
-    pass), one + a column sum backward; other shapes / dtypes / devices go through the module."""
+    pass), one + a column sum backward; other shapes / dtypes / devices go through the module.
+
+    Under autocast the kernel runs as an fp32 island: autocast itself evaluates layer_norm in float32 (and the sum
+    ``x + res`` promotes to float32 as soon as one operand is), so casting the low-precision operand up front gives the
+    values autocast would have produced -- through one kernel instead of add + native_layer_norm (+ their backward)."""
     if add_layer_norm_supported(x, res, norm):
-        return _AddLayerNorm.apply(x.contiguous(), res.contiguous(), norm.weight, norm.bias, float(norm.eps))
+        return _AddLayerNorm.apply(x.float().contiguous(), res.float().contiguous(), norm.weight, norm.bias,
+                                   float(norm.eps))
     return norm(x + res)

@@ -50,6 +50,21 @@ def upload(values, dtype, device):
     return t.to(device)
 
 
+def _fp32_island(fn):
+    """Losses and matching costs are float32 work on query-sized tensors: under autocast (the bf16 extension) they run
+    with autocast off -- the model's decode half hands over float32 outputs -- i.e. what autocast's own promotion
+    rules would compute for these loss formulas, minus the casts."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *args, **kwargs):
+        if torch.is_autocast_enabled():
+            with torch.autocast(device_type="cuda", enabled=False):
+                return fn(self, *args, **kwargs)
+        return fn(self, *args, **kwargs)
+    return wrapped
+
+
 class ClipCriterion:
     def __init__(self, num_classes, matcher: HungarianMatcher, n_det_queries, aux_loss: bool, weight: dict,
                  max_frame_length: int, n_aux: int, merge_det_track_layer: int = 0, aux_weights: List = None,
@@ -138,6 +153,7 @@ class ClipCriterion:
         """
         return self.finish_frame(self.begin_frame(model_outputs, tracked_instances, frame_idx))
 
+    @_fp32_island
     def begin_frame(self, model_outputs: dict, tracked_instances: List[TrackInstances], frame_idx: int) -> dict:
         """Device side of the matching: ownership of ground truths + stacked cost tensors, and the (asynchronous,
         pinned-memory) copy of both to the host.  Returns the state ``finish_frame`` consumes."""
@@ -217,6 +233,7 @@ class ClipCriterion:
             streams[device] = torch.cuda.Stream(device=device)
         return streams[device]
 
+    @_fp32_island
     def finish_frame(self, state: dict):
         """Host side (assignment problems) and the device work that depends on it; see process_single_frame."""
         model_outputs, tracked_instances, frame_idx = state["model_outputs"], state["tracked_instances"], state["frame_idx"]

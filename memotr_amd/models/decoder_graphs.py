@@ -132,11 +132,15 @@ class DecoderGraphs:
 
     def usable(self, output, src) -> bool:
         d = self.decoder
+        # use_checkpoint: the graph pair replaces the per-layer checkpoints of the decoder -- its activations are
+        # (300 + n) x 256 per layer, nothing next to the backbone / encoder segments that stay checkpointed
+        # (MEMOTR_CHECKPOINT_DECODER=1 keeps the reference's per-layer recompute, eager).
         # extra_track_attn: a frame without tracks still carries one masked (padded) track slot in the graphed path,
         # and attention over keys that are ALL masked is 0 * inf -- its rows are sliced away, but the NaN reaches the
         # parameter gradients through the norms; those models keep the eager loop
         return (enabled() and not self.failed and output.is_cuda and d.use_dab and d.bbox_embed is not None
-                and not d.use_checkpoint and torch.is_grad_enabled() and src.requires_grad
+                and (not d.use_checkpoint or os.environ.get("MEMOTR_CHECKPOINT_DECODER", "0") != "1")
+                and torch.is_grad_enabled() and src.requires_grad
                 and not torch.is_autocast_enabled() and output.dtype == torch.float32
                 and not any(getattr(layer, "extra_track_attn", False) for layer in d.layers))
 

@@ -8,6 +8,8 @@ them on the CPU and copies, models/memotr.py:222-278 -- a device->host->device r
 """
 from __future__ import annotations
 
+import os
+
 import math
 from typing import List, Optional
 
@@ -120,7 +122,16 @@ class MeMOTR(nn.Module):
         return self.transformer.encode(srcs=srcs, masks=masks, pos_embeds=pos, geometry=getattr(frame, "sizes", None))
 
     def decode_frame(self, encoded: dict, tracks: List[TrackInstances]) -> dict:
-        """Query assembly -> decoder -> heads over an ``encode_frame`` result."""
+        """Query assembly -> decoder -> heads over an ``encode_frame`` result.
+
+        Under autocast (the bf16 extension) this half runs as a float32 island: its GEMMs have a few hundred rows --
+        nothing for the matrix cores to win, while every cast is one more launch in a launch-bound chain -- and in
+        float32 the decoder loop keeps its hipGraphs and hand-written kernels.  bf16 stays where the FLOPs are
+        (backbone, encoder).  MEMOTR_AUTOCAST_DECODER=1 restores plain autocast semantics."""
+        if torch.is_autocast_enabled() and os.environ.get("MEMOTR_AUTOCAST_DECODER", "0") != "1":
+            enc32 = {k: (v.float() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in encoded.items()}
+            with torch.autocast(device_type=encoded["memory"].device.type, enabled=False):
+                return self.decode_frame(enc32, tracks)
         device = encoded["memory"].device
         reference_points = self.get_reference_points(tracks).to(device)     # (B, Nd+Nt, 4) logit space
         query_embed = self.get_query_embed(tracks).to(device)               # (B, Nd+Nt, C | 2C)
@@ -233,7 +244,10 @@ class MeMOTR(nn.Module):
 
     def postprocess_single_frame(self, previous_tracks: List[TrackInstances], new_tracks: List[TrackInstances],
                                  unmatched_dets: Optional[List[TrackInstances]], no_augment: bool = False):
-        """Query updating between frames."""
+        """Query updating between frames (a float32 island under autocast, like ``decode_frame``)."""
+        if torch.is_autocast_enabled() and os.environ.get("MEMOTR_AUTOCAST_DECODER", "0") != "1":
+            with torch.autocast(device_type="cuda", enabled=False):
+                return self.query_updater(previous_tracks, new_tracks, unmatched_dets, no_augment)
         return self.query_updater(previous_tracks, new_tracks, unmatched_dets, no_augment)
 
 

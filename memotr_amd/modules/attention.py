@@ -79,9 +79,20 @@ def self_attention(mha: nn.MultiheadAttention, qk: torch.Tensor, v: torch.Tensor
         q, k = (t.transpose(1, 2) for t in qk_p.view(B, L, 2, H, d).unbind(2))     # (B, H, L, d)
         vh = v_p.view(B, L, H, d).transpose(1, 2)
     else:
-        qk_p = F.linear(qk, w[:2 * E], b[:2 * E]).view(B, L, 2, H, d)
+        qk_p = F.linear(qk, w[:2 * E], b[:2 * E])
+        v_p = F.linear(v, w[2 * E:], b[2 * E:])
+        from ..functions import clip_ops
+        if (torch.is_autocast_enabled() and clip_ops.self_attention_supported(qk_p, H, any_float=True)
+                and not (mha.training and mha.dropout > 0)):
+            # autocast (bf16 projections on MFMA): the attention itself as a float32 island in the hand-written
+            # kernels -- query-sized tensors, the casts are noise, and no AOTriton kernel runs
+            no_pad = key_padding_mask is None or getattr(key_padding_mask, "_no_padding", False)
+            out = clip_ops.self_attention(qk_p.float(), v_p.float(), None if no_pad else key_padding_mask, H)
+            from .linear import row_linear
+            return row_linear(out, mha.out_proj.weight, mha.out_proj.bias)
+        qk_p = qk_p.view(B, L, 2, H, d)
         q, k = qk_p[:, :, 0].transpose(1, 2), qk_p[:, :, 1].transpose(1, 2)        # (B, H, L, d)
-        vh = F.linear(v, w[2 * E:], b[2 * E:]).view(B, L, H, d).transpose(1, 2)
+        vh = v_p.view(B, L, H, d).transpose(1, 2)
     mask = None
     if key_padding_mask is not None and not getattr(key_padding_mask, "_no_padding", False):
         mask = ~key_padding_mask.view(B, 1, 1, L)                                   # True = take part
@@ -100,15 +111,19 @@ def memory_attention(mha: nn.MultiheadAttention, q: torch.Tensor, k: torch.Tenso
     from ..functions import clip_ops
     from .linear import row_linear
     E, H = mha.embed_dim, mha.num_heads
+    island = torch.is_autocast_enabled()          # bf16 projections, float32 attention (as in self_attention)
+    q32, k32 = (q.float(), k.float()) if island else (q, k)
     ok = (mha.batch_first and mha._qkv_same_embed_dim and mha.in_proj_bias is not None and mha.bias_k is None
-          and not mha.add_zero_attn and not (mha.training and mha.dropout > 0) and not torch.is_autocast_enabled()
-          and q.dim() == 3 and q.shape == k.shape == v.shape and q.is_cuda and q.dtype == torch.float32
-          and clip_ops.attention_supported(q, k, H) and clip_ops.fused(v))
+          and not mha.add_zero_attn and not (mha.training and mha.dropout > 0)
+          and q.dim() == 3 and q.shape == k.shape == v.shape and q.is_cuda and q32.dtype == torch.float32
+          and clip_ops.attention_supported(q32, k32, H) and v.is_cuda)
     if not ok:
         return mha(q, k, v, need_weights=False)[0]
     w, b = mha.in_proj_weight, mha.in_proj_bias
     q_p = row_linear(q, w[:E], b[:E])
     k_p = row_linear(k, w[E:2 * E], b[E:2 * E])
     v_p = row_linear(v, w[2 * E:], b[2 * E:])
+    if island:
+        q_p, k_p, v_p = q_p.float(), k_p.float(), v_p.float()
     out = clip_ops.attention(q_p, k_p, v_p, H)
     return row_linear(out, mha.out_proj.weight, mha.out_proj.bias)

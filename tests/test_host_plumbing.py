@@ -33,7 +33,9 @@ def test_encode_chunks_env_and_checkpoint(monkeypatch):
     monkeypatch.setenv("MEMOTR_ENCODE_CHUNKS", "all")
     assert encode_chunks(_Core(), 4) == ([4], False)
     core = _Core()
-    core.use_checkpoint = True                       # activation checkpointing keeps the reference's frame order
+    core.use_checkpoint = True          # activation checkpointing groups like the plain step (segments recompute per
+    assert encode_chunks(core, 4) == ([4], False)                                   # group) unless told otherwise
+    monkeypatch.setenv("MEMOTR_CHECKPOINT_REFERENCE_ORDER", "1")
     assert encode_chunks(core, 4) == (None, False)
 
 

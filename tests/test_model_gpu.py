@@ -393,3 +393,52 @@ def test_track_augmentation_masks_built_on_the_cpu_index_cuda_tracks(monkeypatch
     assert len(sub) == 4 and sub.ids.is_cuda and sub.ids.tolist() == [0, 2, 3, 5]
     sub2 = tr[torch.tensor([5, 1])]
     assert sub2.ids.tolist() == [5, 1]
+
+
+def test_bf16_clip_step_with_eight_classes_tracks_the_fp32_step(monkeypatch):
+    """BASELINE config 5 in miniature: K = 8 classes (BDD100K), bf16 autocast over the clip step.  bf16 runs where the
+    FLOPs are (backbone, encoder, `value`); the decode half, the criterion and the query updater are float32 islands
+    with the decoder hipGraphs active.  Loss within 2 % of the fp32 step; per-parameter gradients within 20 % of the
+    fp32 gradient's norm (two bf16 GEMM chains: ~3 significant digits)."""
+    from memotr_amd.engine import clip_forward_backward, make_synthetic_clip, clip_to_device
+    from memotr_amd.models.criterion import build as build_criterion
+    import memotr_amd.modules.ms_deform_attn as mod
+    monkeypatch.setenv("MEMOTR_REQUIRE_GRAPHS", "1")
+
+    def run(bf16):
+        torch.manual_seed(5)
+        cfg = small_config()
+        cfg.update(HIDDEN_DIM=256, FFN_DIM=256, NUM_ENC_LAYERS=1, NUM_DEC_LAYERS=2, DATASET="BDD100K", MATCH_COST_CLASS=2,
+                   MATCH_COST_BBOX=5, MATCH_COST_GIOU=2, LOSS_WEIGHT_FOCAL=2, LOSS_WEIGHT_L1=5, LOSS_WEIGHT_GIOU=2,
+                   AUX_LOSS_WEIGHT=[1.0], SAMPLE_LENGTHS=[2, 3, 4])
+        from memotr_amd.models.backbone import BackboneWithPE
+        from memotr_amd.models.deformable_transformer import build as build_tr
+        from memotr_amd.models.memotr import MeMOTR
+        from memotr_amd.models.position_embedding import build as build_pe
+        from memotr_amd.models.query_updater import build as build_qu
+        model = MeMOTR(backbone=BackboneWithPE(TinyBackbone(), build_pe(cfg)), transformer=build_tr(cfg),
+                       query_updater=build_qu(cfg), num_classes=8, n_det_queries=cfg["NUM_DET_QUERIES"],
+                       n_feature_levels=4, hidden_dim=256, ffn_dim=256, dropout=0.0, use_dab=True).cuda().train()
+        with torch.no_grad():
+            for m in model.modules():
+                if isinstance(m, mod.MSDeformAttn):
+                    m.sampling_offsets.weight.normal_(0, 0.02)
+                    m.attention_weights.weight.normal_(0, 0.05)
+        criterion = build_criterion(cfg)
+        batch = clip_to_device(make_synthetic_clip(clip_len=3, height=192, width=256, n_gts=5, seed=3, num_classes=8),
+                               torch.device("cuda"))
+        if bf16:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss, _ = clip_forward_backward(model, criterion, batch, torch.device("cuda"))
+        else:
+            loss, _ = clip_forward_backward(model, criterion, batch, torch.device("cuda"))
+        grads = {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None}
+        return float(loss), grads, model.transformer.decoder.graphs()
+
+    loss32, g32, _ = run(False)
+    loss16, g16, cache = run(True)
+    assert cache.captures == 3 and cache.eager == 0, (cache.captures, cache.eager)     # graphs under autocast
+    assert abs(loss16 - loss32) < 0.02 * abs(loss32), (loss16, loss32)
+    assert g16.keys() == g32.keys()
+    worst = max(float((g16[n] - g32[n]).norm()) / (float(g32[n].norm()) + 1e-4) for n in g32)
+    assert worst < 0.2, worst

@@ -212,3 +212,30 @@ def test_non_finite_gradients_propagate_like_float_atomics(msda, hip_lib):
     assert np.array_equal(bad_got, bad_ref)
     ok = ~bad_ref
     np.testing.assert_allclose(got[1][ok], want[1][ok], rtol=1e-4, atol=1e-4)
+
+
+# ----------------------------------------------------------------------------- bf16 storage (BASELINE config 5)
+@pytest.mark.parametrize("pyr", list(PYRAMIDS))
+def test_bf16_encoder_shape_forward_and_backward_match_oracle(msda, hip_lib, pyr):
+    """bf16 `value` / `out` / `grad_out`, fp32 locations, weights and accumulation (msda_*_bf16; no reference
+    counterpart) at the FULL pyramids -- BDD100K's (92,160)... is config 5's -- against the fp32 oracle run on the
+    bf16-rounded inputs.  Tolerances: the output and grad_value are rounded to / accumulated from bf16 values
+    (2^-8 relative steps); grad_loc / grad_attn are fp32 sums over bf16-rounded products."""
+    from memotr_amd.MultiScaleDeformableAttention import tag_host_shapes
+    from memotr_amd.synth import make_inputs
+    h, w = PYRAMIDS[pyr]
+    x = make_inputs(height=h, width=w, dist="encoder_like", device="cuda", seed=13)
+    tag_host_shapes(x["shapes"], x["shapes_list"])
+    vb, gob = x["value"].bfloat16(), x["grad_out"].bfloat16()
+    args = (vb, x["shapes"], x["level_start"], x["loc"], x["attn"])
+    out = msda.ms_deform_attn_forward(*args, 64)
+    assert "bf16" in hip_lib.last_kernel() and "d32" in hip_lib.last_kernel(), hip_lib.last_kernel()
+    gv, gl, ga = msda.ms_deform_attn_backward(*args, gob, 64)
+    assert "bf16" in hip_lib.last_kernel() and "tile" in hip_lib.last_kernel(), hip_lib.last_kernel()
+    c = _cpu(x)
+    c["value"], c["grad_out"] = vb.float().cpu().numpy(), gob.float().cpu().numpy()
+    rout, rgv, rgl, rga = _oracle(c)
+    np.testing.assert_allclose(out.float().cpu().numpy(), rout, rtol=1e-2, atol=1e-2, err_msg="out")
+    np.testing.assert_allclose(gv.float().cpu().numpy(), rgv, rtol=1e-2, atol=3e-2, err_msg="grad_value")
+    np.testing.assert_allclose(gl.cpu().numpy(), rgl, rtol=1e-3, atol=2e-2, err_msg="grad_loc")
+    np.testing.assert_allclose(ga.cpu().numpy(), rga, rtol=1e-3, atol=2e-3, err_msg="grad_attn")

@@ -25,7 +25,7 @@ def reset():
                  ("fwd_tile_l0", 1), ("fwd_block", 256), ("fwd_grid_mult", 32), ("bwd_split", 1),
                  ("fwd_win_rlog", 3), ("fwd_win_rlogx", 3), ("fwd_win_block", 256), ("fwd_win_l0", 1), ("fwd_win_margins", 0x3333),
                  ("fwd_win_dma", 1), ("fwd_head_major", 0), ("fwd_win_early", 2), ("fwd_win_wps", 0),
-                 ("fwd_win_ablate", 0)):
+                 ("fwd_win_ablate", 0), ("bwd_rows_block", 0)):
         _lib.set_option(k, v)
 
 
@@ -92,6 +92,10 @@ def main():
                     record(op=tag, dist=dist, shape=sname, cfg=name, ms=ms, GBps=gbps, err=err,
                            kernel=_lib.last_kernel())
             bwd_cfgs = [("v1 generic", dict(bwd_variant=1))]
+            if not enc:
+                bwd_cfgs.append(("v0 rows (32 lanes/row)", dict(bwd_variant=0)))
+                bwd_cfgs.append(("v0 rows block=128", dict(bwd_variant=0, bwd_rows_block=128)))
+                bwd_cfgs.append(("v0 rows block=256", dict(bwd_variant=0, bwd_rows_block=256)))
             if enc:
                 for v in ((8, 9, 10, 11) if args.old else (10,)):
                     for mg in ((2, 3, 4) if not args.quick else (3,)):
