@@ -32,6 +32,10 @@ import time
 # argument fetch is part of each one's launch latency (203 vs 207 ms per step, tools/ab_step.py).  Read by the HIP
 # runtime when it initialises, hence before torch is imported.
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+# ROCm 7.2: with the runtime's AQL-packet capture on (the default) a MEMSET node of a replayed hipGraph is not ordered
+# behind the kernels before it (tools/graph_memset_probe.py); torch's multi-block reductions, and whatever else a
+# library zeroes that way, then read garbage from the second replay on.  Read when the HIP runtime loads.
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 
 import torch  # noqa: E402
 

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define CLIPOPS_ABI_VERSION 6
+#define CLIPOPS_ABI_VERSION 7
 
 int clipops_abi_version(void);
 const char *clipops_last_error(void);
@@ -89,6 +89,9 @@ int clipops_colsum_f32(const float *x, long rows, int cols, float *out, void *st
 /* First pass for tall matrices: partial[k*cols + c] = sum of rows [k*chunk_rows, (k+1)*chunk_rows) of column c,
  * k < ceil(rows / chunk_rows); clipops_colsum_f32 over `partial` finishes (fixed order end to end). */
 int clipops_colsum_partial_f32(const float *x, long rows, int cols, int chunk_rows, float *partial, void *stream);
+/* The same from bf16 storage (fp32 partial sums): bias gradients of the bf16 linears -- torch's own multi-block
+ * reduction returned garbage inside replayed hipGraphs (round 3, profiles/r03_notes). */
+int clipops_colsum_partial_bf16(const uint16_t *x, long rows, int cols, int chunk_rows, float *partial, void *stream);
 
 /* Multi-head self-attention over the decoder queries (reference models/deformable_decoder.py:245-249: the
  * nn.MultiheadAttention call with query = key = tgt + pos, value = tgt; here after the input projections):

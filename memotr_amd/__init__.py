@@ -13,4 +13,12 @@ The HIP library is mandatory: importing the operator without a built
 ``memotr_amd/lib/libmsda_hip.so`` raises (there is no CPU fallback in the product).
 """
 
+import os as _os
+
+# hipGraph replays on ROCm 7.2 mis-order memset nodes unless the runtime's AQL-packet capture is off (see
+# models/decoder_graphs.py, tools/graph_memset_probe.py).  The runtime reads the flag when it loads, i.e. this only
+# helps when the package is imported before torch; bench.py / the tests / __graft_entry__ set it themselves.  The
+# captured regions of this package contain no memset nodes either way (held by the GPU tests).
+_os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
 __version__ = "0.1.0"

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libclip_ops_hip.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 c_int, c_long, c_float, c_void_p = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_void_p
 
@@ -30,6 +30,7 @@ SYMBOLS = {
     "clipops_focal_bwd_f32": (_FOCAL + [c_void_p, c_void_p, c_void_p], c_int),
     "clipops_colsum_f32": ([c_void_p, c_long, c_int, c_void_p, c_void_p], c_int),
     "clipops_colsum_partial_f32": ([c_void_p, c_long, c_int, c_int, c_void_p, c_void_p], c_int),
+    "clipops_colsum_partial_bf16": ([c_void_p, c_long, c_int, c_int, c_void_p, c_void_p], c_int),
     "clipops_mha_fwd_f32": ([c_void_p] * 3 + [c_long] * 6 + [c_void_p] + [c_int] * 3 + [c_float, c_void_p, c_void_p,
                                                                                           c_void_p], c_int),
     "clipops_mha_bwd_f32": ([c_void_p] * 3 + [c_long] * 6 + [c_void_p] * 4 + [c_int] * 3 + [c_float] +

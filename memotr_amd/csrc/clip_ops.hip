@@ -397,7 +397,13 @@ __global__ __launch_bounds__(256) void colsum_quad_kernel(const float *__restric
 }
 
 // the same tile over one chunk of rows per workgroup row (blockIdx.y): partial sums for tall matrices
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__restrict__ x, long rows, int cols,
+__device__ __forceinline__ float colsum_ld(const float *x, long i) { return x[i]; }
+__device__ __forceinline__ float colsum_ld(const uint16_t *x, long i) {      // bf16 storage, fp32 sums
+    return __uint_as_float(((unsigned)x[i]) << 16);
+}
+
+template <typename TX>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const TX *__restrict__ x, long rows, int cols,
                                                             int chunk_rows, float *__restrict__ partial) {
     __shared__ float s_part[8][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -408,12 +414,12 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__rest
     if (c < cols) {
         long r = r0 + ty;
         for (; r + 24 < r1; r += 32) {
-            a0 += x[r * cols + c];
-            a1 += x[(r + 8) * cols + c];
-            a2 += x[(r + 16) * cols + c];
-            a3 += x[(r + 24) * cols + c];
+            a0 += colsum_ld(x, r * cols + c);
+            a1 += colsum_ld(x, (r + 8) * cols + c);
+            a2 += colsum_ld(x, (r + 16) * cols + c);
+            a3 += colsum_ld(x, (r + 24) * cols + c);
         }
-        for (; r < r1; r += 8) a0 += x[r * cols + c];
+        for (; r < r1; r += 8) a0 += colsum_ld(x, r * cols + c);
     }
     s_part[ty][tx] = (a0 + a1) + (a2 + a3);
     __syncthreads();
@@ -888,9 +894,20 @@ int clipops_colsum_partial_f32(const float *x, long rows, int cols, int chunk_ro
     if (!x || !partial) return fail(1, "clipops_colsum_partial_f32: null pointer");
     const long chunks = (rows + chunk_rows - 1) / chunk_rows;
     if (chunks > 65535) return fail(1, "clipops_colsum_partial_f32: too many chunks");
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 31) / 32, (unsigned)chunks), dim3(256), 0,
+    hipLaunchKernelGGL(colsum_partial_kernel<float>, dim3((cols + 31) / 32, (unsigned)chunks), dim3(256), 0,
                        (hipStream_t)stream, x, rows, cols, chunk_rows, partial);
     return check_launch("colsum_partial_kernel");
+}
+
+int clipops_colsum_partial_bf16(const uint16_t *x, long rows, int cols, int chunk_rows, float *partial, void *stream) {
+    if (rows < 0 || cols < 0 || chunk_rows <= 0) return fail(1, "clipops_colsum_partial_bf16: bad dimension");
+    if (cols == 0 || rows == 0) { g_err[0] = 0; return 0; }
+    if (!x || !partial) return fail(1, "clipops_colsum_partial_bf16: null pointer");
+    const long chunks = (rows + chunk_rows - 1) / chunk_rows;
+    if (chunks > 65535) return fail(1, "clipops_colsum_partial_bf16: too many chunks");
+    hipLaunchKernelGGL(colsum_partial_kernel<uint16_t>, dim3((cols + 31) / 32, (unsigned)chunks), dim3(256), 0,
+                       (hipStream_t)stream, x, rows, cols, chunk_rows, partial);
+    return check_launch("colsum_partial_kernel<bf16>");
 }
 
 int clipops_mha_fwd_f32(const float *q, const float *k, const float *v, long q_bs, long q_rs, long k_bs, long k_rs,

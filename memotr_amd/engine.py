@@ -193,7 +193,9 @@ def clip_forward_backward(model: nn.Module, criterion, batch: dict, device, use_
                     v.record_stream(main)
             on_side.update(range(lo, lo + n))
         else:
-            enc = model(frame=frames(lo, lo + n), stage="encode")
+            batch_frames = frames(lo, lo + n)
+            batch_frames.encode_slot = ci           # which of the clip's encode calls this is (models/encode_graphs.py)
+            enc = model(frame=batch_frames, stage="encode")
         if n == 1:
             encoded[lo] = dict(enc, frame_slot=lo, clip_key=clip_key)   # the frame's slot for the decoder's hipGraphs
             return
@@ -248,7 +250,13 @@ def clip_forward_backward(model: nn.Module, criterion, batch: dict, device, use_
     loss_dict, _ = criterion.get_mean_by_n_gts()
     loss = criterion.get_sum_loss_dict(loss_dict=loss_dict)
     if backward:
-        (loss / accumulation_steps).backward()
+        # the backward pass never runs under autocast (the engine's threads inherit the caller's autocast state):
+        # backward ops take the dtypes their forward ran in; with autocast left on, the float32 islands' backward GEMMs
+        # -- (6, 256, 310) x (6, 310, 1) class heads, a (3, 2) x (2, 6) box product -- were cast to bf16 and cost
+        # ~11 ms of HOST time each in hipBLASLt (10 per step: 110 of the bf16 step's 220 ms, tools/idle_gaps.py --bf16)
+        with (torch.autocast(device_type=torch.device(device).type, enabled=False)
+              if torch.is_autocast_enabled() else contextlib.nullcontext()):
+            (loss / accumulation_steps).backward()
     return loss, loss_dict
 
 

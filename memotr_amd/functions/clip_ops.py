@@ -283,28 +283,54 @@ COLSUM_CHUNK_ROWS = 256         # tall matrices: partial sums per 256 rows, then
 
 
 def colsum(x: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
-    """x.sum(0) of a contiguous 2-d fp32 CUDA matrix through the tiled kernels (fixed summation order): one pass up to
-    COLSUM_MAX_ROWS rows, two passes (per-chunk partial sums, then the partials) above; anything else takes torch's
-    reduction.  ``out`` may be a contiguous (cols,) destination."""
-    ok = (x.dim() == 2 and x.is_contiguous() and fused(x) and x.dtype == torch.float32
+    """x.sum(0) of a contiguous 2-d CUDA matrix through the tiled kernels (fixed summation order, fp32 sums and result):
+    fp32 input -- one pass up to COLSUM_MAX_ROWS rows, two passes (per-chunk partial sums, then the partials) above;
+    bf16 input -- always the two-pass form.  Anything else takes torch's reduction.  ``out`` may be a contiguous
+    fp32 (cols,) destination."""
+    b16 = x.dtype == torch.bfloat16
+    ok = (x.dim() == 2 and x.is_contiguous() and x.is_cuda and (x.dtype == torch.float32 or b16)
+          and os.environ.get("MEMOTR_FUSED_CLIP_OPS", "1") != "0"
           and (out is None or (out.is_contiguous() and out.dtype == torch.float32))
-          and x.shape[0] <= COLSUM_MAX_ROWS * COLSUM_CHUNK_ROWS)
+          and 0 < x.shape[0] <= COLSUM_MAX_ROWS * COLSUM_CHUNK_ROWS)
     if not ok:
         return torch.sum(x, 0, out=out) if out is not None else x.sum(0)
-    if x.shape[0] > COLSUM_MAX_ROWS and os.environ.get("MEMOTR_COLSUM_TALL", "1") == "0":
+    if x.shape[0] > COLSUM_MAX_ROWS and not b16 and os.environ.get("MEMOTR_COLSUM_TALL", "1") == "0":
         return torch.sum(x, 0, out=out) if out is not None else x.sum(0)
     L = _lib()
-    if x.shape[0] > COLSUM_MAX_ROWS:
+    if x.shape[0] > COLSUM_MAX_ROWS or b16:
         chunks = -(-x.shape[0] // COLSUM_CHUNK_ROWS)
         partial = torch.empty((chunks, x.shape[1]), dtype=torch.float32, device=x.device)
-        L.check(L.lib.clipops_colsum_partial_f32(x.data_ptr(), x.shape[0], x.shape[1], COLSUM_CHUNK_ROWS,
-                                                 partial.data_ptr(), _stream(x)), "clipops_colsum_partial_f32")
+        fn = L.lib.clipops_colsum_partial_bf16 if b16 else L.lib.clipops_colsum_partial_f32
+        L.check(fn(x.data_ptr(), x.shape[0], x.shape[1], COLSUM_CHUNK_ROWS, partial.data_ptr(), _stream(x)),
+                "clipops_colsum_partial")
         x = partial
     if out is None:
         out = torch.empty((x.shape[1],), dtype=torch.float32, device=x.device)
     L.check(L.lib.clipops_colsum_f32(x.data_ptr(), x.shape[0], x.shape[1], out.data_ptr(), _stream(x)),
             "clipops_colsum_f32")
     return out
+
+
+class _AddRowBias(torch.autograd.Function):
+    """x (..., C) + bias (C,): the bias gradient through the tiled column sums instead of torch's reduction."""
+
+    @staticmethod
+    def forward(ctx, x, bias):
+        return x + bias
+
+    @staticmethod
+    def backward(ctx, g):
+        gb = None
+        if ctx.needs_input_grad[1]:
+            g2 = g.reshape(-1, g.shape[-1])
+            gb = colsum(g2 if g2.is_contiguous() else g2.contiguous())
+        return (g if ctx.needs_input_grad[0] else None), gb
+
+
+def add_row_bias(x: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    if x.is_cuda and bias.requires_grad and torch.is_grad_enabled() and bias.dim() == 1:
+        return _AddRowBias.apply(x, bias)
+    return x + bias
 
 
 # --------------------------------------------------------------------------------------------------------------

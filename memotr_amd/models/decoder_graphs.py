@@ -106,11 +106,53 @@ def _thread_local_capture():
             kwargs.setdefault("capture_error_mode", "thread_local")
             super().__init__(*args, **kwargs)
 
+        def __exit__(self, *exc):
+            out = super().__exit__(*exc)
+            if exc[0] is None and CENSUS is not None:
+                CENSUS.append(graph_node_census(self.cuda_graph))
+            return out
+
+    orig_graph_cls = torch.cuda.CUDAGraph
+    if CENSUS is not None:       # (the raw hipGraph_t only survives capture_end when asked for)
+        torch.cuda.CUDAGraph = lambda *a, **k: orig_graph_cls(keep_graph=True)
     torch.cuda.graph = _Graph
     try:
         yield
     finally:
         torch.cuda.graph = orig
+        torch.cuda.CUDAGraph = orig_graph_cls
+
+
+# MEMOTR_GRAPH_CENSUS=1: every capture appends {node type: count} of its hipGraph here (tools/graph_census.py, the GPU
+# tests).  What it is for: on ROCm 7.2 a MEMSET node is not ordered behind the kernels before it when a graph is
+# replayed with the runtime's AQL-packet capture on (the default) -- tools/graph_memset_probe.py shows it in ten
+# lines, DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 restores the order.  torch's multi-block reductions zero their semaphores
+# with such a node (bias gradients of captured linears came back as garbage from the second replay on), so nothing
+# inside the captured regions may reduce through them: the census is how the tests hold the graphs to ZERO memset
+# nodes, whatever the runtime flag says.
+CENSUS = [] if os.environ.get("MEMOTR_GRAPH_CENSUS", "0") == "1" else None
+_NODE_TYPES = {0: "kernel", 1: "memcpy", 2: "memset", 3: "host", 4: "graph", 5: "empty", 6: "wait_event",
+               7: "event_record"}
+
+
+def graph_node_census(cuda_graph) -> dict:
+    """{node type: count} of a ``torch.cuda.CUDAGraph`` created with ``keep_graph=True``."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    raw = ctypes.c_void_p(cuda_graph.raw_cuda_graph())
+    n = ctypes.c_size_t(0)
+    if hip.hipGraphGetNodes(raw, None, ctypes.byref(n)) != 0:
+        return {"error": 1}
+    nodes = (ctypes.c_void_p * max(n.value, 1))()
+    if hip.hipGraphGetNodes(raw, nodes, ctypes.byref(n)) != 0:
+        return {"error": 1}
+    out = {}
+    for i in range(n.value):
+        t = ctypes.c_int(-1)
+        hip.hipGraphNodeGetType(ctypes.c_void_p(nodes[i]), ctypes.byref(t))
+        name = _NODE_TYPES.get(t.value, f"type{t.value}")
+        out[name] = out.get(name, 0) + 1
+    return out
 
 
 def enabled() -> bool:
@@ -177,7 +219,7 @@ class DecoderGraphs:
         else:
             self._misses = 0
             self.slots.move_to_end(key)
-        fn, params = slot
+        fn, params = slot[0], slot[1]
         self.replays += 1
         return fn(*args, self._flat_parameters(params, clip_key))
 

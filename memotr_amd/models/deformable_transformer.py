@@ -9,6 +9,8 @@ import torch.nn as nn
 from torch.nn.init import constant_, normal_, xavier_uniform_
 from torch.utils.checkpoint import checkpoint
 
+from ..functions.clip_ops import add_row_bias
+
 from .. import MultiScaleDeformableAttention as MSDA
 from ..modules import MSDeformAttn
 from .deformable_decoder import DeformableDecoder, DeformableDecoderLayer
@@ -104,7 +106,7 @@ class DeformableTransformer(nn.Module):
         shapes_list = [(int(s.shape[2]), int(s.shape[3])) for s in srcs]
         src_flatten = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)                 # (B, S, C)
         lvl_pos_embed_flatten = torch.cat(
-            [p.flatten(2).transpose(1, 2) + self.level_embed[lvl].view(1, 1, -1) for lvl, p in enumerate(pos_embeds)],
+            [add_row_bias(p.flatten(2).transpose(1, 2), self.level_embed[lvl]) for lvl, p in enumerate(pos_embeds)],
             1)
         spatial_shapes, level_start_index = self._pyramid_tensors(shapes_list, src_flatten.device)
         key = None if geometry is None else (geometry, tuple(shapes_list), str(src_flatten.device))

@@ -95,12 +95,34 @@ class MeMOTR(nn.Module):
         result, ``model(tracks=t, encoded=enc)`` finishes the frame.  Both go through ``forward`` so a
         DistributedDataParallel wrapper sees every call."""
         if encoded is None:
-            encoded = self.encode_frame(frame)
-        if stage == "encode":
+            encoded = self._encode_frame_eager(frame) if stage == "encode_eager" else self.encode_frame(frame)
+        if stage in ("encode", "encode_eager"):
             return encoded
         return self.decode_frame(encoded, tracks)
 
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state.pop("_encode_graphs", None)          # captured hipGraphs are per-process objects
+        return state
+
+    def encode_graphs(self):
+        g = self.__dict__.get("_encode_graphs")
+        if g is None:
+            from .encode_graphs import EncodeGraphs
+            g = self.__dict__["_encode_graphs"] = EncodeGraphs(self)
+        return g
+
     def encode_frame(self, frame: NestedTensor) -> dict:
+        """Backbone -> feature projections -> encoder (independent of the track queries); replayed from a hipGraph
+        pair where that pays (models/encode_graphs.py: the launch-bound bf16 step), else kernel by kernel."""
+        graphs = self.encode_graphs()
+        if graphs.usable(frame):
+            enc = graphs.run(frame, getattr(frame, "encode_slot", 0))
+            if enc is not None:
+                return enc
+        return self._encode_frame_eager(frame)
+
+    def _encode_frame_eager(self, frame: NestedTensor) -> dict:
         """Backbone -> feature projections -> encoder (independent of the track queries)."""
         if self.use_checkpoint and self.checkpoint_level != 3:
             features, pos = checkpoint(self.backbone, frame, use_reentrant=False)

@@ -72,17 +72,27 @@ def _pick_chunks(rows: int) -> int:
 FUSE_RELU_EPILOGUE = os.environ.get("MEMOTR_FUSE_RELU", "1") != "0"
 
 
+AMP_SPLITK = os.environ.get("MEMOTR_AMP_SPLITK", "1") != "0"      # autocast: long linears keep the split-K node
+AMP_MIN_ROWS = 256       # ... from this many rows on (below, torch's bias-gradient reduction is a single block)
+
+
 class _SplitKLinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, relu=False):
         ctx.has_bias = bias is not None
         ctx.relu = bool(relu)
-        if ctx.relu:
-            y = torch._addmm_activation(bias, x, weight.t(), use_gelu=False)      # relu(x W^T + b), one kernel
-            ctx.save_for_backward(x, weight, y)
-            return y
-        ctx.save_for_backward(x, weight)
-        return F.linear(x, weight, bias)
+        xc, wc, bc = x, weight, bias
+        if torch.is_autocast_enabled() and x.is_cuda:     # explicit casts, then autocast off: one cast per operand
+            dt = torch.get_autocast_dtype("cuda")
+            xc, wc = x.to(dt), weight.to(dt)
+            bc = None if bias is None else bias.to(dt)
+        with torch.autocast("cuda", enabled=False) if x.is_cuda else contextlib.nullcontext():
+            if ctx.relu:
+                y = torch._addmm_activation(bc, xc, wc.t(), use_gelu=False)      # relu(x W^T + b), one kernel
+                ctx.save_for_backward(x, weight, y)
+                return y
+            ctx.save_for_backward(x, weight)
+            return F.linear(xc, wc, bc)
 
     @staticmethod
     def backward(ctx, grad_out):
@@ -152,13 +162,14 @@ class _RowLinear(torch.autograd.Function):
 
 
 def row_linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor = None, relu: bool = False) -> torch.Tensor:
-    """F.linear (``relu=True``: followed by ReLU); on CUDA fp32 tensors with up to COLSUM_MAX_ROWS rows and a gradient
-    to compute it runs as ``_RowLinear`` (same products, ReLU in the GEMM epilogue, bias gradient through the
-    column-sum kernel)."""
+    """F.linear (``relu=True``: followed by ReLU); on CUDA fp32 tensors with a gradient to compute it runs as
+    ``_RowLinear`` (same products, ReLU in the GEMM epilogue, bias gradient through the column-sum kernels -- one
+    pass up to COLSUM_MAX_ROWS rows, two above; torch's multi-block reduction is kept out of captured regions, see
+    models/encode_graphs.py)."""
     from ..functions import clip_ops
     if (bias is not None and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32
             and torch.is_grad_enabled() and (weight.requires_grad or x.requires_grad)
-            and not torch.is_autocast_enabled() and x.numel() // max(x.shape[-1], 1) <= clip_ops.COLSUM_MAX_ROWS
+            and not torch.is_autocast_enabled() and x.numel() // max(x.shape[-1], 1) <= clip_ops.COLSUM_MAX_ROWS * clip_ops.COLSUM_CHUNK_ROWS
             and clip_ops.fused(x)):
         if relu and not FUSE_RELU_EPILOGUE:
             return torch.relu(_RowLinear.apply(x, weight, bias, False))
@@ -174,12 +185,16 @@ def long_linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor = None
     VIEW of a custom Function's output makes autograd rebase the graph (CopySlices) and copy the whole gradient --
     three passes over the 22,323 x 2048 x frames FFN activation per layer (8 ms per train step, measured)."""
     rows = x.numel() // x.shape[-1]
-    if (rows >= (MIN_ROWS if min_rows is None else min_rows) and torch.is_grad_enabled() and weight.requires_grad
-            and x.dtype == weight.dtype and not torch.is_autocast_enabled()):   # mixed precision keeps the library path
+    amp = torch.is_autocast_enabled() and x.is_cuda and bias is not None and AMP_SPLITK
+    floor = AMP_MIN_ROWS if amp else (MIN_ROWS if min_rows is None else min_rows)
+    if (rows >= floor and torch.is_grad_enabled() and weight.requires_grad
+            and (amp or (x.dtype == weight.dtype and not torch.is_autocast_enabled()))):
         # 2-d in, 2-d out: the Function's output is then a fresh tensor (an N-d F.linear returns a view, and a
         # view made inside a custom Function may not be modified in place -- the FFN applies ReLU in place)
         fuse = (FUSE_RELU_EPILOGUE and isinstance(activation, torch.nn.ReLU) and bias is not None and x.is_cuda
-                and x.dtype == torch.float32)
+                and (x.dtype == torch.float32 or amp))
+        # under autocast (round 3) the same node runs with explicit casts: its bias gradient then goes through the
+        # tiled column sums -- torch's multi-block reduction returned garbage inside replayed hipGraphs
         y = _SplitKLinear.apply(x.reshape(rows, x.shape[-1]), weight, bias, fuse)
         if activation is not None and not fuse:
             y = activation(y)

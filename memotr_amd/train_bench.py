@@ -125,4 +125,6 @@ def run_train(args, rank: int, world: int, clip_len: int = None, height: int = 8
 
 def _graph_stats(model) -> dict:
     g = getattr(model, "module", model).transformer.decoder.graphs()
-    return {"captures": g.captures, "replays": g.replays, "eager": g.eager, "failed": bool(g.failed)}
+    e = getattr(model, "module", model).encode_graphs()
+    return {"captures": g.captures, "replays": g.replays, "eager": g.eager, "failed": bool(g.failed),
+            "encode_captures": e.captures, "encode_replays": e.replays, "encode_eager": e.eager}
