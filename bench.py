@@ -442,6 +442,12 @@ def main():
             # measured); the exhaustive find costs minutes once per process but is worth it there.  At 800x1344 both
             # modes pick the same kernels, so the default line keeps the quick start-up.
             os.environ.setdefault("MEMOTR_MIOPEN_FIND", "1")
+            # the find results of this pyramid (fp32 and bf16) measured on MI355X travel with the package: MIOpen
+            # answers from its user find-db instead of benchmarking every solver again (9 minutes -> the compile time
+            # of the picked kernels)
+            db = os.path.join(ROOT, "memotr_amd", "tuning", "miopen_db")
+            if os.path.isdir(db):
+                os.environ.setdefault("MIOPEN_USER_DB_PATH", db)
         result = run_train(args, rank, world, clip_len=args.clip_len or max(cfg["SAMPLE_LENGTHS"]), height=hw[0],
                            width=hw[1], config=cfg, dtype=args.dtype)
         if rank == 0:   # the kernel roofline and the CPU fallback baseline ride along on rank 0
