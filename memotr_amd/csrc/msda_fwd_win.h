@@ -47,7 +47,8 @@ struct WinPlan {
     float rcpH[kWinMaxL], rcpW[kWinMaxL], rcpP;   // correctly rounded 1/H, 1/W, 1/P (div_small)
     unsigned value_bytes;
     int n_blocks;
-    int ablate;                    // profiling only (msda_set_option "fwd_win_ablate"): 1 stop after the prologue, 2 no gather
+    int ablate;                    // profiling only (msda_set_option "fwd_win_ablate"): 1 stop after the prologue, 2 no gather,
+                                   // 4 write per (row, point) 2 = left its window / 1 = served from it / 0 into `out` (use 6)
 };
 
 struct WinTables {
@@ -437,6 +438,12 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
                 ok01 = ok01 && !c_mask[ok01 ? cell + 1 : 0];
                 ok10 = ok10 && !c_mask[ok10 ? cell + cW : 0];
                 ok11 = ok11 && !c_mask[ok11 ? cell + cW + 1 : 0];
+            }
+            if (pl.ablate & 4) {      // profiling only (tools/fwd_offset_sweep.py): which points left their window
+                const int qq = s_rowq[step * 4 + s_rs];
+                if (c_pt && qq >= 0)
+                    out[(size_t)((q_base + (unsigned)qq) * (unsigned)M + (unsigned)m) * 32u + (unsigned)s_t] =
+                        (need && c_windowed) ? 2.f : ((live && c_windowed) ? 1.f : 0.f);
             }
             const unsigned o00 = c_lbase + (unsigned)cell * pix_stride;
             ra.y = inwin ? lbase : (need ? (ok00 ? o00 : kOobOffset) | c_flag : c_dead);

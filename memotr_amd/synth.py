@@ -86,11 +86,13 @@ def star_offsets(n_heads: int, n_levels: int, n_points: int) -> torch.Tensor:
 def make_inputs(height: int = 800, width: int = 1333, n_queries: int | None = None, batch: int = 1,
                 n_heads: int = 8, head_dim: int = 32, n_levels: int = 4, n_points: int = 4,
                 dist: str = "encoder_like", jitter: float = 1.0, seed: int = 3, dtype=torch.float32,
-                device="cpu", value_dist: str = "normal"):
+                device="cpu", value_dist: str = "normal", off_scale: float = 1.0):
     """Returns dict(value, shapes, level_start, loc, attn, grad_out, shapes_list).
 
     ``n_queries=None`` means one query per pyramid pixel (encoder self-attention, Lq = S);
-    otherwise decoder-style queries with random reference boxes.
+    otherwise decoder-style queries with random reference boxes.  ``off_scale`` multiplies the whole sampling offset
+    (star + noise) of the "encoder_like" pattern: 1.0 is the initialisation (star arms of 1..4 pixels), a trained
+    model's offsets are larger (tools/fwd_offset_sweep.py).
     """
     g = torch.Generator().manual_seed(seed)
     shapes = pyramid_shapes(height, width, n_levels)
@@ -112,6 +114,7 @@ def make_inputs(height: int = 800, width: int = 1333, n_queries: int | None = No
             centre = torch.rand(Lq, 1, 2, generator=g) * 0.8 + 0.1
             ref = centre * vr[None]                                           # (Lq,L,2)
         off = star_offsets(M, L, P)[None] + jitter * torch.randn(Lq, M, L, P, 2, generator=g)
+        off = off * off_scale
         loc = ref[:, None, :, None, :] + off / wh[None, None, :, None, :]
         loc = loc[None].expand(batch, -1, -1, -1, -1, -1).contiguous()
     else:
