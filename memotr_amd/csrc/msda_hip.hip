@@ -1955,7 +1955,9 @@ thread_local const char *g_kernel = "";
 std::atomic<int> opt_fwd_variant{0}, opt_bwd_variant{0};
 std::atomic<int> opt_fwd_block{256}, opt_bwd_block{256};
 std::atomic<int> opt_fwd_grid_mult{32}, opt_bwd_grid_mult{16};
-std::atomic<int> opt_fwd_tile_margin{3}, opt_bwd_tile_margin{3};
+// (backward margin 4, round 3: +1 % at the initialisation's offsets, -21 / -37 % when they are 1.5x / 2x larger,
+//  profiles/r03_bwd_margin_sweep.txt)
+std::atomic<int> opt_fwd_tile_margin{3}, opt_bwd_tile_margin{4};
 std::atomic<int> opt_fwd_tile_l0{1};      // hybrid forward: first level served from LDS windows
 std::atomic<int> opt_bwd_split{1};        // fused backward with a workspace: prologue kernel + plain tiled kernel + finish kernel
 std::atomic<int> opt_bwd_wide_log2{12};   // tiled backward: row-magnitude range (log2) that makes a region "wide"; 0 = off

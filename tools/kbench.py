@@ -21,7 +21,7 @@ from memotr_amd.synth import make_inputs  # noqa: E402
 
 
 def reset():
-    for k, v in (("fwd_variant", 0), ("bwd_variant", 0), ("fwd_tile_margin", 3), ("bwd_tile_margin", 3),
+    for k, v in (("fwd_variant", 0), ("bwd_variant", 0), ("fwd_tile_margin", 3), ("bwd_tile_margin", 4),
                  ("fwd_tile_l0", 1), ("fwd_block", 256), ("fwd_grid_mult", 32), ("bwd_split", 1),
                  ("fwd_win_rlog", 3), ("fwd_win_rlogx", 3), ("fwd_win_block", 256), ("fwd_win_l0", 1), ("fwd_win_margins", 0x3333),
                  ("fwd_win_dma", 1), ("fwd_head_major", 0), ("fwd_win_early", 2), ("fwd_win_wps", 0),
@@ -98,7 +98,7 @@ def main():
                 bwd_cfgs.append(("v0 rows block=256", dict(bwd_variant=0, bwd_rows_block=256)))
             if enc:
                 for v in ((8, 9, 10, 11) if args.old else (10,)):
-                    for mg in ((2, 3, 4) if not args.quick else (3,)):
+                    for mg in ((3, 4, 5) if not args.quick else (4,)):
                         bwd_cfgs.append((f"v{v} {'tile_q2' if v < 10 else 'tile_lv'} m{mg}",
                                          dict(bwd_variant=v, bwd_tile_margin=mg)))
                         if v >= 10:     # fused call without the three-kernel split (the plain call ignores the knob)
