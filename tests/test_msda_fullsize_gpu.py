@@ -198,15 +198,16 @@ def test_fixed_point_window_accumulation_outlier_row_and_small_rows(msda, hip_li
 
 
 def test_fixed_point_smooth_in_region_spread_is_bounded_by_the_local_magnitude(msda, hip_lib):
-    """Row magnitudes that ramp by up to 2^11 INSIDE every region (a 16-pixel sawtooth of the exponent on the finest
-    level) under a slow envelope of 2^0 .. 2^10 across the image -- the spread real encoder gradients show.  Such
-    regions are "wide": rows within 7 bits of the region's bounds accumulate in fixed point (quantum 2^-21 of the
-    bound), smaller ones go out as float atomics.  Stated bound, checked per value cell: |error| <= 2^-12 x (largest
-    row magnitude within 32 finest-level pixels of the cell = the reach of a region plus its window margin) x
-    max|attn| -- the error follows the LOCAL gradient scale (which varies by 2^10 over this image), never the global
-    maximum (measured: 2^-12.7 of the local, 2^-17.5 of the global scale); relative to the cell's own
-    |contribution| mass the median error is below 2^-18 and the 99th percentile below 2^-11 (measured 2^-18.6,
-    2^-11.9: the cells with a large relative error are the ones whose own mass is small next to their neighbours')."""
+    """Row magnitudes that ramp by 2^8 .. 2^10 INSIDE every 8 x 8 region (a 16-pixel diagonal sawtooth of the exponent
+    on the finest level, 11 bits per period) under a slow envelope of 2^0 .. 2^10 across the image -- the spread real
+    encoder gradients show.  Such regions stay on the fixed-point path (only a spread of >= 2^12 makes a region
+    "wide"): every contribution is rounded to 2^-21 of its region's channel x level bound.  Stated bound, checked per
+    value cell: |error| <= 2^-12 x (largest row magnitude within 32 finest-level pixels of the cell = the reach of a
+    region plus its window margin) x max|attn| -- the error follows the LOCAL gradient scale (which varies by 2^10
+    over this image), never the global maximum (measured: 2^-12.7 of the local, 2^-17.5 of the global scale);
+    relative to the cell's own |contribution| mass the median error is below 2^-18 and the 99th percentile below
+    2^-11 (measured 2^-18.6, 2^-11.9: the cells with a large relative error are the ones whose own mass is small next
+    to their neighbours')."""
     import torch.nn.functional as F
     x = _small_pyramid_inputs(seed=35, height=640, width=896)
     shapes = x["shapes_list"]
