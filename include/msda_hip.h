@@ -191,7 +191,13 @@ int msda_fused_points_f32(const int64_t *shapes_dev, const float *proj, int proj
  *       kernels, >=2 = specialised kernels), "fwd_block" | "bwd_block"
  *       (threads per block, multiple of 64), "fwd_grid_mult" | "bwd_grid_mult" (blocks per CU),
  *       "fwd_tile_margin" | "bwd_tile_margin" (LDS window margin in pixels), "fwd_tile_l0" (first pyramid level the
- *       hybrid forward serves from LDS), "bwd_split" (1 = the three-kernel fused backward when a workspace is given).
+ *       hybrid forward serves from LDS), "bwd_split" (1 = the three-kernel fused backward when a workspace is given),
+ *       "fwd_win_auto" (1 = fp32 self-attention over the pyramid takes the windowed forward, variant 12; 0 = the
+ *       gather kernel, the better choice once trained sampling offsets exceed the windows' 3-pixel margins),
+ *       "fwd_win_*" (region size, block size, margins per level as 0xL3L2L1L0, first windowed level, LDS-DMA fill,
+ *       profiling switches; tools/kbench.py lists them), "fwd_head_major" (head-major block numbering of the gather
+ *       kernel), "bwd_rows" / "bwd_rows_block" (the 32-lanes-per-row backward of decoder-shaped calls),
+ *       "bwd_wide_log2", "bwd_ablate" / "fwd_win_ablate" (profiling only: results are wrong by construction).
  * Returns MSDA_OK or MSDA_EINVAL for an unknown key / bad value. */
 int msda_set_option(const char *key, int value);
 int msda_get_option(const char *key, int *value);

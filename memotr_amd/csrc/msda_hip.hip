@@ -13,8 +13,12 @@
 // C ABI: include/msda_hip.h.  Design notes, byte counts and rooflines: DESIGN.md.
 //
 // Variant numbers (msda_set_option "fwd_variant" / "bwd_variant"; 0 = auto):
-//   forward : 1 generic | 2,3,4 d32 gather with 2,4,1 points in flight | 8,9 region-tiled hybrid
-//             (level 0 through the vector L1, coarser levels from LDS windows; 4 / 2 global points in flight)
+//   forward : 0 auto (fp32 pyramid self-attention with host shapes: 12 unless "fwd_win_auto" is 0; other D = 32
+//             calls: 3) | 1 generic | 2,3,4 d32 gather with 2,4,1 points in flight | 8,9 region-tiled hybrid
+//             (level 0 through the vector L1, coarser levels from LDS windows; 4 / 2 global points in flight; round 2,
+//             slower) | 12 msda_fwd_d32_win (msda_fwd_win.h, round 3): (batch, head, 8x8-pixel region) per workgroup,
+//             windows of levels 1-3 filled by LDS-DMA around the measured mean offset, level 0 through the vector L1,
+//             pixel-pair LDS reads, one head per XCD
 //   backward: 0 auto (pyramid self-attention: 10; other D = 32 calls: msda_bwd_d32_rows, 32 lanes per row) | 1 generic |
 //             8,9 region-tiled fixed-point windows, all levels of a region per workgroup (2 / 4 points
 //             in flight) | 10,11 region-tiled fixed-point windows, one pyramid level per workgroup, inputs loaded once
@@ -24,6 +28,8 @@
 //               (forward) or one block per (n,q,m) row (backward).  Correctness path for
 //               shapes the specialised kernels do not cover (reference gradcheck sizes
 //               D in {30,64,71,1025,...}).
+//   *_d32_win / *_d32_tile_* / *_d32_rows   region- or row-organised specialisations, described at their definitions
+//               (msda_fwd_win.h, below, msda_bwd_rows.h)
 //   *_d32       MeMOTR geometry (D = 32 channels/head): the lanes that own one (n,q,m) row hold its
 //               32 channels (8 lanes x 4 fp32 channels, 4 lanes x 8 bf16 channels).  Each lane prepares
 //               the sampling record of a share of the row's L*P points exactly once, parks it in LDS, and the
