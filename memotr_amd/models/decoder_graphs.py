@@ -94,12 +94,14 @@ class DecoderLoop(nn.Module):
 
 
 @contextlib.contextmanager
-def _thread_local_capture():
+def _thread_local_capture(census=None):
     """``make_graphed_callables`` captures in the "global" error mode: ANY thread that touches the runtime while a
     capture is open (the RCCL watchdog polling its events under DistributedDataParallel, a data-loader thread pinning
     memory) invalidates it.  The decoder capture only needs the capturing threads themselves to behave, so the graph
-    context is switched to "thread_local" for its duration."""
+    context is switched to "thread_local" for its duration.  ``census`` (a list, default: the module's ``CENSUS``)
+    receives {node type: count} of every graph captured inside."""
     orig = torch.cuda.graph
+    CENSUS = census if census is not None else globals()["CENSUS"]
 
     class _Graph(orig):
         def __init__(self, *args, **kwargs):
@@ -133,6 +135,55 @@ def _thread_local_capture():
 CENSUS = [] if os.environ.get("MEMOTR_GRAPH_CENSUS", "0") == "1" else None
 _NODE_TYPES = {0: "kernel", 1: "memcpy", 2: "memset", 3: "host", 4: "graph", 5: "empty", 6: "wait_event",
                7: "event_record"}
+
+
+_MEMSET_SAFE = None
+
+
+def memset_nodes_replay_safe() -> bool:
+    """Does THIS process's HIP runtime order a memset node behind the kernels before it when a graph is replayed?
+    (tools/graph_memset_probe.py in miniature, run once: kernel dirties a buffer | memset | kernel reads it.)  False
+    on ROCm 7.2 unless DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 was in the environment when the runtime loaded."""
+    global _MEMSET_SAFE
+    if _MEMSET_SAFE is None:
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        n = 1 << 16
+        dev = torch.device("cuda", torch.cuda.current_device())
+        buf, x, out = torch.zeros(n, device=dev), torch.ones(n, device=dev), torch.empty(n, device=dev)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            buf.add_(1.0)
+            torch.add(buf, x, out=out)
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            buf.add_(1.0)
+            rc = hip.hipMemsetAsync(ctypes.c_void_p(buf.data_ptr()), 0, ctypes.c_size_t(n * 4),
+                                    ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+            torch.add(buf, x, out=out)
+            buf.add_(3.0)
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        _MEMSET_SAFE = rc == 0 and bool((out == x).all())
+    return _MEMSET_SAFE
+
+
+def checked_capture(make):
+    """Run ``make()`` (a ``make_graphed_callables`` call) in thread-local capture mode.  When this runtime does not
+    order memset nodes on replay, the captured graphs are inspected and a graph that contains one is refused -- a
+    library may zero a workspace that way (the bf16 encode backward at 800 x 1333 holds six such nodes), and replaying
+    it would corrupt results silently."""
+    census = [] if (CENSUS is None and not memset_nodes_replay_safe()) else None
+    with _thread_local_capture(census):
+        fn = make()
+    bad = [c for c in (census or []) if c.get("memset", 0) or "error" in c]
+    if bad:
+        raise RuntimeError(f"captured graph contains memset nodes {bad} and this HIP runtime does not order them on "
+                           "replay: set DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in the environment before torch is imported")
+    return fn
 
 
 def graph_node_census(cuda_graph) -> dict:
@@ -274,8 +325,8 @@ class DecoderGraphs:
             flat = torch.cat([p.reshape(-1) for p in params])
         sample = tuple(a.detach().clone().requires_grad_(a.requires_grad) for a in args) + (flat.requires_grad_(True),)
         try:
-            with _thread_local_capture():
-                fn = torch.cuda.make_graphed_callables(run, sample, num_warmup_iters=2, allow_unused_input=True)
+            fn = checked_capture(lambda: torch.cuda.make_graphed_callables(run, sample, num_warmup_iters=2,
+                                                                           allow_unused_input=True))
         except Exception as exc:  # noqa: BLE001 -- capture is an optimisation; eager stays valid
             if require_graphs():
                 raise RuntimeError(f"decoder graph capture failed and MEMOTR_REQUIRE_GRAPHS=1: "

@@ -24,7 +24,7 @@ import torch
 
 from ..functions import clip_ops
 from ..utils.nested_tensor import NestedTensor
-from .decoder_graphs import MISS_LIMIT, RETRY_AFTER, _thread_local_capture, require_graphs
+from .decoder_graphs import MISS_LIMIT, RETRY_AFTER, checked_capture, require_graphs
 
 MAX_GRAPHS = 6           # each holds the activations of a whole batched encode
 
@@ -144,8 +144,9 @@ class EncodeGraphs:
         sample = (frame.tensors.detach().clone(), flat.requires_grad_(True))
         try:
             # (make_graphed_callables refuses an ambient autocast with its cast cache on; `run` opens its own)
-            with _thread_local_capture(), torch.autocast("cuda", enabled=False):
-                fn = torch.cuda.make_graphed_callables(run, sample, num_warmup_iters=2, allow_unused_input=True)
+            with torch.autocast("cuda", enabled=False):
+                fn = checked_capture(lambda: torch.cuda.make_graphed_callables(run, sample, num_warmup_iters=2,
+                                                                               allow_unused_input=True))
         except Exception as exc:  # noqa: BLE001 -- capture is an optimisation; eager stays valid
             if require_graphs():
                 raise RuntimeError(f"encode graph capture failed and MEMOTR_REQUIRE_GRAPHS=1: "

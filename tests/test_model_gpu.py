@@ -4,6 +4,8 @@ The CPU twins of these checks (tests/test_model_golden.py) inject the oracle as 
 injected -- ``MSDeformAttn`` calls the gfx950 kernels through the C ABI -- and the same golden vectors
 (produced by the reference on CPU, tests/golden/gen_golden_model.py) must still be met.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -298,14 +300,14 @@ def test_fused_bias_relu_epilogue_is_bit_identical():
 
 
 # ----------------------------------------------------------------------------- decoder hipGraphs
-def _d32_clip_step(monkeypatch, graphs: bool, clip_len=3, seed=0, **cfg_over):
+def _d32_clip_step(monkeypatch, graphs: bool, clip_len=3, seed=0, require=None, **cfg_over):
     """One clip train step of a D = 32 model (specialised kernels) with the decoder graphs on or off; returns
     (loss, {param: grad}, decoder graph cache)."""
     from memotr_amd.engine import clip_forward_backward, make_synthetic_clip, clip_to_device
     from memotr_amd.models.criterion import build as build_criterion
     import memotr_amd.modules.ms_deform_attn as mod
     monkeypatch.setenv("MEMOTR_DECODER_GRAPHS", "1" if graphs else "0")
-    monkeypatch.setenv("MEMOTR_REQUIRE_GRAPHS", "1" if graphs else "0")
+    monkeypatch.setenv("MEMOTR_REQUIRE_GRAPHS", "1" if (graphs if require is None else require) else "0")
     torch.manual_seed(seed)
     model = build_memotr_cuda(None, hidden=256, ffn=256, NUM_ENC_LAYERS=1, NUM_DEC_LAYERS=2, **cfg_over).train()
     with torch.no_grad():
@@ -339,6 +341,31 @@ def test_decoder_graphs_are_captured_and_match_the_eager_loop(monkeypatch):
         denom = float(grads_e[n].norm()) + 1e-6
         # float atomics in the operator backward make both runs order-dependent at the 1e-3 level
         assert float((grads_g[n] - grads_e[n]).norm()) / denom < 2e-2, n
+
+
+def test_memset_nodes_are_ordered_on_replay_in_the_test_environment():
+    """conftest.py sets DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 before torch loads the HIP runtime: with it a memset node of a
+    replayed graph runs where it was captured (kernel | memset | kernel probe); without it ROCm 7.2 runs it first."""
+    from memotr_amd.models import decoder_graphs as dg
+    assert os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0"
+    assert dg.memset_nodes_replay_safe()
+
+
+def test_a_capture_holding_memset_nodes_is_refused_when_the_runtime_misorders_them(monkeypatch):
+    """On a runtime that fails the probe every captured graph is inspected, and one with a memset node (a library
+    zeroing a workspace) is an error under MEMOTR_REQUIRE_GRAPHS=1 and an eager fallback otherwise -- never replayed."""
+    from memotr_amd.models import decoder_graphs as dg
+    monkeypatch.setattr(dg, "_MEMSET_SAFE", False)
+    monkeypatch.setattr(dg, "graph_node_census", lambda g: {"kernel": 7, "memset": 1})
+    with pytest.raises(RuntimeError, match="DEBUG_CLR_GRAPH_PACKET_CAPTURE"):
+        _d32_clip_step(monkeypatch, True, clip_len=2)
+    with pytest.warns(UserWarning, match="memset"):
+        loss, grads, cache = _d32_clip_step(monkeypatch, True, clip_len=2, require=False)
+    assert cache.failed and cache.captures == 0 and cache.replays == 0 and np.isfinite(loss)
+    # and a clean census passes on the same runtime
+    monkeypatch.setattr(dg, "graph_node_census", lambda g: {"kernel": 7})
+    loss, grads, cache = _d32_clip_step(monkeypatch, True, clip_len=2)
+    assert cache.captures == 2 and not cache.failed
 
 
 def test_decoder_graph_key_is_the_geometry_not_the_tensor_object(monkeypatch):
