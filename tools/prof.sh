@@ -9,7 +9,8 @@ OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 WORKLOAD=${2:-train}
-CMD="python bench.py --workload $WORKLOAD --steps 3 --warmup 2 --no-cpu-baseline"
+# PROF_ARGS: extra bench.py flags, e.g. "--dtype bf16", "--config mot17 --use-checkpoint", "--config bdd100k --dtype bf16"
+CMD="python bench.py --workload $WORKLOAD --steps 3 --warmup 2 --no-cpu-baseline ${PROF_ARGS:-}"
 # MIOpen benchmarks every applicable solver (its naive reference kernels included) the first time a process on this
 # box meets a convolution shape and stores the pick in ~/.config/miopen (MIOPEN_FIND_MODE DYNAMIC_HYBRID).  On a fresh
 # box the profiled process would be that first process and its kernel table would be the find phase, not the train
