@@ -58,6 +58,8 @@ def parse_args():
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores")
     # BASELINE.json configs 4 / 5 (secondary; the default line is config 2: DanceTrack, fp32, no checkpointing)
     ap.add_argument("--config", default="dancetrack", choices=["dancetrack", "mot17", "bdd100k"])
+    ap.add_argument("--no-lookahead", action="store_true",
+                    help="infer workload: do not queue the next frame's encode half ahead")
     ap.add_argument("--use-checkpoint", action="store_true", help="activation checkpointing (CHECKPOINT_LEVEL 2)")
     ap.add_argument("--clip-len", type=int, default=0, help="0 = longest clip of the config")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="bf16 = autocast extension (config 5)")
@@ -362,9 +364,11 @@ def run_infer(args, rank, world):
     tracker.tracker.track_score_thresh = 0.0
     tracker.step(frames[0], hw[0], hw[1])
     tracker.tracker.det_score_thresh = 2.0            # no further births: the live set stays at n_track
+    # (the timed loop starts with frames[warmup % 4] already queued by the last warm-up step)
 
-    def step(i):
-        return tracker.step(frames[i % len(frames)], hw[0], hw[1])
+    def step(i):        # a recorded sequence: the next frame is known, its encode half is queued ahead (inference.py)
+        nxt = frames[(i + 1) % len(frames)] if not args.no_lookahead else None
+        return tracker.step(frames[i % len(frames)], hw[0], hw[1], next_image=nxt)
 
     for i in range(args.warmup):
         step(i)
@@ -390,7 +394,14 @@ def run_infer(args, rank, world):
                    "live_tracks": int(len(tracker.tracks[0])), "reported_tracks": int(len(out)),
                    "parallelism": f"dp{world} (sequences shard by rank, no collective)"},
         "max_memory_MB": torch.cuda.max_memory_allocated() // (1024 ** 2),
+        "infer_graph_stats": _infer_graph_stats(tracker.core),
     }
+
+
+def _infer_graph_stats(core) -> dict:
+    e, d = core.infer_graphs().encode, core.transformer.decoder.infer_graphs().decode
+    return {"encode": {"captures": e.captures, "replays": e.replays, "eager": e.eager, "failed": e.failed},
+            "decoder": {"captures": d.captures, "replays": d.replays, "eager": d.eager, "failed": d.failed}}
 
 
 def run_msda_kernels_only(args):

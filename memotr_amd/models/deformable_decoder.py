@@ -39,6 +39,7 @@ class DeformableDecoder(nn.Module):
     def __getstate__(self):
         state = self.__dict__.copy()
         state.pop("_decoder_graphs", None)        # captured hipGraphs are per-process objects: never pickled / deep-copied
+        state.pop("_infer_graphs", None)
         return state
 
     def graphs(self) -> DecoderGraphs:
@@ -47,10 +48,18 @@ class DeformableDecoder(nn.Module):
             g = self.__dict__["_decoder_graphs"] = DecoderGraphs(self)
         return g
 
+    def infer_graphs(self):
+        g = self.__dict__.get("_infer_graphs")
+        if g is None:
+            from .infer_graphs import InferGraphs
+            g = self.__dict__["_infer_graphs"] = InferGraphs(None)
+        return g
+
     def _forward_graphed(self, tgt, reference_points, src, spatial_shapes, level_start_index, valid_ratios, query_mask,
-                         src_padding_mask, frame_slot, clip_key=None):
-        """The loop below with every iteration replayed from a hipGraph (models/decoder_graphs.py).  Returns None
-        when a capture fails; the caller then runs the eager loop."""
+                         src_padding_mask, frame_slot, clip_key=None, infer=False):
+        """The loop below with every iteration replayed from a hipGraph (models/decoder_graphs.py; ``infer``: the
+        forward-only capture of models/infer_graphs.py).  Returns None when a capture fails; the caller then runs the
+        eager loop."""
         graphs = self.graphs()
         nd = self.n_det_queries
         B, nq, C = tgt.shape
@@ -62,8 +71,11 @@ class DeformableDecoder(nn.Module):
             query_mask = torch.cat((query_mask, query_mask.new_ones(B, pad)), 1)
         ratios4 = torch.cat([valid_ratios, valid_ratios], -1)[:, None].contiguous()
         query_mask = query_mask.contiguous()
-        res = graphs.run(frame_slot, (tgt.contiguous(), reference_points.contiguous(), src, ratios4, query_mask,
-                                      src_padding_mask), spatial_shapes, level_start_index, clip_key)
+        args = (tgt.contiguous(), reference_points.contiguous(), src, ratios4, query_mask, src_padding_mask)
+        if infer:
+            res = self.infer_graphs().run_decode(self, args, spatial_shapes, level_start_index)
+        else:
+            res = graphs.run(frame_slot, args, spatial_shapes, level_start_index, clip_key)
         if res is None:
             return None
         outs, refs, layer_inputs, boxes = res
@@ -86,6 +98,12 @@ class DeformableDecoder(nn.Module):
                 and self.graphs().usable(tgt, src)):
             res = self._forward_graphed(tgt, reference_points, src, src_spatial_shapes, src_level_start_index,
                                         src_valid_ratios, query_mask, src_padding_mask, frame_slot, clip_key)
+            if res is not None:
+                return res
+        if (not torch.is_grad_enabled() and reference_points.shape[-1] == 4 and src_padding_mask is not None
+                and self.infer_graphs().decode_usable(self, tgt, src)):
+            res = self._forward_graphed(tgt, reference_points, src, src_spatial_shapes, src_level_start_index,
+                                        src_valid_ratios, query_mask, src_padding_mask, None, infer=True)
             if res is not None:
                 return res
         nd = self.n_det_queries

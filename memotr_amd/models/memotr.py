@@ -103,7 +103,15 @@ class MeMOTR(nn.Module):
     def __getstate__(self):
         state = self.__dict__.copy()
         state.pop("_encode_graphs", None)          # captured hipGraphs are per-process objects
+        state.pop("_infer_graphs", None)
         return state
+
+    def infer_graphs(self):
+        g = self.__dict__.get("_infer_graphs")
+        if g is None:
+            from .infer_graphs import InferGraphs
+            g = self.__dict__["_infer_graphs"] = InferGraphs(self)
+        return g
 
     def encode_graphs(self):
         g = self.__dict__.get("_encode_graphs")
@@ -115,6 +123,13 @@ class MeMOTR(nn.Module):
     def encode_frame(self, frame: NestedTensor) -> dict:
         """Backbone -> feature projections -> encoder (independent of the track queries); replayed from a hipGraph
         pair where that pays (models/encode_graphs.py: the launch-bound bf16 step), else kernel by kernel."""
+        if not torch.is_grad_enabled():            # inference: forward-only capture (models/infer_graphs.py)
+            infer = self.infer_graphs()
+            if infer.encode_usable(frame):
+                enc = infer.run_encode(frame)
+                if enc is not None:
+                    return enc
+            return self._encode_frame_eager(frame)
         graphs = self.encode_graphs()
         if graphs.usable(frame):
             enc = graphs.run(frame, getattr(frame, "encode_slot", 0))

@@ -46,19 +46,23 @@ class RuntimeTracker:
                                            torch.zeros_like(t.disappear_time))
             t.ids = torch.where(t.disappear_time >= self.miss_tolerance, torch.full_like(t.ids, -1), t.ids)
 
-        # newborn targets from the detect-query slots
+        # newborn targets from the detect-query slots.  ONE nonzero (= one device synchronisation) for all the
+        # fields: a boolean index per field costs a blocking device->host copy each, ~1 ms apiece on this runtime
+        # (seven of them were most of an inference frame's host time, tools/infer_gaps.py)
         keep = torch.max(scores_all[0][:n_dets], dim=-1).values >= self.det_score_thresh
+        idx = keep.nonzero().squeeze(1)
+        pick = lambda x: x[0][:n_dets].index_select(0, idx)  # noqa: E731
         new = TrackInstances(hidden_dim=t.hidden_dim, num_classes=t.num_classes)
-        new.logits = model_outputs["pred_logits"][0][:n_dets][keep]
-        new.boxes = model_outputs["pred_bboxes"][0][:n_dets][keep]
-        new.ref_pts = model_outputs["last_ref_pts"][0][:n_dets][keep]
-        new.scores = scores_all[0][:n_dets][keep]
-        new.output_embed = model_outputs["outputs"][0][:n_dets][keep]
-        queries = model_outputs["aux_outputs"][-1]["queries"][0][:n_dets][keep]
+        new.logits = pick(model_outputs["pred_logits"])
+        new.boxes = pick(model_outputs["pred_bboxes"])
+        new.ref_pts = pick(model_outputs["last_ref_pts"])
+        new.scores = pick(scores_all)
+        new.output_embed = pick(model_outputs["outputs"])
+        queries = pick(model_outputs["aux_outputs"][-1]["queries"])
         if self.use_dab:
             new.query_embed = queries
         else:
-            new.query_embed = torch.cat((model_outputs["det_query_embed"][keep][:, :256], queries), dim=-1)
+            new.query_embed = torch.cat((model_outputs["det_query_embed"].index_select(0, idx)[:, :256], queries), dim=-1)
         device = new.logits.device
         n_new = new.logits.shape[0]
         new.disappear_time = torch.zeros((n_new,), dtype=torch.long, device=device)

@@ -527,3 +527,55 @@ def test_encode_graphs_match_the_eager_encode(monkeypatch, bf16):
     assert g_g.keys() == g_e.keys()
     for n in g_e:
         assert float((g_g[n] - g_e[n]).norm()) / (float(g_e[n].norm()) + 1e-4) < tol_grad, n
+
+
+def test_inference_graphs_match_the_eager_tracker(monkeypatch):
+    """Online tracking (SequenceTracker.step, the submit_engine.py frame loop) with the encode half and the decoder
+    loop replayed from forward-only hipGraphs (models/infer_graphs.py) against the same loop kernel by kernel: same
+    track ids frame by frame, boxes / scores within 1e-4 (the padded query bucket changes the attention kernels' key
+    count, nothing else), graphs captured once per geometry / bucket and replayed after that."""
+    from memotr_amd.inference import SequenceTracker
+    from memotr_amd.models.utils import logits_to_scores
+    from memotr_amd.utils.nested_tensor import tensor_list_to_nested_tensor
+    import memotr_amd.modules.ms_deform_attn as mod
+    monkeypatch.setenv("MEMOTR_REQUIRE_GRAPHS", "1")
+    g = torch.Generator().manual_seed(11)
+    frames = [torch.randn(3, 192, 256, generator=g).cuda() for _ in range(6)]
+
+    def run(graphs, lookahead=False):
+        monkeypatch.setenv("MEMOTR_INFER_GRAPHS", "1" if graphs else "0")
+        torch.manual_seed(4)
+        model = build_memotr_cuda(None, hidden=256, ffn=256, NUM_ENC_LAYERS=2, NUM_DEC_LAYERS=2).eval()
+        with torch.no_grad():
+            for m in model.modules():
+                if isinstance(m, mod.MSDeformAttn):
+                    m.sampling_offsets.weight.normal_(0, 0.02)
+                    m.attention_weights.weight.normal_(0, 0.05)
+        tracker = SequenceTracker(model, det_score_thresh=0.5, track_score_thresh=0.0, result_score_thresh=0.0,
+                                  miss_tolerance=5, use_dab=True, area_thresh=0)
+        with torch.no_grad():       # random-init scores sit near 0.01: give birth to the three best detections per frame
+            res = model(frame=tensor_list_to_nested_tensor([frames[0]]).to(torch.device("cuda")), tracks=tracker.tracks)
+            best = logits_to_scores(res["pred_logits"])[0, :len(res["det_query_embed"])].max(-1).values
+        tracker.tracker.det_score_thresh = float(best.topk(3).values[-1]) - 1e-6
+        outs = []
+        for i, f in enumerate(frames):
+            if i == 3:
+                tracker.tracker.det_score_thresh = 2.0      # ... then none: the live set settles
+            nxt = frames[i + 1] if lookahead and i + 1 < len(frames) else None
+            outs.append(tracker.step(f, 192, 256, next_image=nxt))
+        return outs, model
+
+    eager, _ = run(False)
+    ahead_eager, _ = run(False, lookahead=True)        # the next frame's encode half queued on a side stream
+    ahead, model_a = run(True, lookahead=True)
+    graphed, model = run(True)
+    enc, dec = model.infer_graphs().encode, model.transformer.decoder.infer_graphs().decode
+    assert enc.captures == 2 and enc.replays >= len(frames) and enc.eager == 0 and not enc.failed
+    assert 1 <= dec.captures <= 3 and dec.replays >= len(frames) and dec.eager == 0 and not dec.failed
+    assert len(eager[-1]) >= 3
+    assert model_a.infer_graphs().encode.captures == 2          # two slots: one may still be read by the decoder
+    for other in (graphed, ahead_eager, ahead):
+        for a, b in zip(eager, other):
+            assert a.ids.tolist() == b.ids.tolist()
+            assert torch.allclose(a.boxes, b.boxes, atol=1e-2, rtol=1e-4)          # pixels
+            assert torch.allclose(a.scores, b.scores, atol=1e-4)
