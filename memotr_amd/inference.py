@@ -125,7 +125,8 @@ class SequenceTracker:
         with torch.cuda.stream(side):
             enc = self._encode(image)
             event = side.record_event()
-        image.record_stream(side)
+        if image.is_cuda:
+            image.record_stream(side)
         for v in enc.values():                  # produced on the side stream, consumed on main
             if torch.is_tensor(v) and v.is_cuda:
                 v.record_stream(main)
