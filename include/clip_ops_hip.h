@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define CLIPOPS_ABI_VERSION 7
+#define CLIPOPS_ABI_VERSION 8
 
 int clipops_abi_version(void);
 const char *clipops_last_error(void);
@@ -126,6 +126,21 @@ int clipops_add_layer_norm_fwd_f32(const float *x, const float *res, const float
  * layer_norm_grad_input + two gamma/beta kernels + the add's fan-out. */
 int clipops_add_layer_norm_bwd_f32(const float *grad_y, const float *sum, const float *stats, const float *gamma,
                                    long rows, int chunk_rows, float *grad_sum, float *partial, void *stream);
+
+/* Linear sum assignment of `n_problems` cost matrices of one shape (n_rows, n_cols) on the device -- what the
+ * reference's matcher does on the host with scipy.optimize.linear_sum_assignment after a `.cpu()` copy
+ * (models/matcher.py:122-124).  Same algorithm as scipy's (shortest augmenting paths, Crouse 2016, float64 arithmetic
+ * on the float32 costs) with the same scan order and tie rule, so the PAIRS are scipy's, not just the cost
+ * (memotr_amd/csrc/assign_core.h; held to scipy on 1000 random matrices with ties on the CPU and on the GPU).
+ * Element (p, r, c) of `cost` is at cost[p*stride_problem + r*stride_row + c*stride_col] (element strides: a
+ * (layers, Q, T) cost tensor and its transpose are both addressable without a copy).  One 64-lane wavefront per
+ * problem, all state in LDS, max(n_rows, n_cols) <= CLIPOPS_ASSIGN_MAX_DIM.  Outputs, k = min(n_rows, n_cols):
+ * row_ind, col_ind (n_problems, k) int32 -- pairs ordered by row like scipy's result; status (n_problems) int32,
+ * may be NULL: k, or -1 for an infeasible matrix (every completion costs +inf: scipy raises ValueError).
+ * Round 3: the solver and its parity tests; the criterion still consumes scipy's result on the host. */
+#define CLIPOPS_ASSIGN_MAX_DIM 2048
+int clipops_assign_f32(const float *cost, long stride_problem, long stride_row, long stride_col, int n_problems,
+                       int n_rows, int n_cols, int32_t *row_ind, int32_t *col_ind, int32_t *status, void *stream);
 
 #ifdef __cplusplus
 }

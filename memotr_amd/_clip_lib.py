@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libclip_ops_hip.so")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 c_int, c_long, c_float, c_void_p = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_void_p
 
@@ -31,6 +31,8 @@ SYMBOLS = {
     "clipops_colsum_f32": ([c_void_p, c_long, c_int, c_void_p, c_void_p], c_int),
     "clipops_colsum_partial_f32": ([c_void_p, c_long, c_int, c_int, c_void_p, c_void_p], c_int),
     "clipops_colsum_partial_bf16": ([c_void_p, c_long, c_int, c_int, c_void_p, c_void_p], c_int),
+    "clipops_assign_f32": ([c_void_p, c_long, c_long, c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                            c_void_p], c_int),
     "clipops_mha_fwd_f32": ([c_void_p] * 3 + [c_long] * 6 + [c_void_p] + [c_int] * 3 + [c_float, c_void_p, c_void_p,
                                                                                           c_void_p], c_int),
     "clipops_mha_bwd_f32": ([c_void_p] * 3 + [c_long] * 6 + [c_void_p] * 4 + [c_int] * 3 + [c_float] +

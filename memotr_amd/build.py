@@ -17,6 +17,7 @@ LIB = os.path.join(LIB_DIR, "libmsda_hip.so")
 CLIP_SRC = os.path.join(_HERE, "csrc", "clip_ops.hip")
 CLIP_HDR = os.path.join(os.path.dirname(_HERE), "include", "clip_ops_hip.h")
 CLIP_LIB = os.path.join(LIB_DIR, "libclip_ops_hip.so")
+ASSIGN_CORE = os.path.join(_HERE, "csrc", "assign_core.h")
 
 HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
@@ -69,7 +70,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
 
 
 def build_clip_lib(force: bool = False, verbose: bool = False) -> str:
-    if not force and not _stale(CLIP_LIB, (CLIP_SRC, CLIP_HDR)):
+    if not force and not _stale(CLIP_LIB, (CLIP_SRC, CLIP_HDR, ASSIGN_CORE)):
         return CLIP_LIB
     return _compile(CLIP_SRC, CLIP_LIB, verbose)
 

@@ -11,6 +11,7 @@
 #include <atomic>
 
 #include "../../include/clip_ops_hip.h"
+#include "assign_core.h"
 
 namespace {
 
@@ -738,6 +739,49 @@ __global__ __launch_bounds__(256) void add_layer_norm_bwd_kernel(const float *__
     }
 }
 
+// ---- linear sum assignment on the device (assign_core.h; one wavefront per problem) ----------------------------
+// The wavefront's side of assign::Lanes: lane l scans positions l, l + 64, ... of the unvisited-column list and the
+// 64 partial results meet in an xor butterfly of the (commutative, associative) merge; everything that is not the scan
+// is wave-uniform control flow around LDS arrays, with a workgroup barrier (one wavefront: an s_barrier and the LDS
+// wait) wherever one lane's LDS write must be seen by the others.
+struct WaveLanes {
+    int lane;
+    template <typename F>
+    __device__ __forceinline__ assign::ScanBest scan(int n, F &&body) const {
+        assign::ScanBest mine = assign::scan_empty();
+        for (int it = lane; it < n; it += 64) body(it, mine);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            assign::ScanBest o;
+            o.lowest = __shfl_xor(mine.lowest, off, 64);
+            o.last_free = __shfl_xor(mine.last_free, off, 64);
+            o.first = __shfl_xor(mine.first, off, 64);
+            mine = assign::scan_merge(mine, o);
+        }
+        return mine;
+    }
+    template <typename F>
+    __device__ __forceinline__ void each(int n, F &&body) const {
+        for (int k = lane; k < n; k += 64) body(k);
+    }
+    __device__ __forceinline__ bool leader() const { return lane == 0; }
+    __device__ __forceinline__ void sync() const { __syncthreads(); }
+};
+
+__global__ __launch_bounds__(64) void assign_kernel(const float *__restrict__ cost, long stride_p, long stride_r,
+                                                    long stride_c, int n_rows, int n_cols,
+                                                    int32_t *__restrict__ row_ind, int32_t *__restrict__ col_ind,
+                                                    int32_t *__restrict__ status) {
+#pragma clang fp contract(off)
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_assign[];
+    const long p = blockIdx.x;
+    const int k = n_rows < n_cols ? n_rows : n_cols;
+    const WaveLanes lanes{(int)threadIdx.x};
+    const int rc = assign::solve_problem(lanes, cost + p * stride_p, stride_r, stride_c, n_rows, n_cols, s_assign,
+                                         row_ind + p * k, col_ind + p * k);
+    if (threadIdx.x == 0 && status != nullptr) status[p] = rc;
+}
+
 int grid_for(long total) {
     long g = (total + 255) / 256;
     if (g < 1) g = 1;
@@ -964,6 +1008,19 @@ int clipops_add_layer_norm_bwd_f32(const float *grad_y, const float *sum, const 
     hipLaunchKernelGGL(add_layer_norm_bwd_kernel, dim3((unsigned)((rows + chunk_rows - 1) / chunk_rows)), dim3(256), 0,
                        (hipStream_t)stream, grad_y, sum, stats, gamma, rows, chunk_rows, grad_sum, partial);
     return check_launch("add_layer_norm_bwd_kernel");
+}
+
+int clipops_assign_f32(const float *cost, long stride_problem, long stride_row, long stride_col, int n_problems,
+                       int n_rows, int n_cols, int32_t *row_ind, int32_t *col_ind, int32_t *status, void *stream) {
+    if (n_problems < 0 || n_rows < 0 || n_cols < 0) return fail(1, "clipops_assign_f32: bad dimension");
+    if (n_problems == 0 || n_rows == 0 || n_cols == 0) { g_err[0] = 0; return 0; }
+    if (!cost || !row_ind || !col_ind) return fail(1, "clipops_assign_f32: null pointer");
+    const int nr = n_rows < n_cols ? n_rows : n_cols, nc = n_rows < n_cols ? n_cols : n_rows;
+    if (nc > CLIPOPS_ASSIGN_MAX_DIM) return fail(2, "clipops_assign_f32: problem exceeds CLIPOPS_ASSIGN_MAX_DIM");
+    const size_t lds = (assign::work_bytes(nr, nc) + 15) & ~(size_t)15;
+    hipLaunchKernelGGL(assign_kernel, dim3(n_problems), dim3(64), lds, (hipStream_t)stream, cost, stride_problem,
+                       stride_row, stride_col, n_rows, n_cols, row_ind, col_ind, status);
+    return check_launch("assign_kernel");
 }
 
 }  // extern "C"

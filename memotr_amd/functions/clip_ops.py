@@ -137,6 +137,25 @@ def pair_iou(boxes: torch.Tensor, tgt_boxes: torch.Tensor, gidx: torch.Tensor = 
     return out
 
 
+def assign(cost: torch.Tensor):
+    """Linear sum assignment of a batch of cost matrices (P, R, C) (any strides) on the device:
+    (row_ind (P, k) int32, col_ind (P, k) int32, status (P,) int32), k = min(R, C) -- per problem the pairs
+    ``scipy.optimize.linear_sum_assignment`` returns (same algorithm, scan order and tie rule:
+    csrc/assign_core.h), status k, or -1 where scipy would raise "cost matrix is infeasible".  No synchronisation."""
+    if cost.dim() != 3 or cost.dtype != torch.float32 or not cost.is_cuda:
+        raise RuntimeError("assign expects a float32 CUDA tensor of shape (problems, rows, cols)")
+    P, R, C = cost.shape
+    k = min(R, C)
+    row = torch.empty((P, k), dtype=torch.int32, device=cost.device)
+    col = torch.empty((P, k), dtype=torch.int32, device=cost.device)
+    status = torch.empty((P,), dtype=torch.int32, device=cost.device)
+    L = _lib()
+    L.check(L.lib.clipops_assign_f32(cost.data_ptr(), cost.stride(0), cost.stride(1), cost.stride(2), P, R, C,
+                                     row.data_ptr(), col.data_ptr(), status.data_ptr(), _stream(cost)),
+            "clipops_assign_f32")
+    return row, col, status
+
+
 def pair_iou_reference(boxes, tgt_boxes, gidx=None):
     from ..models.criterion import paired_iou
     from ..utils.box_ops import box_cxcywh_to_xyxy

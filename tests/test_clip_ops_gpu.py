@@ -1,5 +1,6 @@
 """GPU: the fused criterion kernels (include/clip_ops_hip.h) against the element-wise torch formulation of the same
 reference formulas (models/matcher.py:83-121, models/criterion.py:417-467 of the reference), values and gradients."""
+import numpy as np
 import pytest
 import torch
 
@@ -342,3 +343,46 @@ def test_add_layer_norm_values_and_gradients(shape):
             dict(rtol=1e-5, atol=2e-5)
         torch.testing.assert_close(a, b_, msg=lambda m, what=what: f"{what}: {m}", **tol)
     assert not clip_ops.add_layer_norm_supported(x[..., :128], r[..., :128], nn.LayerNorm(128).cuda())
+
+
+# ----------------------------------------------------------------------------- device-side assignment
+def test_device_assignment_is_identical_to_scipy_on_1000_random_matrices():
+    """clipops_assign_f32 (one wavefront per problem, csrc/assign_core.h) against scipy.optimize.linear_sum_assignment
+    -- the reference matcher's host call (models/matcher.py:122-124) -- on the matrices of tests/test_assign_core.py
+    (matcher-shaped, transposed, square, heavy ties, duplicated rows / columns, constants): identical pairs."""
+    from scipy.optimize import linear_sum_assignment
+    from test_assign_core import cases
+    from memotr_amd.functions import clip_ops
+    n_ties = 0
+    pending = []
+    for c in cases():
+        t = torch.from_numpy(c).cuda()
+        # the (rows, cols) problem and, from the same memory, its transpose as a strided view
+        batch = t[None]
+        pending.append((c, clip_ops.assign(batch), clip_ops.assign(batch.transpose(1, 2))))
+        n_ties += len(np.unique(c)) < c.size
+    torch.cuda.synchronize()
+    for c, (r, col, st), (rt, colt, stt) in pending:
+        want_r, want_c = linear_sum_assignment(c)
+        assert int(st[0]) == min(c.shape) == int(stt[0])
+        assert np.array_equal(r[0].cpu().numpy(), want_r) and np.array_equal(col[0].cpu().numpy(), want_c), c.shape
+        want_rt, want_ct = linear_sum_assignment(c.T)
+        assert np.array_equal(rt[0].cpu().numpy(), want_rt) and np.array_equal(colt[0].cpu().numpy(), want_ct), c.shape
+    assert n_ties > 300
+
+
+def test_device_assignment_batches_the_layers_of_a_frame_and_flags_infeasible_costs():
+    from scipy.optimize import linear_sum_assignment
+    from memotr_amd.functions import clip_ops
+    g = torch.Generator().manual_seed(5)
+    cost = torch.randn(6, 310, 17, generator=g).cuda()               # six decoder layers x (queries, ground truths)
+    r, c, st = clip_ops.assign(cost)
+    assert st.tolist() == [17] * 6
+    for layer in range(6):
+        wr, wc = linear_sum_assignment(cost[layer].cpu().numpy())
+        assert np.array_equal(r[layer].cpu().numpy(), wr) and np.array_equal(c[layer].cpu().numpy(), wc)
+    bad = torch.tensor([[[float("inf"), float("inf")], [1.0, 2.0]]]).cuda()
+    assert clip_ops.assign(bad)[2].tolist() == [-1]
+    big = torch.zeros(1, 4, 3000).cuda()
+    with pytest.raises(RuntimeError, match="CLIPOPS_ASSIGN_MAX_DIM"):
+        clip_ops.assign(big)
