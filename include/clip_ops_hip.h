@@ -90,7 +90,7 @@ int clipops_colsum_f32(const float *x, long rows, int cols, float *out, void *st
  * k < ceil(rows / chunk_rows); clipops_colsum_f32 over `partial` finishes (fixed order end to end). */
 int clipops_colsum_partial_f32(const float *x, long rows, int cols, int chunk_rows, float *partial, void *stream);
 /* The same from bf16 storage (fp32 partial sums): bias gradients of the bf16 linears -- torch's own multi-block
- * reduction returned garbage inside replayed hipGraphs (round 3, profiles/r03_notes). */
+ * reduction returned garbage inside replayed hipGraphs (round 3, profiles/r03_graph_memset_probe.txt). */
 int clipops_colsum_partial_bf16(const uint16_t *x, long rows, int cols, int chunk_rows, float *partial, void *stream);
 
 /* Multi-head self-attention over the decoder queries (reference models/deformable_decoder.py:245-249: the
