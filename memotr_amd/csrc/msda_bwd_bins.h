@@ -1,0 +1,408 @@
+// msda_bwd_bins.h -- region-tiled backward for pyramid self-attention (Lq == S, D = 32), round 4.
+//
+// Reference semantics: ms_deformable_col2im_gpu_kernel_* + ms_deform_attn_col2im_bilinear
+// (models/ops/src/cuda/ms_deform_im2col_cuda.cuh:87-159, 301-403): per (query, head, level, point)
+//   grad_value[corner k] += w_k * attn * grad_out_row          (4 corners x 32 channels, atomics)
+//   grad_attn            = <grad_out_row, sum_k w_k v_k>
+//   grad_loc             = attn * <grad_out_row, d(sum_k w_k v_k)/d(x, y)> * (W, H)
+//
+// msda_bwd_d32_tile_lv (round 2) did the grad_value part as a SCATTER: every (row, point, corner) converts its 32
+// products to fixed point and adds them to an LDS window with packed 64-bit integer atomics (ds_add_f32 retires 15x
+// slower) -- 106 M VALU instructions per encoder call, 74 % VALU-busy, 215 us.  This kernel turns the scatter into a
+// GATHER, which needs neither fixed point nor per-element atomics:
+//
+//   * a workgroup owns (batch, region, head, level) like tile_lv: the 8x8 + 4x4 + 2x2 + 1 = 85 query rows of one
+//     region x the P points of one level = 340 ITEMS, one lane each for all scalar work (sample arithmetic, masks,
+//     window cells, bilinear weights) -- done once, not by the 8 lanes of a row redundantly;
+//   * the window of the level is only a table of COUNTERS (4 B per cell instead of 128 B), so it can be generous;
+//     every valid corner takes a ticket in its cell (one returning ds_add_u32 per corner instead of 16 ds_add_u64),
+//     a prefix sum over the cells turns tickets into positions: a counting sort of the <= 1360 (cell, row, weight)
+//     entries by cell, entirely in LDS;
+//   * grad_out rows of the region are staged once in LDS (fp32); four lanes x 8 channels own a cell and walk its
+//     entry list: acc += weight * grad_out_row -- float accumulation in registers, 2 pk_fma per 4 channels, no
+//     conversions, no scales, no "wide region" or non-finite bypass: NaN / Inf propagate like the reference's
+//     atomicAdd does;
+//   * the three gradient dot products of a point all derive from the FOUR corner dot products
+//     d_k = <grad_out_row, v_k>: grad_attn = sum_k w_k d_k, d/dx = a (hh (d1 - d0) + lh (d3 - d2)),
+//     d/dy = a (hw (d2 - d0) + lw (d3 - d1)); four lanes x 8 channels per item, reduced with two DPP steps;
+//   * a cell's 32 sums leave as ONE 128-byte row of float atomics (32 consecutive lanes, the L2 atomic units' fastest
+//     pattern), after a per-wavefront transpose through LDS.
+// Points whose corners fall outside the window take global float atomics on the spot (results never depend on the
+// window placement, only the speed does).
+#pragma once
+
+constexpr unsigned kBinsGRow = 144u;          // LDS bytes per staged grad_out row: 128 + 16 (bank spread for b128 reads)
+constexpr unsigned kBinsStageBytes = 8192u;   // 4 wavefronts x 16 cells x 128 B: the flush transpose, aliases the records
+
+#ifndef MSDA_BINS_WGS
+#define MSDA_BINS_WGS 4
+#endif
+
+struct BinsPlan {
+    int n_items;             // rows * P
+    int magic_p;             // (i * magic_p) >> 16 == i / P for i < 256 * NI
+    int scan_c;              // cells per lane in the prefix sum (multiple of 4); counters are padded to 64 * scan_c
+    unsigned o_e, o_r, o_fl, o_rowq, o_cnt, o_start;   // byte offsets into dynamic LDS (grad_out rows at 0)
+};
+
+__device__ __forceinline__ unsigned bins_incl_scan(unsigned x, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
+    }
+    return x;
+}
+
+// four consecutive channels of a grad_out row as floats
+template <typename TV>
+__device__ __forceinline__ f32x4 bins_load_g4(const TV *p);
+template <>
+__device__ __forceinline__ f32x4 bins_load_g4<float>(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+template <>
+__device__ __forceinline__ f32x4 bins_load_g4<bf16_t>(const bf16_t *p) {
+    const u32x2 u = *reinterpret_cast<const u32x2 *>(p);
+    return f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                 __uint_as_float(u.y & 0xffff0000u)};
+}
+
+// <ga, va> + <gb, vb> over 8 channels as packed pairs (v_pk_fma_f32 on the natural register pairs)
+__device__ __forceinline__ float bins_dot8(const f32x4 ga, const f32x4 va, const f32x4 gb, const f32x4 vb) {
+    f32x2 s = f32x2{ga.x, ga.y} * f32x2{va.x, va.y};
+    s += f32x2{ga.z, ga.w} * f32x2{va.z, va.w};
+    s += f32x2{gb.x, gb.y} * f32x2{vb.x, vb.y};
+    s += f32x2{gb.z, gb.w} * f32x2{vb.z, vb.w};
+    return s.x + s.y;
+}
+
+__device__ __forceinline__ int bins_mul24(int a, int b) { return __mul24(a, b); }
+
+#define MSDA_QUAD_SUM(x)                                          \
+    do {                                                          \
+        (x) += MSDA_DPP((x), 0xB1); /* quad_perm [1,0,3,2] */     \
+        (x) += MSDA_DPP((x), 0x4E); /* quad_perm [2,3,0,1] */     \
+    } while (0)
+
+template <int NI, typename TV>
+__global__ __launch_bounds__(kTileThreads, MSDA_BINS_WGS) void msda_bwd_d32_bins(
+    const TV *__restrict__ value, const int64_t *__restrict__ lstart, const PointSrc src,
+    const TV *__restrict__ grad_out, float *__restrict__ grad_value, float *__restrict__ grad_loc,
+    float *__restrict__ grad_attn, float *__restrict__ grad_proj, const TilePlan pl, const BinsPlan bp) {
+    constexpr int D = 32;
+    constexpr unsigned ROWB = 32u * (unsigned)sizeof(TV);
+    constexpr bool kB16 = sizeof(TV) == 2;
+    __shared__ float s_sum[4];
+    __shared__ unsigned s_off[kTileThreads / 64][16];       // flush: grad_value byte offset of a wavefront's 16 cells
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+
+    // ---- block -> (batch, region, head, level); XCD-aware like tile_lv ----
+    const int nb_pad = gridDim.x, chunk = nb_pad >> 3;
+    const int sw = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if (sw >= pl.n_blocks * pl.L) return;
+    const int L = pl.L, P = pl.P, LP = L * P, M = pl.M;
+    const int l = sw % L;
+    const int id = sw / L;
+    const int m = id % M;
+    const int reg = (id / M) % (pl.RY * pl.RX);
+    const int b = id / (M * pl.RY * pl.RX);
+    const int ry = reg / pl.RX, rx = reg - ry * pl.RX;
+    int H = pl.H[0], W = pl.W[0], win = pl.win[0], magic = pl.win_magic[0], shl = pl.shift[0];
+#pragma unroll
+    for (int i = 1; i < kTileMaxL; ++i)
+        if (l == i) { H = pl.H[i]; W = pl.W[i]; win = pl.win[i]; magic = pl.win_magic[i]; shl = pl.shift[i]; }
+    const int lstart_l = (int)lstart[l];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rows = pl.rows, n_items = bp.n_items, ncell = win * win;
+
+    unsigned char *const G = s_dyn;
+    u32x2 *const E = reinterpret_cast<u32x2 *>(s_dyn + bp.o_e);
+    u32x4 *const R = reinterpret_cast<u32x4 *>(s_dyn + bp.o_r);
+    unsigned *const FL = reinterpret_cast<unsigned *>(s_dyn + bp.o_fl);
+    unsigned *const ROWQ = reinterpret_cast<unsigned *>(s_dyn + bp.o_rowq);
+    unsigned *const CNT = reinterpret_cast<unsigned *>(s_dyn + bp.o_cnt);
+    unsigned *const START = reinterpret_cast<unsigned *>(s_dyn + bp.o_start);
+    const __amdgpu_buffer_rsrc_t vr = make_rsrc(value, pl.value_bytes);
+    const __amdgpu_buffer_rsrc_t gr = make_rsrc(grad_value, (unsigned)((size_t)pl.N * pl.S * M * D * 4u));
+
+    // ---- phase 0: counters, grad_out rows -> LDS, this thread's items ----
+    if (tid < 4) s_sum[tid] = 0.f;
+    for (int i = tid; i < bp.scan_c * 64; i += kTileThreads) CNT[i] = 0u;
+    for (int idx = tid; idx < (rows + 1) * 8; idx += kTileThreads) {
+        const int r = idx >> 3, c = idx & 7;
+        const LevelPlanRow row = level_tile_row(pl, r, ry, rx);           // r == rows: not ok -> the zero row
+        const unsigned qrow = (unsigned)b * (unsigned)pl.Lq + (unsigned)row.q;
+        f32x4 g = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (row.ok) g = bins_load_g4<TV>(grad_out + ((qrow * (unsigned)M + (unsigned)m) * (unsigned)D + (unsigned)(c * 4)));
+        *reinterpret_cast<f32x4 *>(G + (unsigned)r * kBinsGRow + (unsigned)c * 16u) = g;
+        if (c == 0 && r < rows) ROWQ[r] = row.ok ? qrow : 0xffffffffu;
+    }
+    int it_r[NI];
+    bool it_live[NI], it_gate[NI];
+    int it_h0[NI], it_w0[NI];
+    float it_lh[NI], it_lw[NI], it_a[NI];
+    {
+        float sx = 0.f, sy = 0.f, cn = 0.f;
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const int it = tid + k * kTileThreads;
+            it_live[k] = it < n_items;
+            const int itc = it_live[k] ? it : 0;
+            const int r = bins_mul24(itc, bp.magic_p) >> 16, p = itc - bins_mul24(r, P);
+            it_r[k] = r;
+            const LevelPlanRow row = level_tile_row(pl, r, ry, rx);
+            const bool ok = row.ok && it_live[k];
+            const unsigned qrow = (unsigned)b * (unsigned)pl.Lq + (unsigned)row.q;
+            const unsigned pm = qrow * (unsigned)M + (unsigned)m;
+            const unsigned t = (unsigned)(l * P + p);
+            f32x2 xy = f32x2{0.f, 0.f};
+            float a = 0.f;
+            if (ok) {
+                xy = *reinterpret_cast<const f32x2 *>(src.loc + (pm * (unsigned)LP + t) * 2u);
+                a = src.attn[pm * (unsigned)LP + t];
+            }
+            const Sample<float> s = sample_setup<float>(xy.x, xy.y, H, W);
+            const bool gate = s.gate && ok;
+            it_live[k] = ok;                       // from here on: the row exists
+            it_gate[k] = gate;
+            it_h0[k] = s.h_low;
+            it_w0[k] = s.w_low;
+            it_lh[k] = gate ? s.lh : 0.f;
+            it_lw[k] = gate ? s.lw : 0.f;
+            it_a[k] = gate ? a : 0.f;
+            if (gate) {
+                sx += (float)s.w_low + s.lw;
+                sy += (float)s.h_low + s.lh;
+                cn += 1.f;
+            }
+        }
+        sx = wave_sum(sx);
+        sy = wave_sum(sy);
+        cn = wave_sum(cn);
+        if (lane == 0) {
+            atomicAdd(&s_sum[0], sx);
+            atomicAdd(&s_sum[1], sy);
+            atomicAdd(&s_sum[2], cn);
+        }
+    }
+    __syncthreads();      // B1: counters zeroed, grad_out rows staged, position sums complete
+    if (pl.ablate & 8) return;      // (profiling: bits 8 / 16 stop after phase 0 / 1, 32 / 64 skip phase 3 / 2)
+
+    // ---- phase 1: window origin (every thread: the same inputs give the same bits), tickets, records ----
+    int oy, ox;
+    {
+        const float cnt = s_sum[2];
+        const float cx = cnt > 0.f ? s_sum[0] / cnt : (float)((rx << shl) + (1 << shl) / 2);
+        const float cy = cnt > 0.f ? s_sum[1] / cnt : (float)((ry << shl) + (1 << shl) / 2);
+        ox = (int)floorf(cx - 0.5f * (float)(win - 1) + 0.5f);
+        oy = (int)floorf(cy - 0.5f * (float)(win - 1) + 0.5f);
+        const int max_x = W - win, max_y = H - win;
+        ox = ox > max_x ? max_x : ox;
+        oy = oy > max_y ? max_y : oy;
+        ox = ox < 0 ? 0 : ox;
+        oy = oy < 0 ? 0 : oy;
+    }
+    const long mask_base = (long)b * pl.S + lstart_l;
+    unsigned cr[NI][4];          // cell | ticket << 16 of the corners that are inside the window, else ~0
+    float wa[NI][4];
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        const int h0 = it_h0[k], w0 = it_w0[k];
+        const bool on = it_gate[k];
+        const bool okh0 = on && h0 >= 0, okh1 = on && h0 + 1 <= H - 1;
+        const bool okw0 = w0 >= 0, okw1 = w0 + 1 <= W - 1;
+        bool v[4] = {okh0 && okw0, okh0 && okw1, okh1 && okw0, okh1 && okw1};
+        if (src.mask != nullptr) {       // (the split fused backward runs this kernel with the padding mask of `value`)
+            const unsigned char *mk = src.mask + mask_base;
+            const int p00 = bins_mul24(h0, W) + w0;
+            v[0] = v[0] && !mk[v[0] ? p00 : 0];
+            v[1] = v[1] && !mk[v[1] ? p00 + 1 : 0];
+            v[2] = v[2] && !mk[v[2] ? p00 + W : 0];
+            v[3] = v[3] && !mk[v[3] ? p00 + W + 1 : 0];
+        }
+        const int wy0 = h0 - oy, wx0 = w0 - ox;
+        const bool iy0 = (unsigned)wy0 < (unsigned)win, iy1 = (unsigned)(wy0 + 1) < (unsigned)win;
+        const bool ix0 = (unsigned)wx0 < (unsigned)win, ix1 = (unsigned)(wx0 + 1) < (unsigned)win;
+        const bool in[4] = {v[0] && iy0 && ix0, v[1] && iy0 && ix1, v[2] && iy1 && ix0, v[3] && iy1 && ix1};
+        const unsigned c00 = (unsigned)(bins_mul24(wy0, win) + wx0);
+        const unsigned cell[4] = {c00, c00 + 1u, c00 + (unsigned)win, c00 + (unsigned)win + 1u};
+        const float lh = it_lh[k], lw = it_lw[k], a = it_a[k];
+        const float hh = 1.f - lh, hw = 1.f - lw;
+        const float wk[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
+        unsigned fl = it_live[k] ? 0x100u : 0u;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            cr[k][c] = 0xffffffffu;
+            wa[k][c] = wk[c] * a;
+            if (in[c]) {
+                const unsigned ticket = atomicAdd(&CNT[cell[c]], 1u);
+                cr[k][c] = cell[c] | (ticket << 16);
+            }
+            fl |= (v[c] ? 1u : 0u) << c;
+            fl |= ((v[c] && !in[c]) ? 1u : 0u) << (4 + c);
+        }
+        const int it = tid + k * kTileThreads;
+        if (it < n_items) {
+            u32x4 rec;
+            rec.x = (((unsigned)b * (unsigned)pl.S + (unsigned)(lstart_l + bins_mul24(h0, W) + w0)) * (unsigned)M + (unsigned)m) * ROWB;
+            rec.y = __float_as_uint(lh);
+            rec.z = __float_as_uint(lw);
+            rec.w = __float_as_uint(a);
+            R[it] = rec;
+            FL[it] = fl;
+        }
+    }
+    __syncthreads();      // B2: tickets drawn, records written
+    if (pl.ablate & 16) return;
+
+    // ---- phase 2: prefix sum over the cells (every wavefront for itself: no barrier), entries to their places ----
+    unsigned total = 0u;
+    if (!(pl.ablate & 64)) {
+        const int C = bp.scan_c;
+        unsigned sum = 0u;
+        for (int j = 0; j < C; ++j) sum += CNT[lane * C + j];
+        const unsigned incl = bins_incl_scan(sum, lane);
+        unsigned run = incl - sum;
+        for (int j = 0; j < C; ++j) {
+            START[lane * C + j] = run;             // (the four wavefronts write the same values)
+            run += CNT[lane * C + j];
+        }
+        total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+        if (lane == 63) E[total] = u32x2{(unsigned)rows * kBinsGRow, 0u};      // the list terminator: zero row, weight 0
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        if (pl.ablate & 64) break;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (cr[k][c] != 0xffffffffu) {
+                const unsigned pos = START[cr[k][c] & 0xffffu] + (cr[k][c] >> 16);
+                E[pos] = u32x2{(unsigned)it_r[k] * kBinsGRow, __float_as_uint(wa[k][c])};
+            }
+        }
+    }
+
+    // ---- phase 3: the items' gradient dot products: 4 lanes x 8 channels per item, 16 items per wavefront step ----
+    const int grp = lane >> 2, j4 = lane & 3;
+    const unsigned ch_a = kB16 ? 2u * (unsigned)j4 : (unsigned)j4;             // this lane's two 16-byte chunks of a
+    const unsigned ch_b = kB16 ? 2u * (unsigned)j4 + 1u : (unsigned)j4 + 4u;   // staged (fp32) grad_out row
+    const unsigned ps = (unsigned)M * ROWB, wps = (unsigned)W * ps;
+    const unsigned gps = (unsigned)M * 128u, gwps = (unsigned)W * gps;
+    for (int st = wave; st * 16 < n_items && !(pl.ablate & 32); st += kTileThreads / 64) {
+        const int it = st * 16 + grp;
+        const bool vi = it < n_items;
+        const int itc = vi ? it : n_items - 1;
+        const u32x4 rec = R[itc];
+        const unsigned fl = vi ? FL[itc] : 0u;
+        const int r = bins_mul24(itc, bp.magic_p) >> 16, p = itc - bins_mul24(r, P);
+        const f32x4 ga = *reinterpret_cast<const f32x4 *>(G + (unsigned)r * kBinsGRow + ch_a * 16u);
+        const f32x4 gb = *reinterpret_cast<const f32x4 *>(G + (unsigned)r * kBinsGRow + ch_b * 16u);
+        const unsigned qrow = ROWQ[r];
+        const unsigned base = rec.x + (unsigned)j4 * 16u;
+        const bool ld = !(pl.ablate & 4);
+        const unsigned off[4] = {((fl & 1u) && ld) ? base : kOobOffset, ((fl & 2u) && ld) ? base + ps : kOobOffset,
+                                 ((fl & 4u) && ld) ? base + wps : kOobOffset,
+                                 ((fl & 8u) && ld) ? base + wps + ps : kOobOffset};
+        f32x4 va[4], vb[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (kB16) {
+                const u32x4 u = buf_load_u4(vr, off[k]);
+                va[k] = f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                              __uint_as_float(u.y & 0xffff0000u)};
+                vb[k] = f32x4{__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u), __uint_as_float(u.w << 16),
+                              __uint_as_float(u.w & 0xffff0000u)};
+            } else {
+                va[k] = buf_load_f4(vr, off[k]);
+                vb[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(vr, (int)off[k], 64, 0));
+            }
+        }
+        float d[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            d[k] = bins_dot8(ga, va[k], gb, vb[k]);
+            MSDA_QUAD_SUM(d[k]);
+        }
+        const float lh = __uint_as_float(rec.y), lw = __uint_as_float(rec.z), a = __uint_as_float(rec.w);
+        const float hh = 1.f - lh, hw = 1.f - lw;
+        const float wk[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
+        const float r_a = wk[0] * d[0] + wk[1] * d[1] + wk[2] * d[2] + wk[3] * d[3];
+        const float r_w = a * (hh * (d[1] - d[0]) + lh * (d[3] - d[2]));
+        const float r_h = a * (hw * (d[2] - d[0]) + lw * (d[3] - d[1]));
+        if ((fl & 0x100u) && j4 < 3) {
+            const float outv = j4 == 0 ? r_w * (float)W : (j4 == 1 ? r_h * (float)H : r_a);
+            if (grad_proj != nullptr) {      // split fused backward: raw d/d(location), d/d(attention) into grad_proj's columns
+                const unsigned col = j4 < 2 ? (unsigned)(m * 2 * LP + l * P * 2 + 2 * p + j4)
+                                            : (unsigned)(src.n_off + m * LP + l * P + p);
+                grad_proj[qrow * (unsigned)src.proj_stride + col] = outv;
+            } else {
+                const unsigned pm = qrow * (unsigned)M + (unsigned)m;
+                if (j4 < 2) grad_loc[pm * (unsigned)(LP * 2) + (unsigned)(l * P * 2 + 2 * p + j4)] = outv;
+                else grad_attn[pm * (unsigned)LP + (unsigned)(l * P + p)] = outv;
+            }
+        }
+        if (!(pl.ablate & 2) && __builtin_amdgcn_ballot_w64((fl & 0xf0u) != 0u) != 0ull) {   // rare: corners outside the window
+            const unsigned gbase = rec.x * (128u / ROWB);
+            const unsigned dg[4] = {0u, gps, gwps, gwps + gps};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (fl & (16u << k)) {
+                    const float w = wk[k] * a;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(w * ga[i], gr, (int)(gbase + dg[k] + ch_a * 16u + (unsigned)i * 4u), 0, 0);
+                        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(w * gb[i], gr, (int)(gbase + dg[k] + ch_b * 16u + (unsigned)i * 4u), 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();      // B3: every entry is in place; the records are dead (the flush transpose reuses their LDS)
+
+    // ---- phase 4: per cell, gather its entries; flush the sums as whole 128-byte rows ----
+    if (pl.ablate & 2) return;
+    unsigned char *const ST = s_dyn + bp.o_r + (unsigned)wave * 2048u;
+    const int half = lane >> 5, c32 = lane & 31;
+    for (int round = 0; round * 64 < ncell; ++round) {
+        const int cell0 = round * 64 + wave * 16;
+        const int cell = cell0 + grp;
+        const bool live = cell < ncell;
+        const unsigned n = live ? CNT[cell] : 0u, s0 = live ? START[cell] : 0u;
+        if (__builtin_amdgcn_ballot_w64(n != 0u) == 0ull) continue;      // (wave-uniform)
+        f32x4 acc_a = f32x4{0.f, 0.f, 0.f, 0.f}, acc_b = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (unsigned i = 0; __builtin_amdgcn_ballot_w64(i < n) != 0ull; i += 2) {
+            const unsigned i0 = i < n ? s0 + i : total, i1 = i + 1 < n ? s0 + i + 1 : total;
+            const u32x2 e0 = E[i0], e1 = E[i1];
+            const f32x4 a0 = *reinterpret_cast<const f32x4 *>(G + e0.x + ch_a * 16u);
+            const f32x4 b0 = *reinterpret_cast<const f32x4 *>(G + e0.x + ch_b * 16u);
+            const f32x4 a1 = *reinterpret_cast<const f32x4 *>(G + e1.x + ch_a * 16u);
+            const f32x4 b1 = *reinterpret_cast<const f32x4 *>(G + e1.x + ch_b * 16u);
+            const float w0 = __uint_as_float(e0.y), w1 = __uint_as_float(e1.y);
+            acc_a += w0 * a0;
+            acc_b += w0 * b0;
+            acc_a += w1 * a1;
+            acc_b += w1 * b1;
+        }
+        if (pl.ablate & 1) continue;
+        *reinterpret_cast<f32x4 *>(ST + (unsigned)grp * 128u + ch_a * 16u) = acc_a;
+        *reinterpret_cast<f32x4 *>(ST + (unsigned)grp * 128u + ch_b * 16u) = acc_b;
+        if (j4 == 0) {      // where the cell's row goes (cells nothing was added to: dropped by the buffer's range check)
+            const int wy = bins_mul24(cell, magic) >> 16, wx = cell - bins_mul24(wy, win);
+            const unsigned goff = (((unsigned)b * (unsigned)pl.S + (unsigned)(lstart_l + bins_mul24(oy + wy, W) + ox + wx)) *
+                                   (unsigned)M + (unsigned)m) * 128u;
+            s_off[wave][grp] = n != 0u ? goff : kOobOffset;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int h = 0; h < 8; ++h) {
+            const int slot = 2 * h + half;
+            const float v = *reinterpret_cast<const float *>(ST + (unsigned)slot * 128u + (unsigned)c32 * 4u);
+            const unsigned goff = s_off[wave][slot] + (unsigned)c32 * 4u;      // (kOobOffset + 124 is still out of range)
+            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, gr, (int)goff, 0, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}

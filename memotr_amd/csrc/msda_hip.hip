@@ -1951,6 +1951,7 @@ __global__ __launch_bounds__(256) void msda_fused_finish16_kernel(const int64_t 
 
 #include "msda_fwd_win.h"
 #include "msda_bwd_rows.h"
+#include "msda_bwd_bins.h"
 
 // ----------------------------------------------------------------------------------------
 // host side
@@ -1969,6 +1970,7 @@ std::atomic<int> opt_bwd_split{1};        // fused backward with a workspace: pr
 std::atomic<int> opt_bwd_wide_log2{12};   // tiled backward: row-magnitude range (log2) that makes a region "wide"; 0 = off
 std::atomic<int> opt_bwd_ablate{0};
 std::atomic<int> opt_bwd_rows_block{0};   // threads per workgroup of msda_bwd_d32_rows (0: by problem size)
+std::atomic<int> opt_bwd_bins_margin{4};  // counting-sort backward: window margin (the window is only a table of counters)
 std::atomic<int> opt_bwd_rows{1};         // 0: few-query D = 32 calls keep the generic row-per-block backward
 std::atomic<int> opt_fwd_head_major{0};    // gather forward: head-major task walk (one head per XCD)
 std::atomic<int> opt_fwd_win_rlog{3};       // windowed forward: log2 of the region height on level 0
@@ -2021,7 +2023,8 @@ bool d32_ok(int D, int L, long value_elems) { return D == 32 && L <= kMaxLevels 
 // Plan the region tiling from the HOST copy of the level shapes.  Returns false when the tiled
 // kernels do not apply (then the gather / generic kernels run).  Levels below `l0` get no window.
 bool make_tile_plan(TilePlan &pl, const int64_t *shapes_host, int N, int S, int M, int D, int L, int Lq, int P,
-                    long value_bytes, int margin, int l0, size_t lds_rows_extra, size_t fixed_lds, size_t &lds) {
+                    long value_bytes, int margin, int l0, size_t lds_rows_extra, size_t fixed_lds, size_t &lds,
+                    bool check_lds = true) {
     if (!shapes_host || D != 32 || L < 1 || L > kTileMaxL || Lq != S || L * P > kMaxFusedLP) return false;
     if (margin < 0) margin = 0;
     if (l0 < 0) l0 = 0;
@@ -2067,7 +2070,39 @@ bool make_tile_plan(TilePlan &pl, const int64_t *shapes_host, int N, int S, int 
     if (nb > (1L << 30)) return false;
     pl.n_blocks = (int)nb;
     lds = ((size_t)px + lds_rows_extra) * 128 + fixed_lds;
-    return lds <= 160 * 1024 - 2048;
+    return !check_lds || lds <= 160 * 1024 - 2048;
+}
+
+// LDS layout of msda_bwd_d32_bins (msda_bwd_bins.h) for `ni` items per thread; false when the call does not fit.
+bool make_bins_plan(BinsPlan &bp, const TilePlan &pl, int ni, size_t &lds) {
+    const int P = pl.P, n_items = pl.rows * P;
+    if (P < 1 || n_items < 1 || n_items > kTileThreads * ni) return false;
+    const int magic = 65536 / P + 1;
+    for (int i = 0; i < kTileThreads * ni; ++i)
+        if (((i * magic) >> 16) != i / P) return false;
+    int win_max = 0;
+    for (int l = 0; l < pl.L; ++l) win_max = pl.win[l] > win_max ? pl.win[l] : win_max;
+    const int ncell = win_max * win_max;
+    const int C = (((ncell + 63) / 64) + 3) & ~3;
+    auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    size_t o = up16((size_t)(pl.rows + 1) * kBinsGRow);
+    bp.n_items = n_items;
+    bp.magic_p = magic;
+    bp.scan_c = C;
+    bp.o_e = (unsigned)o;
+    o += up16((size_t)(4 * n_items + 1) * 8);
+    bp.o_r = (unsigned)o;
+    bp.o_fl = (unsigned)(o + (size_t)n_items * 16);
+    bp.o_rowq = (unsigned)(bp.o_fl + up16((size_t)n_items * 4));
+    size_t region = (size_t)n_items * 16 + up16((size_t)n_items * 4) + up16((size_t)pl.rows * 4);
+    if (region < kBinsStageBytes) region = kBinsStageBytes;
+    o += region;
+    bp.o_cnt = (unsigned)o;
+    o += (size_t)C * 64 * 4;
+    bp.o_start = (unsigned)o;
+    o += (size_t)C * 64 * 4;
+    lds = o;
+    return lds <= 64 * 1024;
 }
 
 // Dynamic LDS above 64 KiB needs an opt-in per kernel; do it once per kernel and device for the full
@@ -2304,14 +2339,36 @@ int backward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart,
     if (variant == 0) variant = can_tile ? (P <= 8 ? 10 : 8) : 1;   // measured (profiles/): 224 vs 317 us at the encoder shape
     if (variant >= 2 && !can_tile) variant = 1;
     if constexpr (kD32Type) {
-        if (variant == 10 || variant == 11) {       // one pyramid level per workgroup
+        if (variant == 12) {        // counting-sort gather (msda_bwd_bins.h); the one-kernel fused form stays with tile_lv
+            const bool will_split = fa.proj != nullptr && opt_bwd_split.load() != 0 && workspace != nullptr &&
+                                    workspace_bytes >= (size_t)N * Lq * M * L * P * 3 * sizeof(float);
+            if (P > 8 || (fa.proj != nullptr && !will_split)) variant = 10;
+        }
+        if (variant == 10 || variant == 11 || variant == 12) {       // one pyramid level per workgroup
             TilePlan pl;
             size_t lds_all = 0;
-            if (P <= 8 && make_tile_plan(pl, shapes_host, N, S, M, D, L, Lq, P, value_bytes, opt_bwd_tile_margin.load(),
-                                         0, 8, 0, lds_all)) {
+            BinsPlan bp;
+            memset(&bp, 0, sizeof(bp));
+            int bins_ni = 0;
+            size_t bins_lds = 0;
+            bool planned = false;
+            if (variant == 12) {
+                if (make_tile_plan(pl, shapes_host, N, S, M, D, L, Lq, P, value_bytes, opt_bwd_bins_margin.load(), 0, 8, 0,
+                                   lds_all, false)) {
+                    for (int ni = 2; ni <= 3 && !bins_ni; ++ni)
+                        if (make_bins_plan(bp, pl, ni, bins_lds)) bins_ni = ni;
+                }
+                planned = bins_ni != 0;
+                if (!planned) variant = 10;
+            }
+            if (!planned)
+                planned = P <= 8 && make_tile_plan(pl, shapes_host, N, S, M, D, L, Lq, P, value_bytes,
+                                                   opt_bwd_tile_margin.load(), 0, 8, 0, lds_all);
+            if (planned) {
                 int win_max = 0;
                 for (int l = 0; l < L; ++l) win_max = pl.win[l] > win_max ? pl.win[l] : win_max;
-                const size_t lds = (size_t)(win_max * win_max + 8) * 128 + (size_t)32 * (2 * P + 1) * 16;
+                const size_t lds = variant == 12 ? bins_lds
+                                                 : (size_t)(win_max * win_max + 8) * 128 + (size_t)32 * (2 * P + 1) * 16;
                 const int grid = (pl.n_blocks * L + 7) & ~7;
                 PointSrc src = make_src(loc, attn, fa, M, L, P);
                 pl.ablate = opt_bwd_ablate.load();
@@ -2345,7 +2402,19 @@ int backward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart,
                            grad_proj, pl);                                                                           \
     } while (0)
                 const bool b16 = sizeof(TV) == 2;
-                if (variant == 11) {
+#define MSDA_LAUNCH_BINS(NI, NAME)                                                                                   \
+    do {                                                                                                             \
+        g_kernel = NAME;                                                                                             \
+        hipLaunchKernelGGL((msda_bwd_d32_bins<NI, TV>), dim3(grid), dim3(kTileThreads), lds, stream, value, lstart,  \
+                           src, grad_out, (float *)grad_value, (float *)grad_loc, (float *)grad_attn, grad_proj, pl, \
+                           bp);                                                                                      \
+    } while (0)
+                if (variant == 12) {
+                    if (bins_ni == 2) MSDA_LAUNCH_BINS(2, split ? (b16 ? "msda_bwd_d32_tile_bins<bf16,split>" : "msda_bwd_d32_tile_bins<split>")
+                                                                : (b16 ? "msda_bwd_d32_tile_bins<bf16>" : "msda_bwd_d32_tile_bins"));
+                    else MSDA_LAUNCH_BINS(3, split ? (b16 ? "msda_bwd_d32_tile_bins<3,bf16,split>" : "msda_bwd_d32_tile_bins<3,split>")
+                                                   : (b16 ? "msda_bwd_d32_tile_bins<3,bf16>" : "msda_bwd_d32_tile_bins<3>"));
+                } else if (variant == 11) {
                     if (split) MSDA_LAUNCH_LV(4, false, b16 ? "msda_bwd_d32_tile_lv<4,bf16,split>" : "msda_bwd_d32_tile_lv<4,split>");
                     else if (fused) MSDA_LAUNCH_LV(4, true, b16 ? "msda_bwd_d32_tile_lv<4,bf16,fused>" : "msda_bwd_d32_tile_lv<4,fused>");
                     else MSDA_LAUNCH_LV(4, false, b16 ? "msda_bwd_d32_tile_lv<4,bf16>" : "msda_bwd_d32_tile_lv<4>");
@@ -2355,6 +2424,7 @@ int backward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart,
                     else MSDA_LAUNCH_LV(2, false, b16 ? "msda_bwd_d32_tile_lv<2,bf16>" : "msda_bwd_d32_tile_lv<2>");
                 }
 #undef MSDA_LAUNCH_LV
+#undef MSDA_LAUNCH_BINS
                 rc = check_launch(g_kernel);
                 if (rc || !fused) return rc;
                 const int jgrid = clamp_grid((n_rows * 8 + 255) / 256, 16);
@@ -2654,6 +2724,7 @@ static std::atomic<int> *find_opt(const char *key) {
     if (!strcmp(key, "bwd_ablate")) return &opt_bwd_ablate;
     if (!strcmp(key, "bwd_wide_log2")) return &opt_bwd_wide_log2;
     if (!strcmp(key, "bwd_split")) return &opt_bwd_split;
+    if (!strcmp(key, "bwd_bins_margin")) return &opt_bwd_bins_margin;
     if (!strcmp(key, "bwd_rows")) return &opt_bwd_rows;
     if (!strcmp(key, "bwd_rows_block")) return &opt_bwd_rows_block;
     if (!strcmp(key, "fwd_win_rlog")) return &opt_fwd_win_rlog;

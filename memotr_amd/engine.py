@@ -183,6 +183,7 @@ def clip_forward_backward(model: nn.Module, criterion, batch: dict, device, use_
         if side is not None and ci > 0:
             main = torch.cuda.current_stream()
             batch_frames = frames(lo, lo + n)      # assembled on the main stream, read on the side stream
+            batch_frames.encode_slot = ci
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 enc = model(frame=batch_frames, stage="encode")

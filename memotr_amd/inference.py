@@ -101,6 +101,7 @@ class SequenceTracker:
     def _encode(self, image: torch.Tensor) -> dict:
         frame = tensor_list_to_nested_tensor([image]).to(self.device)
         frame.encode_slot = self._slot          # (models/infer_graphs.py: one static `memory` per slot)
+        frame.encode_static_ok = True           # ... read in place: this loop alternates the two slots itself
         self._slot ^= 1
         return self.model(frame=frame, stage="encode")
 

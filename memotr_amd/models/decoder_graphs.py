@@ -25,28 +25,17 @@ from __future__ import annotations
 
 import contextlib
 import os
-from collections import OrderedDict
-
 import torch
 import torch.nn as nn
 
 from ..functions import clip_ops
 from ..utils.utils import inverse_sigmoid, refine_boxes
+from .graph_cache import MISS_LIMIT, RETRY_AFTER, GraphCache, require_graphs  # noqa: F401 (re-exported)
 from .utils import pos_to_pos_embed
 
 BUCKET = 32
 MAX_GRAPHS = 24          # (frame slots x geometries x buckets) kept alive; least recently used go first
-# Multi-scale / random-crop training gives almost every clip its own pyramid: capturing (two warm-up runs + the capture,
-# forward and backward, ~3x an eager decoder pass, plus a private memory pool) per clip would cost more than the graphs
-# save.  After this many consecutive NEW keys without one replay in between the cache stops capturing; replays of
-# what is already captured continue, and a later recurrence of a geometry (`RETRY_AFTER` eager calls) re-arms it.
-MISS_LIMIT = 12
-RETRY_AFTER = 200
-
-
-def require_graphs() -> bool:
-    """MEMOTR_REQUIRE_GRAPHS=1 (set by bench.py): a capture failure is an error, not a silent eager fallback."""
-    return os.environ.get("MEMOTR_REQUIRE_GRAPHS", "0") == "1"
+# (the thrash guard -- MISS_LIMIT / RETRY_AFTER -- and MEMOTR_REQUIRE_GRAPHS live in graph_cache.py)
 
 
 class DecoderLoop(nn.Module):
@@ -100,29 +89,39 @@ def _thread_local_capture(census=None):
     memory) invalidates it.  The decoder capture only needs the capturing threads themselves to behave, so the graph
     context is switched to "thread_local" for its duration.  ``census`` (a list, default: the module's ``CENSUS``)
     receives {node type: count} of every graph captured inside."""
-    orig = torch.cuda.graph
     CENSUS = census if census is not None else globals()["CENSUS"]
+    # The patch below replaces process-global names: one capture at a time (re-entrant for the capturing thread), and
+    # the originals are read under the lock so that a nested use restores what it found.
+    with _PATCH_LOCK:
+        orig = torch.cuda.graph
+        orig_graph_cls = torch.cuda.CUDAGraph
 
-    class _Graph(orig):
-        def __init__(self, *args, **kwargs):
-            kwargs.setdefault("capture_error_mode", "thread_local")
-            super().__init__(*args, **kwargs)
+        class _Graph(orig):
+            def __init__(self, *args, **kwargs):
+                kwargs.setdefault("capture_error_mode", "thread_local")
+                super().__init__(*args, **kwargs)
 
-        def __exit__(self, *exc):
-            out = super().__exit__(*exc)
-            if exc[0] is None and CENSUS is not None:
-                CENSUS.append(graph_node_census(self.cuda_graph))
-            return out
+            def __exit__(self, *exc):
+                out = super().__exit__(*exc)
+                if exc[0] is None and CENSUS is not None:
+                    CENSUS.append(graph_node_census(self.cuda_graph))
+                return out
 
-    orig_graph_cls = torch.cuda.CUDAGraph
-    if CENSUS is not None:       # (the raw hipGraph_t only survives capture_end when asked for)
-        torch.cuda.CUDAGraph = lambda *a, **k: orig_graph_cls(keep_graph=True)
-    torch.cuda.graph = _Graph
-    try:
-        yield
-    finally:
-        torch.cuda.graph = orig
-        torch.cuda.CUDAGraph = orig_graph_cls
+        if CENSUS is not None:       # (the raw hipGraph_t only survives capture_end when asked for)
+            class _KeepGraph(orig_graph_cls):      # a subclass: isinstance(x, torch.cuda.CUDAGraph) keeps working
+                def __new__(cls, *a, **k):
+                    return orig_graph_cls.__new__(cls, keep_graph=True)
+
+            torch.cuda.CUDAGraph = _KeepGraph
+        torch.cuda.graph = _Graph
+        try:
+            yield
+        finally:
+            torch.cuda.graph = orig
+            torch.cuda.CUDAGraph = orig_graph_cls
+
+
+_PATCH_LOCK = __import__("threading").RLock()
 
 
 # MEMOTR_GRAPH_CENSUS=1: every capture appends {node type: count} of its hipGraph here (tools/graph_census.py, the GPU
@@ -210,18 +209,12 @@ def enabled() -> bool:
     return os.environ.get("MEMOTR_DECODER_GRAPHS", "1") != "0"
 
 
-class DecoderGraphs:
+class DecoderGraphs(GraphCache):
     """Cache of captured decoder steps, owned by a ``DeformableDecoder``."""
 
     def __init__(self, decoder):
+        super().__init__("decoder", MAX_GRAPHS)
         self.decoder = decoder
-        self.slots: "OrderedDict[tuple, object]" = OrderedDict()
-        self.failed = False
-        self.captures = 0        # graphs captured so far
-        self.replays = 0         # decoder loops served from a graph
-        self.eager = 0           # decoder loops that were eligible but ran eagerly (thrash guard / failed capture)
-        self._misses = 0         # consecutive new keys
-        self._paused_at = None   # eager count when the thrash guard tripped
 
     def usable(self, output, src) -> bool:
         d = self.decoder
@@ -248,28 +241,9 @@ class DecoderGraphs:
         """The decoder loop of frame ``frame_slot`` through its graph (captured on first use); None if capture failed."""
         key = (frame_slot, tuple(a.shape for a in args), tuple(bool(a.requires_grad) for a in args),
                self._geometry(shapes), clip_ops.config_key())          # (a capture bakes the kernel choice in)
-        slot = self.slots.get(key)
+        slot = self.lookup(key, lambda: self._capture(args, shapes, lsi))
         if slot is None:
-            if self._paused_at is not None:
-                if self.eager - self._paused_at < RETRY_AFTER:
-                    self.eager += 1
-                    return None
-                self._paused_at, self._misses = None, 0        # try again: the input sizes may have settled
-            self._misses += 1
-            if self._misses > MISS_LIMIT and not require_graphs():
-                self._paused_at = self.eager       # every clip brings a new geometry: capturing costs more than it saves
-                self.eager += 1
-                return None
-            slot = self._capture(args, shapes, lsi)
-            if slot is None:
-                self.eager += 1
-                return None
-            self.slots[key] = slot
-            while len(self.slots) > MAX_GRAPHS:
-                self.slots.popitem(last=False)
-        else:
-            self._misses = 0
-            self.slots.move_to_end(key)
+            return None
         fn, params = slot[0], slot[1]
         self.replays += 1
         return fn(*args, self._flat_parameters(params, clip_key))
@@ -328,13 +302,7 @@ class DecoderGraphs:
             fn = checked_capture(lambda: torch.cuda.make_graphed_callables(run, sample, num_warmup_iters=2,
                                                                            allow_unused_input=True))
         except Exception as exc:  # noqa: BLE001 -- capture is an optimisation; eager stays valid
-            if require_graphs():
-                raise RuntimeError(f"decoder graph capture failed and MEMOTR_REQUIRE_GRAPHS=1: "
-                                   f"{type(exc).__name__}: {exc}") from exc
-            import warnings
-            warnings.warn(f"decoder graph capture failed ({type(exc).__name__}: {exc}); running eager")
-            self.failed = True
-            return None
+            return self.capture_failed(exc)
         # functional_call must have put every nn.Parameter back (see DecoderLoop)
         assert all(isinstance(p, nn.Parameter) for p in loop.parameters()) and \
             [id(p) for p in loop.parameters()] == [id(p) for p in params], "decoder parameters were replaced"

@@ -18,13 +18,12 @@ pyramid tensors) comes back from the warm-up call as constants, the graph's only
 from __future__ import annotations
 
 import os
-from collections import OrderedDict
-
 import torch
 
 from ..functions import clip_ops
 from ..utils.nested_tensor import NestedTensor
-from .decoder_graphs import MISS_LIMIT, RETRY_AFTER, checked_capture, require_graphs
+from .decoder_graphs import checked_capture
+from .graph_cache import GraphCache
 
 MAX_GRAPHS = 6           # each holds the activations of a whole batched encode
 
@@ -38,18 +37,12 @@ def enabled() -> bool:
     return v != "0"
 
 
-class EncodeGraphs:
+class EncodeGraphs(GraphCache):
     """Cache of captured encode calls, owned by a ``MeMOTR``."""
 
     def __init__(self, core):
+        super().__init__("encode", MAX_GRAPHS)
         self.core = core
-        self.slots: "OrderedDict[tuple, object]" = OrderedDict()
-        self.failed = False
-        self.captures = 0
-        self.replays = 0
-        self.eager = 0
-        self._misses = 0
-        self._paused_at = None
 
     # ------------------------------------------------------------------ eligibility
     def usable(self, frame: NestedTensor) -> bool:
@@ -73,28 +66,9 @@ class EncodeGraphs:
         # not replay the old ones)
         bufver = sum(b._version for b in self.core.backbone.buffers())
         key = (slot, tuple(frame.tensors.shape), frame.sizes, amp, clip_ops.config_key(), bufver)
-        entry = self.slots.get(key)
+        entry = self.lookup(key, lambda: self._capture(frame, amp))
         if entry is None:
-            if self._paused_at is not None:
-                if self.eager - self._paused_at < RETRY_AFTER:
-                    self.eager += 1
-                    return None
-                self._paused_at, self._misses = None, 0
-            self._misses += 1
-            if self._misses > MISS_LIMIT and not require_graphs():
-                self._paused_at = self.eager
-                self.eager += 1
-                return None
-            entry = self._capture(frame, amp)
-            if entry is None:
-                self.eager += 1
-                return None
-            self.slots[key] = entry
-            while len(self.slots) > MAX_GRAPHS:
-                self.slots.popitem(last=False)
-        else:
-            self._misses = 0
-            self.slots.move_to_end(key)
+            return None
         fn, params, constants, state = entry[:4]
         if state["busy"]:
             # this slot's activations are still waiting for their backward (a second encode call with the same slot
@@ -148,13 +122,7 @@ class EncodeGraphs:
                 fn = checked_capture(lambda: torch.cuda.make_graphed_callables(run, sample, num_warmup_iters=2,
                                                                                allow_unused_input=True))
         except Exception as exc:  # noqa: BLE001 -- capture is an optimisation; eager stays valid
-            if require_graphs():
-                raise RuntimeError(f"encode graph capture failed and MEMOTR_REQUIRE_GRAPHS=1: "
-                                   f"{type(exc).__name__}: {exc}") from exc
-            import warnings
-            warnings.warn(f"encode graph capture failed ({type(exc).__name__}: {exc}); running eager")
-            self.failed = True
-            return None
+            return self.capture_failed(exc)
         live = dict(core.named_parameters())
         assert all(live[n] is p for n, p in zip(names, params)), "encode parameters were replaced by the capture"
         # `constants` were taken from the FIRST (eager, warm-up) call: the geometry caches' own tensors -- ordinary

@@ -1,0 +1,79 @@
+"""The one cache behind every hipGraph capture of the model (decoder loop, batched encode, forward-only inference
+graphs): keyed entries in least-recently-used order, a capture on first use, and a guard that stops capturing when
+keys never recur.
+
+Why a guard: multi-scale / random-crop training gives almost every clip its own pyramid.  A capture costs two warm-up
+runs plus the capture itself (~3x an eager pass, forward and backward) and a private memory pool, so capturing per clip
+would cost more than the graphs save.  After ``MISS_LIMIT`` consecutive NEW keys without one replay in between the
+cache stops capturing; replays of what is already captured continue, and after ``RETRY_AFTER`` eager calls it re-arms
+(the input sizes may have settled).  ``MEMOTR_REQUIRE_GRAPHS=1`` (set by bench.py) never gives up: there a capture
+failure is an error, not a silent eager fallback.
+"""
+from __future__ import annotations
+
+import os
+from collections import OrderedDict
+
+MISS_LIMIT = 12
+RETRY_AFTER = 200
+
+
+def require_graphs() -> bool:
+    return os.environ.get("MEMOTR_REQUIRE_GRAPHS", "0") == "1"
+
+
+class GraphCache:
+    """``lookup(key, capture)`` -> the entry stored under ``key`` or None (the caller then runs eagerly).
+
+    ``capture()`` builds the entry on a miss; it returns None when the capture failed (and is expected to have set
+    ``failed`` and counted itself in ``captures`` otherwise).  Counters: ``captures`` graphs built, ``replays`` calls
+    served from a graph (counted by the owner), ``eager`` eligible calls that ran eagerly."""
+
+    def __init__(self, what: str, max_graphs: int):
+        self.what = what
+        self.max_graphs = max_graphs
+        self.slots: "OrderedDict[tuple, object]" = OrderedDict()
+        self.failed = False
+        self.captures = 0
+        self.replays = 0
+        self.eager = 0
+        self._misses = 0         # consecutive new keys
+        self._paused_at = None   # eager count when the guard tripped
+
+    def lookup(self, key, capture):
+        entry = self.slots.get(key)
+        if entry is not None:
+            self._misses = 0
+            self.slots.move_to_end(key)
+            return entry
+        if self.failed:
+            return None
+        if self._paused_at is not None:
+            if self.eager - self._paused_at < RETRY_AFTER:
+                self.eager += 1
+                return None
+            self._paused_at, self._misses = None, 0
+        self._misses += 1
+        if self._misses > MISS_LIMIT and not require_graphs():
+            self._paused_at = self.eager
+            self.eager += 1
+            return None
+        entry = capture()
+        if entry is None:
+            self.eager += 1
+            return None
+        self.slots[key] = entry
+        while len(self.slots) > self.max_graphs:
+            self.slots.popitem(last=False)
+        return entry
+
+    def capture_failed(self, exc: Exception):
+        """Shared failure policy of the capture sites: an error under MEMOTR_REQUIRE_GRAPHS=1, else a warning, and the
+        cache is marked failed (eager from here on)."""
+        if require_graphs():
+            raise RuntimeError(f"{self.what} graph capture failed and MEMOTR_REQUIRE_GRAPHS=1: "
+                               f"{type(exc).__name__}: {exc}") from exc
+        import warnings
+        warnings.warn(f"{self.what} graph capture failed ({type(exc).__name__}: {exc}); running eager")
+        self.failed = True
+        return None

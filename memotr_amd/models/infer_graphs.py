@@ -10,18 +10,18 @@ storage does not move between frames; a fingerprint of the data pointers re-capt
 Rules kept from the training captures: thread-local capture mode, the memset-node check of this runtime
 (``decoder_graphs.checked_capture``), every tensor the capture read through a raw pointer pinned by the entry, a cache
 that stops capturing when keys never recur.  Outputs are static buffers of the graph: what outlives the frame (decoder
-stacks: the tracks keep slices of them) is cloned after the replay, what is consumed at once (``memory``) is not.
+stacks: the tracks keep slices of them; ``memory`` unless the caller alternates slots itself) is cloned after the replay.
 """
 from __future__ import annotations
 
 import os
-from collections import OrderedDict
 
 import torch
 
 from ..functions import clip_ops
 from ..utils.nested_tensor import NestedTensor
-from .decoder_graphs import MISS_LIMIT, RETRY_AFTER, DecoderLoop, checked_capture, require_graphs
+from .decoder_graphs import DecoderLoop, checked_capture
+from .graph_cache import MISS_LIMIT, RETRY_AFTER, GraphCache, require_graphs  # noqa: F401 (re-exported for the tests)
 
 MAX_GRAPHS = 8
 
@@ -30,18 +30,11 @@ def enabled() -> bool:
     return os.environ.get("MEMOTR_INFER_GRAPHS", "1") != "0" and os.environ.get("MEMOTR_DECODER_GRAPHS", "1") != "0"
 
 
-class ForwardGraphs:
+class ForwardGraphs(GraphCache):
     """LRU cache of forward-only captures: ``run(key, make_fn, inputs)``."""
 
     def __init__(self, what: str):
-        self.what = what
-        self.slots: "OrderedDict[tuple, object]" = OrderedDict()
-        self.failed = False
-        self.captures = 0
-        self.replays = 0
-        self.eager = 0
-        self._misses = 0
-        self._paused_at = None
+        super().__init__(what + " inference", MAX_GRAPHS)
         # a capture stream of its own: the BLAS workspaces torch hands out are per (handle, stream), and a capture
         # bakes the pointer in -- two caches whose graphs may replay concurrently (the next frame's encode on a side
         # stream next to this frame's decoder loop) must not share one
@@ -50,30 +43,9 @@ class ForwardGraphs:
     def run(self, key, make_fn, inputs, pins=()):
         """Outputs of ``make_fn()(*inputs)`` through the graph stored under ``key`` (captured on first use; ``make_fn``
         builds the function to capture and is only called then).  None -> the caller runs eagerly."""
-        entry = self.slots.get(key)
+        entry = self.lookup(key, lambda: self._capture(make_fn(), inputs, pins))
         if entry is None:
-            if self.failed:
-                return None
-            if self._paused_at is not None:
-                if self.eager - self._paused_at < RETRY_AFTER:
-                    self.eager += 1
-                    return None
-                self._paused_at, self._misses = None, 0
-            self._misses += 1
-            if self._misses > MISS_LIMIT and not require_graphs():
-                self._paused_at = self.eager
-                self.eager += 1
-                return None
-            entry = self._capture(make_fn(), inputs, pins)
-            if entry is None:
-                self.eager += 1
-                return None
-            self.slots[key] = entry
-            while len(self.slots) > MAX_GRAPHS:
-                self.slots.popitem(last=False)
-        else:
-            self._misses = 0
-            self.slots.move_to_end(key)
+            return None
         graph, static_in, static_out = entry[:3]
         for dst, src in zip(static_in, inputs):
             if dst.data_ptr() != src.data_ptr():
@@ -105,13 +77,7 @@ class ForwardGraphs:
 
             graph, static_out = checked_capture(make)
         except Exception as exc:  # noqa: BLE001 -- capture is an optimisation; eager stays valid
-            if require_graphs():
-                raise RuntimeError(f"{self.what} inference graph capture failed and MEMOTR_REQUIRE_GRAPHS=1: "
-                                   f"{type(exc).__name__}: {exc}") from exc
-            import warnings
-            warnings.warn(f"{self.what} inference graph capture failed ({type(exc).__name__}: {exc}); running eager")
-            self.failed = True
-            return None
+            return self.capture_failed(exc)
         self.captures += 1
         return graph, static_in, static_out, (fn, tuple(pins))
 
@@ -119,16 +85,26 @@ class ForwardGraphs:
 def _fingerprint(module) -> int:
     """Changes when the parameters / buffers of ``module`` move to other storage (``.to()``, ``.half()``, a replaced
     Parameter): the captures read them in place.  In-place updates (``load_state_dict``, an optimiser step) keep it
-    -- and stay valid.  The walk over the module tree costs ~3 ms for the full model, so it is redone every 256
-    calls (and the first and last parameter are looked at every call)."""
+    -- the captured kernels then read the new values through the same pointers.  (Constants DERIVED from buffers, i.e.
+    the folded batch-norm scale / shift of the backbone, are not covered by this: the encode key carries the buffer
+    versions for them.)  The walk over the module tree costs ~3 ms for the full model, so it is redone every 256 calls;
+    the first and the last parameter are looked at on every call."""
     cache = module.__dict__.setdefault("_infer_fingerprint", [0, None, None, None])
     first = next(module.parameters(), None)
-    quick = (None if first is None else first.data_ptr(), None if first is None else first.dtype)
+    last = cache[3]() if cache[3] is not None else None
+    quick = (None if first is None else (first.data_ptr(), first.dtype),
+             None if last is None else (last.data_ptr(), last.dtype))
     cache[0] -= 1
-    if cache[0] <= 0 or cache[2] != quick:
+    if cache[0] <= 0 or cache[2] != quick or (cache[3] is not None and last is None):
+        import weakref
         h = 0
-        for t in list(module.parameters()) + list(module.buffers()):
+        tensors = list(module.parameters()) + list(module.buffers())
+        for t in tensors:
             h = (h * 1000003 + t.data_ptr()) & 0xFFFFFFFFFFFF
+        params = list(module.parameters())
+        last = params[-1] if params else None
+        cache[3] = weakref.ref(last) if last is not None else None
+        quick = (quick[0], None if last is None else (last.data_ptr(), last.dtype))
         cache[0], cache[1], cache[2] = 256, h, quick
     return cache[1]
 
@@ -152,8 +128,11 @@ class InferGraphs:
         masks, geometry = frame.masks, frame.sizes
         # `encode_slot`: a caller that queues the next frame's encode while this frame's `memory` is still being read
         # (inference.SequenceTracker) alternates between two captures, each with its own static output
+        # (the folded batch-norm constants are baked in: an in-place write to a buffer -- a checkpoint load -- must not
+        # replay the old ones; models/encode_graphs.py keys on the same)
+        bufver = sum(b._version for b in core.backbone.buffers())
         key = (getattr(frame, "encode_slot", 0), tuple(frame.tensors.shape), geometry, clip_ops.config_key(),
-               _fingerprint(core))
+               _fingerprint(core), bufver)
         constants = {}
 
         def make_fn():
@@ -180,6 +159,11 @@ class InferGraphs:
             e = self.encode.slots[key]
             self.encode.slots[key] = e[:3] + (e[3] + (dict(constants), extra),)
         consts = self.encode.slots[key][3][2]
+        # `memory` is the graph's static output: the next replay of this (slot, shape) overwrites it.  A caller that
+        # alternates slots itself (inference.SequenceTracker sets `encode_static_ok`) reads it in place; everyone else
+        # gets a copy (1.4 % of a frame's traffic), so two encode results can be held at once
+        if not getattr(frame, "encode_static_ok", False):
+            memory = memory.clone()
         return dict(consts, memory=memory)
 
     # ------------------------------------------------------------------ decoder loop
