@@ -32,17 +32,19 @@
 #pragma once
 
 constexpr unsigned kBinsGRow = 144u;          // LDS bytes per staged grad_out row: 128 + 16 (bank spread for b128 reads)
-constexpr unsigned kBinsStageBytes = 8192u;   // 4 wavefronts x 16 cells x 128 B: the flush transpose, aliases the records
+constexpr unsigned kBinsStageWave = 1024u;    // flush transpose: 8 cells x 128 B per wavefront and pass
 
 #ifndef MSDA_BINS_WGS
-#define MSDA_BINS_WGS 4
+#define MSDA_BINS_WGS 5       // workgroups per CU the register budget is sized for (LDS: ~31 KB per workgroup)
 #endif
 
 struct BinsPlan {
     int n_items;             // rows * P
     int magic_p;             // (i * magic_p) >> 16 == i / P for i < 256 * NI
     int scan_c;              // cells per lane in the prefix sum (multiple of 4); counters are padded to 64 * scan_c
-    unsigned o_e, o_r, o_fl, o_rowq, o_cnt, o_start;   // byte offsets into dynamic LDS (grad_out rows at 0)
+    // byte offsets into dynamic LDS (grad_out rows at 0).  o_x is a union: the items' records (16 B each) and flags
+    // (at o_fl) until the row phase is over, the sorted entries afterwards.
+    unsigned o_x, o_fl, o_st, o_rowp, o_rowa, o_cnt, o_start, o_cells, o_misc;   // (o_misc: 4 sums + 64 flush offsets)
 };
 
 __device__ __forceinline__ unsigned bins_incl_scan(unsigned x, int lane) {
@@ -52,6 +54,19 @@ __device__ __forceinline__ unsigned bins_incl_scan(unsigned x, int lane) {
         if (lane >= o) x += y;
     }
     return x;
+}
+
+// sum over the wavefront, DPP inside the rows of 16 lanes, the four row sums through SGPRs; every lane gets the sum
+__device__ __forceinline__ float bins_wave_sum(float x) {
+    x += MSDA_DPP(x, 0xB1);      // quad_perm [1,0,3,2]
+    x += MSDA_DPP(x, 0x4E);      // quad_perm [2,3,0,1]
+    x += MSDA_DPP(x, 0x141);     // row_half_mirror
+    x += MSDA_DPP(x, 0x140);     // row_mirror
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 48));
+    return (r0 + r1) + (r2 + r3);
 }
 
 // four consecutive channels of a grad_out row as floats
@@ -77,6 +92,8 @@ __device__ __forceinline__ float bins_dot8(const f32x4 ga, const f32x4 va, const
 
 __device__ __forceinline__ int bins_mul24(int a, int b) { return __mul24(a, b); }
 
+#define BINS_DPP_U(x, ctrl) ((unsigned)__builtin_amdgcn_update_dpp(0, (int)(x), (ctrl), 0xF, 0xF, true))
+
 #define MSDA_QUAD_SUM(x)                                          \
     do {                                                          \
         (x) += MSDA_DPP((x), 0xB1); /* quad_perm [1,0,3,2] */     \
@@ -91,8 +108,8 @@ __global__ __launch_bounds__(kTileThreads, MSDA_BINS_WGS) void msda_bwd_d32_bins
     constexpr int D = 32;
     constexpr unsigned ROWB = 32u * (unsigned)sizeof(TV);
     constexpr bool kB16 = sizeof(TV) == 2;
-    __shared__ float s_sum[4];
-    __shared__ unsigned s_off[kTileThreads / 64][16];       // flush: grad_value byte offset of a wavefront's 16 cells
+    constexpr unsigned kChunkDelta = kB16 ? 16u : 64u;      // between a lane's two 16-byte chunks of a staged grad_out row
+    // (no static LDS: the dynamic block then starts at LDS address 0 and every offset below folds into the instructions)
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
 
     // ---- block -> (batch, region, head, level); XCD-aware like tile_lv ----
@@ -112,29 +129,42 @@ __global__ __launch_bounds__(kTileThreads, MSDA_BINS_WGS) void msda_bwd_d32_bins
         if (l == i) { H = pl.H[i]; W = pl.W[i]; win = pl.win[i]; magic = pl.win_magic[i]; shl = pl.shift[i]; }
     const int lstart_l = (int)lstart[l];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rows = pl.rows, n_items = bp.n_items, ncell = win * win;
+    const int rows = pl.rows, n_items = bp.n_items;
 
     unsigned char *const G = s_dyn;
-    u32x2 *const E = reinterpret_cast<u32x2 *>(s_dyn + bp.o_e);
-    u32x4 *const R = reinterpret_cast<u32x4 *>(s_dyn + bp.o_r);
+    u32x4 *const R = reinterpret_cast<u32x4 *>(s_dyn + bp.o_x);
     unsigned *const FL = reinterpret_cast<unsigned *>(s_dyn + bp.o_fl);
-    unsigned *const ROWQ = reinterpret_cast<unsigned *>(s_dyn + bp.o_rowq);
+    unsigned *const ROWP = reinterpret_cast<unsigned *>(s_dyn + bp.o_rowp);
+    unsigned *const ROWA = reinterpret_cast<unsigned *>(s_dyn + bp.o_rowa);
     unsigned *const CNT = reinterpret_cast<unsigned *>(s_dyn + bp.o_cnt);
     unsigned *const START = reinterpret_cast<unsigned *>(s_dyn + bp.o_start);
+    unsigned short *const CELLS = reinterpret_cast<unsigned short *>(s_dyn + bp.o_cells);
+    float *const s_sum = reinterpret_cast<float *>(s_dyn + bp.o_misc);
+    unsigned *const s_off = reinterpret_cast<unsigned *>(s_dyn + bp.o_misc + 16u) + wave * 16;   // flush: grad_value byte offsets of this wavefront's 16 cells
     const __amdgpu_buffer_rsrc_t vr = make_rsrc(value, pl.value_bytes);
     const __amdgpu_buffer_rsrc_t gr = make_rsrc(grad_value, (unsigned)((size_t)pl.N * pl.S * M * D * 4u));
 
-    // ---- phase 0: counters, grad_out rows -> LDS, this thread's items ----
+    // ---- phase -1: the region's row table (one level_tile_row per row, not per use), zeroed counters ----
     if (tid < 4) s_sum[tid] = 0.f;
     for (int i = tid; i < bp.scan_c * 64; i += kTileThreads) CNT[i] = 0u;
+    if (tid <= rows) {                                  // (tid == rows: the zero row, not ok)
+        const LevelPlanRow row = level_tile_row(pl, tid, ry, rx);
+        const unsigned qrow = (unsigned)b * (unsigned)pl.Lq + (unsigned)row.q;
+        const unsigned pm = qrow * (unsigned)M + (unsigned)m;
+        ROWP[tid] = row.ok ? pm : 0xffffffffu;
+        // first output element of the row (floats): a row of grad_proj (split fused backward) or of grad_attn (plain;
+        // grad_loc is twice that)
+        ROWA[tid] = grad_proj != nullptr ? qrow * (unsigned)src.proj_stride : pm * (unsigned)LP;
+    }
+    __syncthreads();      // B0
+
+    // ---- phase 0: grad_out rows -> LDS, this thread's items ----
     for (int idx = tid; idx < (rows + 1) * 8; idx += kTileThreads) {
         const int r = idx >> 3, c = idx & 7;
-        const LevelPlanRow row = level_tile_row(pl, r, ry, rx);           // r == rows: not ok -> the zero row
-        const unsigned qrow = (unsigned)b * (unsigned)pl.Lq + (unsigned)row.q;
+        const unsigned pm = ROWP[r];
         f32x4 g = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (row.ok) g = bins_load_g4<TV>(grad_out + ((qrow * (unsigned)M + (unsigned)m) * (unsigned)D + (unsigned)(c * 4)));
+        if (pm != 0xffffffffu) g = bins_load_g4<TV>(grad_out + (pm * (unsigned)D + (unsigned)(c * 4)));
         *reinterpret_cast<f32x4 *>(G + (unsigned)r * kBinsGRow + (unsigned)c * 16u) = g;
-        if (c == 0 && r < rows) ROWQ[r] = row.ok ? qrow : 0xffffffffu;
     }
     int it_r[NI];
     bool it_live[NI], it_gate[NI];
@@ -145,14 +175,12 @@ __global__ __launch_bounds__(kTileThreads, MSDA_BINS_WGS) void msda_bwd_d32_bins
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
             const int it = tid + k * kTileThreads;
-            it_live[k] = it < n_items;
-            const int itc = it_live[k] ? it : 0;
+            const bool live = it < n_items;
+            const int itc = live ? it : 0;
             const int r = bins_mul24(itc, bp.magic_p) >> 16, p = itc - bins_mul24(r, P);
             it_r[k] = r;
-            const LevelPlanRow row = level_tile_row(pl, r, ry, rx);
-            const bool ok = row.ok && it_live[k];
-            const unsigned qrow = (unsigned)b * (unsigned)pl.Lq + (unsigned)row.q;
-            const unsigned pm = qrow * (unsigned)M + (unsigned)m;
+            const unsigned pm = ROWP[r];
+            const bool ok = live && pm != 0xffffffffu;
             const unsigned t = (unsigned)(l * P + p);
             f32x2 xy = f32x2{0.f, 0.f};
             float a = 0.f;
@@ -162,7 +190,7 @@ __global__ __launch_bounds__(kTileThreads, MSDA_BINS_WGS) void msda_bwd_d32_bins
             }
             const Sample<float> s = sample_setup<float>(xy.x, xy.y, H, W);
             const bool gate = s.gate && ok;
-            it_live[k] = ok;                       // from here on: the row exists
+            it_live[k] = ok;                       // the row exists
             it_gate[k] = gate;
             it_h0[k] = s.h_low;
             it_w0[k] = s.w_low;
@@ -175,17 +203,17 @@ __global__ __launch_bounds__(kTileThreads, MSDA_BINS_WGS) void msda_bwd_d32_bins
                 cn += 1.f;
             }
         }
-        sx = wave_sum(sx);
-        sy = wave_sum(sy);
-        cn = wave_sum(cn);
+        sx = bins_wave_sum(sx);
+        sy = bins_wave_sum(sy);
+        cn = bins_wave_sum(cn);
         if (lane == 0) {
             atomicAdd(&s_sum[0], sx);
             atomicAdd(&s_sum[1], sy);
             atomicAdd(&s_sum[2], cn);
         }
     }
-    __syncthreads();      // B1: counters zeroed, grad_out rows staged, position sums complete
-    if (pl.ablate & 8) return;      // (profiling: bits 8 / 16 stop after phase 0 / 1, 32 / 64 skip phase 3 / 2)
+    __syncthreads();      // B1: grad_out rows staged, position sums complete
+    if (pl.ablate & 8) return;      // (profiling: bits 8 / 16 stop after phase 0 / 1, 32 / 64 skip the row phase / the sort)
 
     // ---- phase 1: window origin (every thread: the same inputs give the same bits), tickets, records ----
     int oy, ox;
@@ -254,155 +282,192 @@ __global__ __launch_bounds__(kTileThreads, MSDA_BINS_WGS) void msda_bwd_d32_bins
     __syncthreads();      // B2: tickets drawn, records written
     if (pl.ablate & 16) return;
 
-    // ---- phase 2: prefix sum over the cells (every wavefront for itself: no barrier), entries to their places ----
-    unsigned total = 0u;
-    if (!(pl.ablate & 64)) {
-        const int C = bp.scan_c;
-        unsigned sum = 0u;
-        for (int j = 0; j < C; ++j) sum += CNT[lane * C + j];
-        const unsigned incl = bins_incl_scan(sum, lane);
-        unsigned run = incl - sum;
-        for (int j = 0; j < C; ++j) {
-            START[lane * C + j] = run;             // (the four wavefronts write the same values)
-            run += CNT[lane * C + j];
-        }
-        total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
-        if (lane == 63) E[total] = u32x2{(unsigned)rows * kBinsGRow, 0u};      // the list terminator: zero row, weight 0
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int k = 0; k < NI; ++k) {
-        if (pl.ablate & 64) break;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            if (cr[k][c] != 0xffffffffu) {
-                const unsigned pos = START[cr[k][c] & 0xffffu] + (cr[k][c] >> 16);
-                E[pos] = u32x2{(unsigned)it_r[k] * kBinsGRow, __float_as_uint(wa[k][c])};
-            }
-        }
-    }
-
-    // ---- phase 3: the items' gradient dot products: 4 lanes x 8 channels per item, 16 items per wavefront step ----
+    // ---- phase 2: the items' gradient dot products: 4 lanes x 8 channels per item, 16 items per wavefront step ----
     const int grp = lane >> 2, j4 = lane & 3;
     const unsigned ch_a = kB16 ? 2u * (unsigned)j4 : (unsigned)j4;             // this lane's two 16-byte chunks of a
     const unsigned ch_b = kB16 ? 2u * (unsigned)j4 + 1u : (unsigned)j4 + 4u;   // staged (fp32) grad_out row
     const unsigned ps = (unsigned)M * ROWB, wps = (unsigned)W * ps;
     const unsigned gps = (unsigned)M * 128u, gwps = (unsigned)W * gps;
-    for (int st = wave; st * 16 < n_items && !(pl.ablate & 32); st += kTileThreads / 64) {
-        const int it = st * 16 + grp;
-        const bool vi = it < n_items;
-        const int itc = vi ? it : n_items - 1;
-        const u32x4 rec = R[itc];
-        const unsigned fl = vi ? FL[itc] : 0u;
-        const int r = bins_mul24(itc, bp.magic_p) >> 16, p = itc - bins_mul24(r, P);
-        const f32x4 ga = *reinterpret_cast<const f32x4 *>(G + (unsigned)r * kBinsGRow + ch_a * 16u);
-        const f32x4 gb = *reinterpret_cast<const f32x4 *>(G + (unsigned)r * kBinsGRow + ch_b * 16u);
-        const unsigned qrow = ROWQ[r];
-        const unsigned base = rec.x + (unsigned)j4 * 16u;
-        const bool ld = !(pl.ablate & 4);
-        const unsigned off[4] = {((fl & 1u) && ld) ? base : kOobOffset, ((fl & 2u) && ld) ? base + ps : kOobOffset,
-                                 ((fl & 4u) && ld) ? base + wps : kOobOffset,
-                                 ((fl & 8u) && ld) ? base + wps + ps : kOobOffset};
-        f32x4 va[4], vb[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (kB16) {
-                const u32x4 u = buf_load_u4(vr, off[k]);
-                va[k] = f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
-                              __uint_as_float(u.y & 0xffff0000u)};
-                vb[k] = f32x4{__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u), __uint_as_float(u.w << 16),
-                              __uint_as_float(u.w & 0xffff0000u)};
-            } else {
-                va[k] = buf_load_f4(vr, off[k]);
-                vb[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(vr, (int)off[k], 64, 0));
-            }
-        }
-        float d[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            d[k] = bins_dot8(ga, va[k], gb, vb[k]);
-            MSDA_QUAD_SUM(d[k]);
-        }
-        const float lh = __uint_as_float(rec.y), lw = __uint_as_float(rec.z), a = __uint_as_float(rec.w);
-        const float hh = 1.f - lh, hw = 1.f - lw;
-        const float wk[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
-        const float r_a = wk[0] * d[0] + wk[1] * d[1] + wk[2] * d[2] + wk[3] * d[3];
-        const float r_w = a * (hh * (d[1] - d[0]) + lh * (d[3] - d[2]));
-        const float r_h = a * (hw * (d[2] - d[0]) + lw * (d[3] - d[1]));
-        if ((fl & 0x100u) && j4 < 3) {
-            const float outv = j4 == 0 ? r_w * (float)W : (j4 == 1 ? r_h * (float)H : r_a);
-            if (grad_proj != nullptr) {      // split fused backward: raw d/d(location), d/d(attention) into grad_proj's columns
-                const unsigned col = j4 < 2 ? (unsigned)(m * 2 * LP + l * P * 2 + 2 * p + j4)
-                                            : (unsigned)(src.n_off + m * LP + l * P + p);
-                grad_proj[qrow * (unsigned)src.proj_stride + col] = outv;
-            } else {
-                const unsigned pm = qrow * (unsigned)M + (unsigned)m;
-                if (j4 < 2) grad_loc[pm * (unsigned)(LP * 2) + (unsigned)(l * P * 2 + 2 * p + j4)] = outv;
-                else grad_attn[pm * (unsigned)LP + (unsigned)(l * P + p)] = outv;
-            }
-        }
-        if (!(pl.ablate & 2) && __builtin_amdgcn_ballot_w64((fl & 0xf0u) != 0u) != 0ull) {   // rare: corners outside the window
-            const unsigned gbase = rec.x * (128u / ROWB);
-            const unsigned dg[4] = {0u, gps, gwps, gwps + gps};
+    {
+        // lane roles inside an item's quad: 0 -> d/dx, 1 -> d/dy, 2 -> d/d(attention), 3 -> none
+        const bool role_y = j4 == 1, role_a = j4 == 2;
+        const float size_r = role_y ? (float)H : (float)W;
+        const bool split = grad_proj != nullptr;
+        float *const dst_base = split ? grad_proj : (role_a ? grad_attn : grad_loc);
+        const unsigned sh_row = (!split && !role_a) ? 1u : 0u;      // plain grad_loc rows are twice as long
+        const unsigned sh_p = role_a ? 0u : 1u;
+        const unsigned col = split ? (role_a ? (unsigned)(src.n_off + m * LP + l * P) : (unsigned)(m * 2 * LP + l * P * 2 + j4))
+                                   : (role_a ? (unsigned)(l * P) : (unsigned)(l * P * 2 + j4));
+        for (int st = wave; st * 16 < n_items && !(pl.ablate & 32); st += kTileThreads / 64) {
+            const int it = st * 16 + grp;
+            const bool vi = it < n_items;
+            const int itc = vi ? it : n_items - 1;
+            const u32x4 rec = R[itc];
+            const unsigned fl = vi ? FL[itc] : 0u;
+            const int r = bins_mul24(itc, bp.magic_p) >> 16, p = itc - bins_mul24(r, P);
+            const unsigned char *const grow = G + (unsigned)r * kBinsGRow + ch_a * 16u;
+            const f32x4 ga = *reinterpret_cast<const f32x4 *>(grow);
+            const f32x4 gb = *reinterpret_cast<const f32x4 *>(grow + kChunkDelta);
+            const unsigned rowa = ROWA[r];
+            const unsigned base = rec.x + (unsigned)j4 * 16u;
+            const bool ld = !(pl.ablate & 4);
+            const unsigned off[4] = {((fl & 1u) && ld) ? base : kOobOffset, ((fl & 2u) && ld) ? base + ps : kOobOffset,
+                                     ((fl & 4u) && ld) ? base + wps : kOobOffset,
+                                     ((fl & 8u) && ld) ? base + wps + ps : kOobOffset};
+            f32x4 va[4], vb[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                if (fl & (16u << k)) {
-                    const float w = wk[k] * a;
+                if (kB16) {
+                    const u32x4 u = buf_load_u4(vr, off[k]);
+                    va[k] = f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                                  __uint_as_float(u.y & 0xffff0000u)};
+                    vb[k] = f32x4{__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u), __uint_as_float(u.w << 16),
+                                  __uint_as_float(u.w & 0xffff0000u)};
+                } else {
+                    va[k] = buf_load_f4(vr, off[k]);
+                    vb[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(vr, (int)off[k], 64, 0));
+                }
+            }
+            float d[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(w * ga[i], gr, (int)(gbase + dg[k] + ch_a * 16u + (unsigned)i * 4u), 0, 0);
-                        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(w * gb[i], gr, (int)(gbase + dg[k] + ch_b * 16u + (unsigned)i * 4u), 0, 0);
+            for (int k = 0; k < 4; ++k) {
+                d[k] = bins_dot8(ga, va[k], gb, vb[k]);
+                MSDA_QUAD_SUM(d[k]);
+            }
+            const float lh = __uint_as_float(rec.y), lw = __uint_as_float(rec.z), a = __uint_as_float(rec.w);
+            const float hh = 1.f - lh, hw = 1.f - lw;
+            const float wk[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
+            // d/dx = a (hh (d1 - d0) + lh (d3 - d2)) W,  d/dy = a (hw (d2 - d0) + lw (d3 - d1)) H: one expression, the
+            // lane's role picks the operands (no divergent branches)
+            const float pp = role_y ? hw : hh, qq = role_y ? lw : lh;
+            const float d_a = role_y ? d[2] : d[1], d_c = role_y ? d[1] : d[2];
+            const float r_loc = (a * size_r) * (pp * (d_a - d[0]) + qq * (d[3] - d_c));
+            const float r_att = wk[0] * d[0] + wk[1] * d[1] + wk[2] * d[2] + wk[3] * d[3];
+            const float outv = role_a ? r_att : r_loc;
+            if ((fl & 0x100u) && j4 < 3) dst_base[(rowa << sh_row) + col + ((unsigned)p << sh_p)] = outv;
+            if (!(pl.ablate & 2) && __builtin_amdgcn_ballot_w64((fl & 0xf0u) != 0u) != 0ull) {   // rare: corners outside the window
+                const unsigned gbase = rec.x * (128u / ROWB);
+                const unsigned dg[4] = {0u, gps, gwps, gwps + gps};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (fl & (16u << k)) {
+                        const float w = wk[k] * a;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(w * ga[i], gr, (int)(gbase + dg[k] + ch_a * 16u + (unsigned)i * 4u), 0, 0);
+                            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(w * gb[i], gr, (int)(gbase + dg[k] + ch_b * 16u + (unsigned)i * 4u), 0, 0);
+                        }
                     }
                 }
             }
         }
     }
-    __syncthreads();      // B3: every entry is in place; the records are dead (the flush transpose reuses their LDS)
+    __syncthreads();      // B3: the records are dead -- the sorted entries take their place
 
-    // ---- phase 4: per cell, gather its entries; flush the sums as whole 128-byte rows ----
-    if (pl.ablate & 2) return;
-    unsigned char *const ST = s_dyn + bp.o_r + (unsigned)wave * 2048u;
-    const int half = lane >> 5, c32 = lane & 31;
-    for (int round = 0; round * 64 < ncell; ++round) {
-        const int cell0 = round * 64 + wave * 16;
-        const int cell = cell0 + grp;
-        const bool live = cell < ncell;
-        const unsigned n = live ? CNT[cell] : 0u, s0 = live ? START[cell] : 0u;
-        if (__builtin_amdgcn_ballot_w64(n != 0u) == 0ull) continue;      // (wave-uniform)
-        f32x4 acc_a = f32x4{0.f, 0.f, 0.f, 0.f}, acc_b = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (unsigned i = 0; __builtin_amdgcn_ballot_w64(i < n) != 0ull; i += 2) {
-            const unsigned i0 = i < n ? s0 + i : total, i1 = i + 1 < n ? s0 + i + 1 : total;
-            const u32x2 e0 = E[i0], e1 = E[i1];
-            const f32x4 a0 = *reinterpret_cast<const f32x4 *>(G + e0.x + ch_a * 16u);
-            const f32x4 b0 = *reinterpret_cast<const f32x4 *>(G + e0.x + ch_b * 16u);
-            const f32x4 a1 = *reinterpret_cast<const f32x4 *>(G + e1.x + ch_a * 16u);
-            const f32x4 b1 = *reinterpret_cast<const f32x4 *>(G + e1.x + ch_b * 16u);
-            const float w0 = __uint_as_float(e0.y), w1 = __uint_as_float(e1.y);
-            acc_a += w0 * a0;
-            acc_b += w0 * b0;
-            acc_a += w1 * a1;
-            acc_b += w1 * b1;
+    // ---- phase 3: prefix sum over the cells (every wavefront for itself), list of the non-empty cells, entries ----
+    u32x2 *const E = reinterpret_cast<u32x2 *>(s_dyn + bp.o_x);
+    unsigned total = 0u, nz_total = 0u;
+    if (!(pl.ablate & 64)) {
+        const int C = bp.scan_c;
+        unsigned packed = 0u;          // entries in the low half, non-empty cells in the high half
+        for (int j = 0; j < C; j += 4) {
+            const u32x4 c4 = *reinterpret_cast<const u32x4 *>(&CNT[lane * C + j]);
+            packed += (c4.x + c4.y + c4.z + c4.w) +
+                      (((c4.x ? 1u : 0u) + (c4.y ? 1u : 0u) + (c4.z ? 1u : 0u) + (c4.w ? 1u : 0u)) << 16);
         }
-        if (pl.ablate & 1) continue;
-        *reinterpret_cast<f32x4 *>(ST + (unsigned)grp * 128u + ch_a * 16u) = acc_a;
-        *reinterpret_cast<f32x4 *>(ST + (unsigned)grp * 128u + ch_b * 16u) = acc_b;
-        if (j4 == 0) {      // where the cell's row goes (cells nothing was added to: dropped by the buffer's range check)
-            const int wy = bins_mul24(cell, magic) >> 16, wx = cell - bins_mul24(wy, win);
-            const unsigned goff = (((unsigned)b * (unsigned)pl.S + (unsigned)(lstart_l + bins_mul24(oy + wy, W) + ox + wx)) *
-                                   (unsigned)M + (unsigned)m) * 128u;
-            s_off[wave][grp] = n != 0u ? goff : kOobOffset;
+        const unsigned incl = bins_incl_scan(packed, lane);
+        unsigned run = incl - packed;
+        for (int j = 0; j < C; j += 4) {
+            const u32x4 c4 = *reinterpret_cast<const u32x4 *>(&CNT[lane * C + j]);
+            u32x4 s4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s4[e] = run & 0xffffu;
+                if (c4[e] != 0u) {
+                    CELLS[run >> 16] = (unsigned short)(lane * C + j + e);      // (the four wavefronts write the same values)
+                    run += c4[e] + 0x10000u;
+                }
+            }
+            *reinterpret_cast<u32x4 *>(&START[lane * C + j]) = s4;
         }
+        const unsigned last = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+        total = last & 0xffffu;
+        nz_total = last >> 16;
+        if (lane == 63) E[total] = u32x2{(unsigned)rows * kBinsGRow, 0u};      // the list terminator: zero row, weight 0
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int h = 0; h < 8; ++h) {
-            const int slot = 2 * h + half;
-            const float v = *reinterpret_cast<const float *>(ST + (unsigned)slot * 128u + (unsigned)c32 * 4u);
-            const unsigned goff = s_off[wave][slot] + (unsigned)c32 * 4u;      // (kOobOffset + 124 is still out of range)
-            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, gr, (int)goff, 0, 0);
+        for (int k = 0; k < NI; ++k) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (cr[k][c] != 0xffffffffu) {
+                    const unsigned pos = START[cr[k][c] & 0xffffu] + (cr[k][c] >> 16);
+                    E[pos] = u32x2{(unsigned)it_r[k] * kBinsGRow, __float_as_uint(wa[k][c])};
+                }
+            }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();      // B4: every entry is in place
+    if (pl.ablate & 2) return;
+
+    // ---- phase 4: per non-empty cell, gather its entries; flush the sums as whole 128-byte rows ----
+    unsigned char *const ST = s_dyn + bp.o_st + (unsigned)wave * kBinsStageWave;
+    const int half = lane >> 5, c32 = lane & 31;
+    const unsigned sent = bp.o_x + total * 8u;                      // LDS offset of the terminator
+    const unsigned g_a = ch_a * 16u, g_b = ch_b * 16u;
+    for (int round = 0; round * 64 + wave * 16 < (int)nz_total; ++round) {
+        const int idx = round * 64 + wave * 16 + grp;
+        const bool live = idx < (int)nz_total;
+        const unsigned cell = live ? (unsigned)CELLS[idx] : 0u;
+        const unsigned n = live ? CNT[cell] : 0u;
+        unsigned pe = bp.o_x + START[cell] * 8u;
+        f32x4 acc_a = f32x4{0.f, 0.f, 0.f, 0.f}, acc_b = f32x4{0.f, 0.f, 0.f, 0.f};
+        // trip count: the longest list among this wavefront's 16 cells (the 4 lanes of a cell hold the same n)
+        unsigned nm = n;
+        nm = max(nm, BINS_DPP_U(nm, 0x124));      // row_ror:4
+        nm = max(nm, BINS_DPP_U(nm, 0x128));      // row_ror:8
+        const unsigned nmax = max(max((unsigned)__builtin_amdgcn_readlane((int)nm, 0), (unsigned)__builtin_amdgcn_readlane((int)nm, 16)),
+                                  max((unsigned)__builtin_amdgcn_readlane((int)nm, 32), (unsigned)__builtin_amdgcn_readlane((int)nm, 48)));
+        const unsigned lim = pe + n * 8u;          // one past this cell's last entry
+        for (unsigned i = 0; i < nmax; i += 2, pe += 16u) {
+            const unsigned a0 = pe < lim ? pe : sent, a1 = pe + 8u < lim ? pe + 8u : sent;
+            const u32x2 e0 = *reinterpret_cast<const u32x2 *>(s_dyn + a0);
+            const u32x2 e1 = *reinterpret_cast<const u32x2 *>(s_dyn + a1);
+            const unsigned char *const g0 = G + e0.x + g_a, *const g1 = G + e1.x + g_a;
+            const f32x4 x0 = *reinterpret_cast<const f32x4 *>(g0);
+            const f32x4 y0 = *reinterpret_cast<const f32x4 *>(g0 + kChunkDelta);
+            const f32x4 x1 = *reinterpret_cast<const f32x4 *>(g1);
+            const f32x4 y1 = *reinterpret_cast<const f32x4 *>(g1 + kChunkDelta);
+            const float w0 = __uint_as_float(e0.y), w1 = __uint_as_float(e1.y);
+            acc_a += w0 * x0;
+            acc_b += w0 * y0;
+            acc_a += w1 * x1;
+            acc_b += w1 * y1;
+        }
+        if (pl.ablate & 1) continue;
+        if (j4 == 0) {      // where the cell's row goes (slots past the list: dropped by the buffer's range check)
+            const int wy = bins_mul24((int)cell, magic) >> 16, wx = (int)cell - bins_mul24(wy, win);
+            const unsigned goff = (((unsigned)b * (unsigned)pl.S + (unsigned)(lstart_l + bins_mul24(oy + wy, W) + ox + wx)) *
+                                   (unsigned)M + (unsigned)m) * 128u;
+            s_off[grp] = live ? goff : kOobOffset;
+        }
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            if ((grp >> 3) == pass) {
+                *reinterpret_cast<f32x4 *>(ST + (unsigned)(grp & 7) * 128u + g_a) = acc_a;
+                *reinterpret_cast<f32x4 *>(ST + (unsigned)(grp & 7) * 128u + g_b) = acc_b;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const int slot = 2 * h + half;
+                const float v = *reinterpret_cast<const float *>(ST + (unsigned)slot * 128u + (unsigned)c32 * 4u);
+                const unsigned goff = s_off[pass * 8 + slot] + (unsigned)c32 * 4u;    // (kOobOffset + 124: still out of range)
+                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, gr, (int)goff, 0, 0);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
     }
 }

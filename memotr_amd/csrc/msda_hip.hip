@@ -2089,18 +2089,24 @@ bool make_bins_plan(BinsPlan &bp, const TilePlan &pl, int ni, size_t &lds) {
     bp.n_items = n_items;
     bp.magic_p = magic;
     bp.scan_c = C;
-    bp.o_e = (unsigned)o;
-    o += up16((size_t)(4 * n_items + 1) * 8);
-    bp.o_r = (unsigned)o;
+    bp.o_x = (unsigned)o;                       // records + flags, later the sorted entries
     bp.o_fl = (unsigned)(o + (size_t)n_items * 16);
-    bp.o_rowq = (unsigned)(bp.o_fl + up16((size_t)n_items * 4));
-    size_t region = (size_t)n_items * 16 + up16((size_t)n_items * 4) + up16((size_t)pl.rows * 4);
-    if (region < kBinsStageBytes) region = kBinsStageBytes;
-    o += region;
+    const size_t rec_bytes = up16((size_t)n_items * 20), ent_bytes = up16((size_t)(4 * n_items + 1) * 8);
+    o += rec_bytes > ent_bytes ? rec_bytes : ent_bytes;
+    bp.o_st = (unsigned)o;
+    o += (size_t)(kTileThreads / 64) * kBinsStageWave;
+    bp.o_rowp = (unsigned)o;
+    o += up16((size_t)(pl.rows + 1) * 4);
+    bp.o_rowa = (unsigned)o;
+    o += up16((size_t)(pl.rows + 1) * 4);
     bp.o_cnt = (unsigned)o;
     o += (size_t)C * 64 * 4;
     bp.o_start = (unsigned)o;
     o += (size_t)C * 64 * 4;
+    bp.o_cells = (unsigned)o;
+    o += up16((size_t)C * 64 * 2);
+    bp.o_misc = (unsigned)o;
+    o += 16 + (size_t)(kTileThreads / 64) * 16 * 4;
     lds = o;
     return lds <= 64 * 1024;
 }
