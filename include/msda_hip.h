@@ -28,8 +28,11 @@
  *     it must equal shapes_dev; it lets the library plan level-aware launches
  *     without a device->host read.  Results never depend on it.
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls are
- *     asynchronous, allocate nothing, never synchronise, hold no global state
- *     besides the tuning options below, and are thread-safe.
+ *     asynchronous, never synchronise and are thread-safe.  Global state: the tuning
+ *     options below and, for self-attention over the pyramid, one 32-byte device +
+ *     32-byte mapped-host record per (call site, geometry) through which the kernels
+ *     report how many sampling points left their windows (see "kernel selection";
+ *     allocated on the first such call, never while `stream` is capturing).
  *   - Buffers are borrowed for the duration of the enqueued work.  `out`,
  *     `grad_loc`, `grad_attn` are fully overwritten.  `grad_value` is accumulated
  *     into with hardware float atomics: it must be zero on entry (the reference
@@ -172,6 +175,23 @@ int msda_fused_backward_ws_bf16(const uint16_t *value, const int64_t *shapes_dev
                                 int zero_grad_value, const int64_t *shapes_host,
                                 void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- kernel selection (round 4; memotr_amd/csrc/msda_select.h) ----
+ * The cost of the reference kernels does not depend on where the sampling points land
+ * (ms_deform_im2col_cuda.cuh:237-403); the windowed kernels here are fast for points near their query and slow
+ * for points far away.  With "fwd_variant" / "bwd_variant" 0 the library therefore follows the data: the windowed
+ * kernels report the share of corners outside their windows, and the next call of the same (call site, geometry)
+ * picks the window margin -- or a kernel without windows -- accordingly.  Results never depend on the choice.
+ *   msda_set_call_site   tags the calling thread's following calls (e.g. one tag per attention module; 0 = untagged),
+ *                        so that modules with different learnt offsets on the same geometry are judged separately;
+ *   msda_selector_last   level (0 = small windows ... top = no windows) and the last measured shares of corners outside
+ *                        the window / outside the next smaller window, for this thread's last selected call
+ *                        (shares < 0: nothing measured yet);
+ *   msda_selector_next   the transition function itself (pure; for tests): next level from (kind 0 fwd / 1 bwd,
+ *                        level, off-window and inner-window shares in 1/1000). */
+void msda_set_call_site(uint64_t site);
+int msda_selector_last(int *level, float *off_share, float *inner_share);
+int msda_selector_next(int kind, int level, int off_permille, int inner_permille);
+
 /* ---- parity hooks ----
  * msda_sample_indices_f32: the integer side of the sampling arithmetic.  For every (n,q,m,l,p):
  * h_low = floor(loc_y*H_l - 0.5), w_low = floor(loc_x*W_l - 0.5) and gate = (-1 < h < H_l && -1 < w < W_l) as computed
@@ -197,7 +217,11 @@ int msda_fused_points_f32(const int64_t *shapes_dev, const float *proj, int proj
  *       "fwd_win_*" (region size, block size, margins per level as 0xL3L2L1L0, first windowed level, LDS-DMA fill,
  *       profiling switches; tools/kbench.py lists them), "fwd_head_major" (head-major block numbering of the gather
  *       kernel), "bwd_rows" / "bwd_rows_block" (the 32-lanes-per-row backward of decoder-shaped calls),
- *       "bwd_wide_log2", "bwd_ablate" / "fwd_win_ablate" (profiling only: results are wrong by construction).
+ *       "bwd_wide_log2", "bwd_ablate" / "fwd_win_ablate" (profiling only: results are wrong by construction),
+ *       "bwd_bins_margin" / "bwd_bins_margin_hi" / "bwd_bins_strip" (counting-sort backward, variant 12: window margins
+ *       of selector levels 0 / 1, region rows per strip of the block walk), "auto_select" (0: no selection, level 0),
+ *       "sel_level" (-1: follow the data; >= 0: pin the level), "sel_up0" / "sel_up1" / "sel_down1" / "sel_down2" /
+ *       "sel_fwd_up" / "sel_fwd_down" (thresholds in 1/1000 of the valid corners).
  * Returns MSDA_OK or MSDA_EINVAL for an unknown key / bad value. */
 int msda_set_option(const char *key, int value);
 int msda_get_option(const char *key, int *value);

@@ -94,6 +94,29 @@ def _host_ptr(spatial_shapes, eligible: bool):
     return arr, arr.ctypes.data
 
 
+# ---- kernel selection (include/msda_hip.h, "kernel selection"): which module a call belongs to ----
+import itertools
+import threading
+
+_SITE = threading.local()
+_SITE_IDS = itertools.count(1)
+
+
+def new_call_site() -> int:
+    """A fresh tag for one attention module (the library keeps one off-window record per (tag, geometry))."""
+    return next(_SITE_IDS)
+
+
+def set_call_site(site: int) -> None:
+    """Tag this thread's following operator calls; 0 = untagged."""
+    _SITE.value = int(site)
+    _lib.set_call_site(int(site))
+
+
+def get_call_site() -> int:
+    return getattr(_SITE, "value", 0)
+
+
 def _stream(device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 

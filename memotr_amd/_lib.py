@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MEMOTR_MSDA_LIB") or os.path.join(_HERE, "lib", "libmsda_hip.so")   # (override: A/B builds)
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_int = ctypes.c_int
 c_void_p = ctypes.c_void_p
@@ -44,6 +44,9 @@ SYMBOLS = {
     "msda_fused_workspace_bytes": ([c_int] * 5, ctypes.c_size_t),
     "msda_sample_indices_f32": ([c_void_p, c_void_p] + [c_int] * 5 + [c_void_p] * 4, c_int),
     "msda_fused_points_f32": ([c_void_p, c_void_p, c_int, c_void_p, c_int] + [c_int] * 5 + [c_void_p] * 3, c_int),
+    "msda_set_call_site": ([ctypes.c_uint64], None),
+    "msda_selector_last": ([ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)], c_int),
+    "msda_selector_next": ([c_int] * 4, c_int),
     "msda_set_option": ([ctypes.c_char_p, c_int], c_int),
     "msda_get_option": ([ctypes.c_char_p, ctypes.POINTER(c_int)], c_int),
 }
@@ -90,3 +93,16 @@ def get_option(key: str) -> int:
     if lib.msda_get_option(key.encode(), ctypes.byref(out)) != 0:
         raise ValueError(f"unknown option {key!r}")
     return out.value
+
+
+def set_call_site(site: int) -> None:
+    """Tag this thread's following operator calls (kernel selection keeps one record per (site, geometry))."""
+    lib.msda_set_call_site(ctypes.c_uint64(site & 0xFFFFFFFFFFFFFFFF))
+
+
+def selector_last():
+    """(level, off-window share, share outside the next smaller window) of this thread's last selected call;
+    shares < 0: nothing measured yet."""
+    lv, fr, fi = c_int(0), ctypes.c_float(0.0), ctypes.c_float(0.0)
+    lib.msda_selector_last(ctypes.byref(lv), ctypes.byref(fr), ctypes.byref(fi))
+    return lv.value, fr.value, fi.value

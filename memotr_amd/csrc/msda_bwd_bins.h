@@ -42,9 +42,14 @@ struct BinsPlan {
     int n_items;             // rows * P
     int magic_p;             // (i * magic_p) >> 16 == i / P for i < 256 * NI
     int scan_c;              // cells per lane in the prefix sum (multiple of 4); counters are padded to 64 * scan_c
-    // byte offsets into dynamic LDS (grad_out rows at 0).  o_x is a union: the items' records (16 B each) and flags
-    // (at o_fl) until the row phase is over, the sorted entries afterwards.
-    unsigned o_x, o_fl, o_st, o_rowp, o_rowa, o_cnt, o_start, o_cells, o_misc;   // (o_misc: 4 sums + 64 flush offsets)
+    int strip;               // region rows per strip of the block -> region walk (1: raster order)
+    int shrink, level, parity;   // statistics: also count the corners outside the window shrunk by `shrink` pixels; selector level; launch parity
+    unsigned *stats, *stats_host;   // msda_select.h records (device / mapped host), null: no statistics
+    // byte offsets into dynamic LDS (grad_out rows at 0).  Two unions: o_x holds the items' records (16 B each) and
+    // flags (at o_fl) until the row phase is over, the sorted entries afterwards; o_st holds the ticket counters and the
+    // row tables until the sort is done, the flush transpose afterwards.  o_start: u16 per cell, o_comp: u32 per
+    // non-empty cell (cell | count << 16), o_misc: 4 sums + 64 flush offsets + 3 counters.
+    unsigned o_x, o_fl, o_st, o_rowp, o_rowa, o_cnt, o_start, o_comp, o_misc;
 };
 
 __device__ __forceinline__ unsigned bins_incl_scan(unsigned x, int lane) {
@@ -122,7 +127,15 @@ __global__ __launch_bounds__(kTileThreads, MSDA_BINS_WGS) void msda_bwd_d32_bins
     const int m = id % M;
     const int reg = (id / M) % (pl.RY * pl.RX);
     const int b = id / (M * pl.RY * pl.RX);
-    const int ry = reg / pl.RX, rx = reg - ry * pl.RX;
+    // Regions are walked in strips of `strip` region rows, column by column inside a strip: the windows of vertical
+    // neighbours overlap as much as those of horizontal ones, and in raster order a vertical neighbour comes a whole
+    // region row (thousands of workgroups, tens of MB through this XCD's L2) later -- its flush then finds the shared
+    // grad_value lines evicted.  In strip order both kinds of neighbour are a few dozen workgroups apart.
+    const int sh_rows = bp.strip;
+    const int strip = reg / (sh_rows * pl.RX);
+    const int rem = reg - strip * sh_rows * pl.RX;
+    const int hgt = pl.RY - sh_rows * strip < sh_rows ? pl.RY - sh_rows * strip : sh_rows;
+    const int rx = rem / hgt, ry = sh_rows * strip + (rem - rx * hgt);
     int H = pl.H[0], W = pl.W[0], win = pl.win[0], magic = pl.win_magic[0], shl = pl.shift[0];
 #pragma unroll
     for (int i = 1; i < kTileMaxL; ++i)
@@ -137,8 +150,8 @@ __global__ __launch_bounds__(kTileThreads, MSDA_BINS_WGS) void msda_bwd_d32_bins
     unsigned *const ROWP = reinterpret_cast<unsigned *>(s_dyn + bp.o_rowp);
     unsigned *const ROWA = reinterpret_cast<unsigned *>(s_dyn + bp.o_rowa);
     unsigned *const CNT = reinterpret_cast<unsigned *>(s_dyn + bp.o_cnt);
-    unsigned *const START = reinterpret_cast<unsigned *>(s_dyn + bp.o_start);
-    unsigned short *const CELLS = reinterpret_cast<unsigned short *>(s_dyn + bp.o_cells);
+    unsigned short *const START = reinterpret_cast<unsigned short *>(s_dyn + bp.o_start);
+    unsigned *const COMP = reinterpret_cast<unsigned *>(s_dyn + bp.o_comp);
     float *const s_sum = reinterpret_cast<float *>(s_dyn + bp.o_misc);
     unsigned *const s_off = reinterpret_cast<unsigned *>(s_dyn + bp.o_misc + 16u) + wave * 16;   // flush: grad_value byte offsets of this wavefront's 16 cells
     const __amdgpu_buffer_rsrc_t vr = make_rsrc(value, pl.value_bytes);
@@ -147,6 +160,10 @@ __global__ __launch_bounds__(kTileThreads, MSDA_BINS_WGS) void msda_bwd_d32_bins
     // ---- phase -1: the region's row table (one level_tile_row per row, not per use), zeroed counters ----
     if (tid < 4) s_sum[tid] = 0.f;
     for (int i = tid; i < bp.scan_c * 64; i += kTileThreads) CNT[i] = 0u;
+    unsigned *const s_cnt = reinterpret_cast<unsigned *>(s_dyn + bp.o_misc + 16u + 256u);   // valid / off / inner corners
+    // statistics (msda_select.h): one workgroup in eight counts -- a sample of > 1000 workgroups per launch
+    const bool stat_wg = bp.stats != nullptr && (sw & 7) == 0;
+    if (tid < 3) s_cnt[tid] = 0u;
     if (tid <= rows) {                                  // (tid == rows: the zero row, not ok)
         const LevelPlanRow row = level_tile_row(pl, tid, ry, rx);
         const unsigned qrow = (unsigned)b * (unsigned)pl.Lq + (unsigned)row.q;
@@ -216,7 +233,7 @@ __global__ __launch_bounds__(kTileThreads, MSDA_BINS_WGS) void msda_bwd_d32_bins
     if (pl.ablate & 8) return;      // (profiling: bits 8 / 16 stop after phase 0 / 1, 32 / 64 skip the row phase / the sort)
 
     // ---- phase 1: window origin (every thread: the same inputs give the same bits), tickets, records ----
-    int oy, ox;
+    int oy, ox, oyu, oxu;        // window origin, clamped to the level / as measured
     {
         const float cnt = s_sum[2];
         const float cx = cnt > 0.f ? s_sum[0] / cnt : (float)((rx << shl) + (1 << shl) / 2);
@@ -224,6 +241,8 @@ __global__ __launch_bounds__(kTileThreads, MSDA_BINS_WGS) void msda_bwd_d32_bins
         ox = (int)floorf(cx - 0.5f * (float)(win - 1) + 0.5f);
         oy = (int)floorf(cy - 0.5f * (float)(win - 1) + 0.5f);
         const int max_x = W - win, max_y = H - win;
+        oxu = ox;
+        oyu = oy;
         ox = ox > max_x ? max_x : ox;
         oy = oy > max_y ? max_y : oy;
         ox = ox < 0 ? 0 : ox;
@@ -232,6 +251,7 @@ __global__ __launch_bounds__(kTileThreads, MSDA_BINS_WGS) void msda_bwd_d32_bins
     const long mask_base = (long)b * pl.S + lstart_l;
     unsigned cr[NI][4];          // cell | ticket << 16 of the corners that are inside the window, else ~0
     float wa[NI][4];
+    unsigned my_cnt = 0u;        // statistics: valid | outside the window << 10 | outside the shrunk window << 20
 #pragma unroll
     for (int k = 0; k < NI; ++k) {
         const int h0 = it_h0[k], w0 = it_w0[k];
@@ -268,6 +288,20 @@ __global__ __launch_bounds__(kTileThreads, MSDA_BINS_WGS) void msda_bwd_d32_bins
             fl |= (v[c] ? 1u : 0u) << c;
             fl |= ((v[c] && !in[c]) ? 1u : 0u) << (4 + c);
         }
+        if (stat_wg) {
+            // the window a margin smaller by `shrink` would have had: same centre, clamped to the level the same way
+            const int sh = bp.shrink, ws = win - 2 * sh;
+            const int mxs = W - ws > 0 ? W - ws : 0, mys = H - ws > 0 ? H - ws : 0;
+            int oxs = oxu + sh < mxs ? oxu + sh : mxs, oys = oyu + sh < mys ? oyu + sh : mys;
+            oxs = oxs < 0 ? 0 : oxs;
+            oys = oys < 0 ? 0 : oys;
+            const unsigned wn = (unsigned)ws;
+            const bool jy0 = (unsigned)(h0 - oys) < wn, jy1 = (unsigned)(h0 + 1 - oys) < wn;
+            const bool jx0 = (unsigned)(w0 - oxs) < wn, jx1 = (unsigned)(w0 + 1 - oxs) < wn;
+            const unsigned ni = (v[0] && !(jy0 && jx0) ? 1u : 0u) + (v[1] && !(jy0 && jx1) ? 1u : 0u) +
+                                (v[2] && !(jy1 && jx0) ? 1u : 0u) + (v[3] && !(jy1 && jx1) ? 1u : 0u);
+            my_cnt += (unsigned)__builtin_popcount(fl & 15u) + ((unsigned)__builtin_popcount((fl >> 4) & 15u) << 10) + (ni << 20);
+        }
         const int it = tid + k * kTileThreads;
         if (it < n_items) {
             u32x4 rec;
@@ -279,8 +313,54 @@ __global__ __launch_bounds__(kTileThreads, MSDA_BINS_WGS) void msda_bwd_d32_bins
             FL[it] = fl;
         }
     }
+    if (stat_wg) {       // (fields stay below 2^10: at most 64 lanes x NI x 4 corners)
+        unsigned c = my_cnt;
+        c += BINS_DPP_U(c, 0xB1);
+        c += BINS_DPP_U(c, 0x4E);
+        c += BINS_DPP_U(c, 0x141);
+        c += BINS_DPP_U(c, 0x140);
+        const unsigned r0 = (unsigned)__builtin_amdgcn_readlane((int)c, 0), r1 = (unsigned)__builtin_amdgcn_readlane((int)c, 16);
+        const unsigned r2 = (unsigned)__builtin_amdgcn_readlane((int)c, 32), r3 = (unsigned)__builtin_amdgcn_readlane((int)c, 48);
+        if (lane == 0) {
+            atomicAdd(&s_cnt[0], (r0 & 1023u) + (r1 & 1023u) + (r2 & 1023u) + (r3 & 1023u));
+            atomicAdd(&s_cnt[1], ((r0 >> 10) & 1023u) + ((r1 >> 10) & 1023u) + ((r2 >> 10) & 1023u) + ((r3 >> 10) & 1023u));
+            atomicAdd(&s_cnt[2], (r0 >> 20) + (r1 >> 20) + (r2 >> 20) + (r3 >> 20));
+        }
+    }
     __syncthreads();      // B2: tickets drawn, records written
+    if (bp.stats != nullptr) {
+        if (tid == 0 && stat_wg) sel_add(bp.stats, bp.parity, (unsigned)(sw >> 3), s_cnt[0], s_cnt[1], s_cnt[2]);
+        if (sw == 0 && wave == 1) sel_publish_previous(bp.stats, bp.stats_host, bp.parity, (unsigned)bp.level, lane);
+    }
     if (pl.ablate & 16) return;
+
+    // ---- phase 2a (the last wavefront, which has one row step fewer): prefix sum over the cells, list of the
+    //      non-empty ones.  Touches only counters / START / COMP -- the records are still being read ----
+    if (wave == kTileThreads / 64 - 1 && !(pl.ablate & 64)) {
+        const int C = bp.scan_c;
+        unsigned packed = 0u;          // entries in the low half, non-empty cells in the high half
+        for (int j = 0; j < C; j += 4) {
+            const u32x4 c4 = *reinterpret_cast<const u32x4 *>(&CNT[lane * C + j]);
+            packed += (c4.x + c4.y + c4.z + c4.w) +
+                      (((c4.x ? 1u : 0u) + (c4.y ? 1u : 0u) + (c4.z ? 1u : 0u) + (c4.w ? 1u : 0u)) << 16);
+        }
+        const unsigned incl = bins_incl_scan(packed, lane);
+        unsigned run = incl - packed;
+        for (int j = 0; j < C; j += 4) {
+            const u32x4 c4 = *reinterpret_cast<const u32x4 *>(&CNT[lane * C + j]);
+            unsigned s4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s4[e] = run & 0xffffu;
+                if (c4[e] != 0u) {
+                    COMP[run >> 16] = (unsigned)(lane * C + j + e) | (c4[e] << 16);
+                    run += c4[e] + 0x10000u;
+                }
+            }
+            *reinterpret_cast<u32x2 *>(&START[lane * C + j]) = u32x2{s4[0] | (s4[1] << 16), s4[2] | (s4[3] << 16)};
+        }
+        if (lane == 63) *reinterpret_cast<unsigned *>(s_dyn + bp.o_misc + 12u) = incl;
+    }
 
     // ---- phase 2: the items' gradient dot products: 4 lanes x 8 channels per item, 16 items per wavefront step ----
     const int grp = lane >> 2, j4 = lane & 3;
@@ -364,50 +444,25 @@ __global__ __launch_bounds__(kTileThreads, MSDA_BINS_WGS) void msda_bwd_d32_bins
     }
     __syncthreads();      // B3: the records are dead -- the sorted entries take their place
 
-    // ---- phase 3: prefix sum over the cells (every wavefront for itself), list of the non-empty cells, entries ----
+    // ---- phase 3: the entries go to their places (START came from the last wavefront's scan, before B3) ----
     u32x2 *const E = reinterpret_cast<u32x2 *>(s_dyn + bp.o_x);
-    unsigned total = 0u, nz_total = 0u;
+    unsigned *const s_tot = reinterpret_cast<unsigned *>(s_dyn + bp.o_misc + 12u);     // entries | non-empty cells << 16
+    const unsigned last = (pl.ablate & 64) ? 0u : (unsigned)__builtin_amdgcn_readfirstlane((int)*s_tot);
+    const unsigned total = last & 0xffffu, nz_total = last >> 16;
     if (!(pl.ablate & 64)) {
-        const int C = bp.scan_c;
-        unsigned packed = 0u;          // entries in the low half, non-empty cells in the high half
-        for (int j = 0; j < C; j += 4) {
-            const u32x4 c4 = *reinterpret_cast<const u32x4 *>(&CNT[lane * C + j]);
-            packed += (c4.x + c4.y + c4.z + c4.w) +
-                      (((c4.x ? 1u : 0u) + (c4.y ? 1u : 0u) + (c4.z ? 1u : 0u) + (c4.w ? 1u : 0u)) << 16);
-        }
-        const unsigned incl = bins_incl_scan(packed, lane);
-        unsigned run = incl - packed;
-        for (int j = 0; j < C; j += 4) {
-            const u32x4 c4 = *reinterpret_cast<const u32x4 *>(&CNT[lane * C + j]);
-            u32x4 s4;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                s4[e] = run & 0xffffu;
-                if (c4[e] != 0u) {
-                    CELLS[run >> 16] = (unsigned short)(lane * C + j + e);      // (the four wavefronts write the same values)
-                    run += c4[e] + 0x10000u;
-                }
-            }
-            *reinterpret_cast<u32x4 *>(&START[lane * C + j]) = s4;
-        }
-        const unsigned last = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
-        total = last & 0xffffu;
-        nz_total = last >> 16;
-        if (lane == 63) E[total] = u32x2{(unsigned)rows * kBinsGRow, 0u};      // the list terminator: zero row, weight 0
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        if (tid == 0) E[total] = u32x2{(unsigned)rows * kBinsGRow, 0u};      // the list terminator: zero row, weight 0
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 if (cr[k][c] != 0xffffffffu) {
-                    const unsigned pos = START[cr[k][c] & 0xffffu] + (cr[k][c] >> 16);
+                    const unsigned pos = (unsigned)START[cr[k][c] & 0xffffu] + (cr[k][c] >> 16);
                     E[pos] = u32x2{(unsigned)it_r[k] * kBinsGRow, __float_as_uint(wa[k][c])};
                 }
             }
         }
     }
-    __syncthreads();      // B4: every entry is in place
+    __syncthreads();      // B4: every entry is in place; counters and row tables are dead (the flush transpose takes their LDS)
     if (pl.ablate & 2) return;
 
     // ---- phase 4: per non-empty cell, gather its entries; flush the sums as whole 128-byte rows ----
@@ -418,9 +473,9 @@ __global__ __launch_bounds__(kTileThreads, MSDA_BINS_WGS) void msda_bwd_d32_bins
     for (int round = 0; round * 64 + wave * 16 < (int)nz_total; ++round) {
         const int idx = round * 64 + wave * 16 + grp;
         const bool live = idx < (int)nz_total;
-        const unsigned cell = live ? (unsigned)CELLS[idx] : 0u;
-        const unsigned n = live ? CNT[cell] : 0u;
-        unsigned pe = bp.o_x + START[cell] * 8u;
+        const unsigned comp = live ? COMP[idx] : 0u;
+        const unsigned cell = comp & 0xffffu, n = comp >> 16;
+        unsigned pe = bp.o_x + (unsigned)START[cell] * 8u;
         f32x4 acc_a = f32x4{0.f, 0.f, 0.f, 0.f}, acc_b = f32x4{0.f, 0.f, 0.f, 0.f};
         // trip count: the longest list among this wavefront's 16 cells (the 4 lanes of a cell hold the same n)
         unsigned nm = n;

@@ -47,6 +47,8 @@ struct WinPlan {
     float rcpH[kWinMaxL], rcpW[kWinMaxL], rcpP;   // correctly rounded 1/H, 1/W, 1/P (div_small)
     unsigned value_bytes;
     int n_blocks;
+    unsigned *stats, *stats_host;  // msda_select.h records (device / mapped host); null: no statistics
+    int sel_parity, sel_level;
     int ablate;                    // profiling only (msda_set_option "fwd_win_ablate"): 1 stop after the prologue, 2 no gather,
                                    // 4 write per (row, point) 2 = left its window / 1 = served from it / 0 into `out` (use 6)
 };
@@ -231,6 +233,9 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
         tb.wbase[tid] = pl.wbase[tid];
     }
     if (tid >= 64 && tid < 80) tb.lvl[tid - 64] = (tid - 64) < LP ? (tid - 64) / P : 0;
+    // statistics (msda_select.h): one workgroup in eight counts, every wavefront for itself
+    const bool stat_wg = pl.stats != nullptr && (sw & 7) == 0;
+    unsigned n_live = 0u, n_off = 0u;   // (wave-uniform)
     __syncthreads();
 
     // staging layout: lane -> (row slot, point)
@@ -455,6 +460,10 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
                 rec_w[2 * lane + 1] = rb;
             }
             const unsigned long long bal = __builtin_amdgcn_ballot_w64(need && c_windowed);
+            if (stat_wg) {
+                n_off += (unsigned)__builtin_popcountll(bal);
+                n_live += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(live && c_windowed));
+            }
             const unsigned fold = (unsigned)(bal | (bal >> 32));
             gmask = (fold | (fold >> 16)) & 0xffffu;
         }
@@ -579,6 +588,10 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+    }
+    if (pl.stats != nullptr) {      // kernel selection: this launch's counts out, the previous launch's totals to the host
+        if (stat_wg && lane == 0) sel_add(pl.stats, pl.sel_parity, (unsigned)((sw >> 3) * nw + wave), n_live, n_off, 0u);
+        if (sw == 0 && wave == 1) sel_publish_previous(pl.stats, pl.stats_host, pl.sel_parity, (unsigned)pl.sel_level, lane);
     }
 }
 

@@ -45,6 +45,7 @@
 
 #include "../../include/msda_hip.h"
 #include "msda_common.h"
+#include "msda_select.h"
 
 namespace {
 
@@ -1970,7 +1971,13 @@ std::atomic<int> opt_bwd_split{1};        // fused backward with a workspace: pr
 std::atomic<int> opt_bwd_wide_log2{12};   // tiled backward: row-magnitude range (log2) that makes a region "wide"; 0 = off
 std::atomic<int> opt_bwd_ablate{0};
 std::atomic<int> opt_bwd_rows_block{0};   // threads per workgroup of msda_bwd_d32_rows (0: by problem size)
-std::atomic<int> opt_bwd_bins_margin{4};  // counting-sort backward: window margin (the window is only a table of counters)
+std::atomic<int> opt_bwd_bins_strip{4};   // counting-sort backward: region rows per strip of the block -> region walk
+std::atomic<int> opt_bwd_bins_margin{6};     // small-margin level (level 0 of the selector)
+std::atomic<int> opt_bwd_bins_margin_hi{9};  // large-margin level (level 1): the largest window that keeps 5 workgroups per CU
+std::atomic<int> opt_auto_select{1};         // msda_select.h: follow the measured off-window share (0: level 0 always)
+std::atomic<int> opt_sel_level{-1};          // >= 0: pin the selector's level (tests, benchmarks)
+std::atomic<int> opt_sel_up0{5}, opt_sel_up1{100}, opt_sel_down1{2}, opt_sel_down2{60};   // backward thresholds, 1/1000 of the valid corners
+std::atomic<int> opt_sel_fwd_up{50}, opt_sel_fwd_down{20};                                  // forward thresholds  // counting-sort backward: window margin (the window is only a table of counters)
 std::atomic<int> opt_bwd_rows{1};         // 0: few-query D = 32 calls keep the generic row-per-block backward
 std::atomic<int> opt_fwd_head_major{0};    // gather forward: head-major task walk (one head per XCD)
 std::atomic<int> opt_fwd_win_rlog{3};       // windowed forward: log2 of the region height on level 0
@@ -2089,24 +2096,25 @@ bool make_bins_plan(BinsPlan &bp, const TilePlan &pl, int ni, size_t &lds) {
     bp.n_items = n_items;
     bp.magic_p = magic;
     bp.scan_c = C;
+    bp.strip = opt_bwd_bins_strip.load() > 0 ? opt_bwd_bins_strip.load() : 1;
     bp.o_x = (unsigned)o;                       // records + flags, later the sorted entries
     bp.o_fl = (unsigned)(o + (size_t)n_items * 16);
     const size_t rec_bytes = up16((size_t)n_items * 20), ent_bytes = up16((size_t)(4 * n_items + 1) * 8);
     o += rec_bytes > ent_bytes ? rec_bytes : ent_bytes;
+    // union: ticket counters + row tables (dead after the sort) | flush transpose
     bp.o_st = (unsigned)o;
-    o += (size_t)(kTileThreads / 64) * kBinsStageWave;
-    bp.o_rowp = (unsigned)o;
-    o += up16((size_t)(pl.rows + 1) * 4);
-    bp.o_rowa = (unsigned)o;
-    o += up16((size_t)(pl.rows + 1) * 4);
     bp.o_cnt = (unsigned)o;
-    o += (size_t)C * 64 * 4;
+    bp.o_rowp = (unsigned)(o + (size_t)C * 64 * 4);
+    bp.o_rowa = (unsigned)(bp.o_rowp + up16((size_t)(pl.rows + 1) * 4));
+    const size_t tab_bytes = (size_t)C * 64 * 4 + 2 * up16((size_t)(pl.rows + 1) * 4);
+    const size_t st_bytes = (size_t)(kTileThreads / 64) * kBinsStageWave;
+    o += tab_bytes > st_bytes ? tab_bytes : st_bytes;
     bp.o_start = (unsigned)o;
-    o += (size_t)C * 64 * 4;
-    bp.o_cells = (unsigned)o;
     o += up16((size_t)C * 64 * 2);
+    bp.o_comp = (unsigned)o;
+    o += (size_t)C * 64 * 4;
     bp.o_misc = (unsigned)o;
-    o += 16 + (size_t)(kTileThreads / 64) * 16 * 4;
+    o += 16 + (size_t)(kTileThreads / 64) * 16 * 4 + 16;
     lds = o;
     return lds <= 64 * 1024;
 }
@@ -2126,6 +2134,90 @@ int allow_big_lds(K kernel, size_t lds) {
     if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
     done.fetch_or(bit, std::memory_order_release);
     return MSDA_OK;
+}
+
+// ---- msda_select.h, host side: the records and their table ----
+SelSlot g_sel[kSelSlots];
+std::mutex g_sel_mu;
+thread_local unsigned long long g_site = 0;
+thread_local int g_sel_level = 0;           // level of this thread's last selected call (msda_selector_last)
+thread_local float g_sel_frac = -1.f, g_sel_inner = -1.f;
+
+// The record of (call site, geometry); created on first use unless `stream` is capturing (allocation is not
+// capturable) -- then, and when the table is full, null: the call runs at level 0 without statistics.
+SelSlot *sel_acquire(int kind, int N, int S, int M, int L, int P, int Lq, int dt, hipStream_t stream) {
+    if (!opt_auto_select.load()) return nullptr;
+    SelKey k;
+    memset(&k, 0, sizeof(k));
+    (void)hipGetDevice(&k.dev);
+    k.kind = kind; k.site = g_site; k.N = N; k.S = S; k.M = M; k.L = L; k.P = P; k.Lq = Lq; k.dt = dt;
+    std::lock_guard<std::mutex> lock(g_sel_mu);
+    SelSlot *free_slot = nullptr;
+    for (int i = 0; i < kSelSlots; ++i) {
+        if (g_sel[i].used && g_sel[i].key == k) return &g_sel[i];
+        if (!g_sel[i].used && !free_slot) free_slot = &g_sel[i];
+    }
+    if (!free_slot) return nullptr;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    unsigned *dev = nullptr, *host = nullptr, *host_dev = nullptr;
+    if (hipMalloc((void **)&dev, kSelDevWords * 4) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipHostMalloc((void **)&host, 32, hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void **)&host_dev, host, 0) != hipSuccess ||
+        hipMemset(dev, 0, kSelDevWords * 4) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(dev);
+        if (host) (void)hipHostFree(host);
+        return nullptr;
+    }
+    for (int i = 0; i < 8; ++i) host[i] = 0u;
+    SelSlot &s = *free_slot;
+    s.key = k; s.dev = dev; s.host = host; s.host_dev = host_dev; s.seen = 0u; s.level = 0; s.calls = 0u; s.launches = 0u;
+    s.frac = s.frac_inner = 0.f;
+    s.used = true;
+    return &s;
+}
+
+// Read what the last completed launch left in the host record, move the level, return the level for THIS call
+// (a level without windows probes one level down every kSelProbeEvery-th call: `probe` is then set).
+int sel_level(SelSlot *s, int kind, bool &probe) {
+    probe = false;
+    const int pinned = opt_sel_level.load();
+    if (!s) return pinned >= 0 ? pinned : 0;
+    std::lock_guard<std::mutex> lock(g_sel_mu);
+    const unsigned seq = s->host[3];
+    if (seq != s->seen) {
+        std::atomic_thread_fence(std::memory_order_acquire);
+        const unsigned valid = s->host[0], off = s->host[1], inner = s->host[2];
+        s->seen = seq;
+        if (valid > 0u) {
+            s->frac = (float)off / (float)valid;
+            s->frac_inner = (float)inner / (float)valid;
+            SelRule r;
+            if (kind == 0) { r.up0 = opt_sel_fwd_up.load(); r.down1 = opt_sel_fwd_down.load(); r.up1 = r.down2 = 0; }
+            else { r.up0 = opt_sel_up0.load(); r.up1 = opt_sel_up1.load(); r.down1 = opt_sel_down1.load(); r.down2 = opt_sel_down2.load(); }
+            // the launch stored the level it ran at: a probe ran one level below the top (and is judged by the top
+            // level's rule); statistics of a launch from before the last move are dropped
+            const int top = kind == 0 ? 1 : 2;
+            const int ran = (int)s->host[4];
+            if (s->level == top && ran == top - 1) s->level = sel_next_level(kind, top, s->frac * 1000.f, s->frac_inner * 1000.f, r);
+            else if (ran == s->level) s->level = sel_next_level(kind, ran, s->frac * 1000.f, s->frac_inner * 1000.f, r);
+        }
+    }
+    ++s->calls;
+    g_sel_frac = s->seen ? s->frac : -1.f;
+    g_sel_inner = s->seen ? s->frac_inner : -1.f;
+    int level = pinned >= 0 ? pinned : s->level;
+    const int top = kind == 0 ? 1 : 2;
+    if (pinned < 0 && level == top && (s->calls % kSelProbeEvery) == 0u) {
+        level = top - 1;
+        probe = true;
+    }
+    g_sel_level = level;
+    return level;
 }
 
 struct FusedArgs {     // null proj = the plain operator
@@ -2172,12 +2264,26 @@ int forward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart, 
     const long value_bytes = value_elems * (long)sizeof(TV);
     constexpr bool kD32Type = sizeof(TC) == 4 && (sizeof(TV) == 4 || sizeof(TV) == 2);
     const bool can32 = kD32Type && d32_ok(D, L, value_elems);
+    SelSlot *slot = nullptr;
+    int sel = 0;
+    bool sel_head_major = false;
     if (variant == 0) {
         // self-attention over the pyramid (one query per pixel): coarse levels from per-head LDS windows; every
         // other D = 32 call: direct gather with 4 points (16 rows) in flight -- best of the sweeps in profiles/
         const bool pyramid = can32 && sizeof(TV) == 4 && shapes_host != nullptr && Lq == S && L <= kWinMaxL &&
                              L * P <= 16 && opt_fwd_win_auto.load() != 0;
         variant = pyramid ? 12 : (can32 ? 3 : 1);
+        if (pyramid) {      // msda_select.h: windows while the points stay near their queries, else the head-major gather
+            slot = sel_acquire(0, N, S, M, L, P, Lq, (int)sizeof(TV), stream);
+            bool probe = false;
+            sel = sel_level(slot, 0, probe);
+            if (sel >= 1) { variant = 3; sel_head_major = true; }
+        }
+    } else if (variant == 12 && can32 && shapes_host != nullptr) {
+        slot = sel_acquire(0, N, S, M, L, P, Lq, (int)sizeof(TV), stream);     // forced: the selector only measures
+        bool probe = false;
+        (void)sel_level(slot, 0, probe);
+        sel = 0;
     }
     if (variant >= 2 && !can32) variant = 1;
     if (variant == 1) {
@@ -2220,6 +2326,19 @@ int forward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart, 
                            (const float *)value, lstart, src, (float *)out, wp);                                     \
     } while (0)
                     wp.ablate = opt_fwd_win_ablate.load();
+                    {       // (a captured launch would replay one parity for ever: no statistics from inside a capture)
+                        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+                        const bool capturing = hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
+                        if (slot && !capturing) {
+                            std::lock_guard<std::mutex> lock(g_sel_mu);
+                            wp.stats = slot->dev;
+                            wp.stats_host = slot->host_dev;
+                            wp.sel_parity = (int)(slot->launches++ & 1u);
+                            wp.sel_level = sel;
+                        } else {
+                            (void)hipGetLastError();
+                        }
+                    }
                     // register budget by what the LDS footprint admits: four 256-thread workgroups per CU (<= 40 KB
                     // each) -> 128 registers and the global points after the LDS phase; three -> 168 registers
                     int wps = opt_fwd_win_wps.load();
@@ -2280,7 +2399,7 @@ int forward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart, 
         int block = opt_fwd_block.load();
         if (block < 64 || block > 256 || (block & 63)) block = 256;  // kernels carry __launch_bounds__(256)
         const int wpb = block / 64;
-        const int head_major = opt_fwd_head_major.load() != 0 && (long)N * Lq >= 4096 ? 1 : 0;
+        const int head_major = (opt_fwd_head_major.load() != 0 || sel_head_major) && (long)N * Lq >= 4096 ? 1 : 0;
         const long n_tasks = head_major ? (((long)N * Lq + ROWS - 1) / ROWS) * M : ((long)N * Lq * M + ROWS - 1) / ROWS;
         // small problems: one wave per block so every task gets its own CU slot
         int use_block = block;
@@ -2342,7 +2461,24 @@ int backward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart,
     // is the fastest of them).  Self-attention over the pyramid (Lq == S, host shapes known) therefore
     // takes the region-tiled kernel that pre-reduces grad_value in fixed-point LDS windows; every other call
     // (decoder queries) takes the row-per-block kernel.
-    if (variant == 0) variant = can_tile ? (P <= 8 ? 10 : 8) : 1;   // measured (profiles/): 224 vs 317 us at the encoder shape
+    // Self-attention over the pyramid: the counting-sort kernel (msda_bwd_bins.h, round 4: 145 us at the encoder
+    // shape; tile_lv 218, tile_q2 317), at the window margin the measured off-window share asks for -- or, when most
+    // points leave even the large window (uniformly random locations), no windows at all (msda_select.h).
+    SelSlot *slot = nullptr;
+    int sel = 0, bins_margin = opt_bwd_bins_margin.load(), bins_shrink = 0;
+    if (kD32Type && can_tile && (variant == 0 || variant == 12)) {
+        slot = sel_acquire(1, N, S, M, L, P, Lq, (int)sizeof(TV), stream);
+        bool probe = false;
+        sel = sel_level(slot, 1, probe);
+        if (variant == 12) sel = opt_sel_level.load() >= 0 ? sel : 0;         // forced: the selector only measures
+        if (sel >= 1) {
+            bins_shrink = opt_bwd_bins_margin_hi.load() - bins_margin;
+            bins_margin = opt_bwd_bins_margin_hi.load();
+            if (bins_shrink < 0) bins_shrink = 0;
+        }
+        if (variant == 0) variant = sel >= 2 ? 1 : 12;
+    }
+    if (variant == 0) variant = can_tile ? (P <= 8 ? 10 : 8) : 1;
     if (variant >= 2 && !can_tile) variant = 1;
     if constexpr (kD32Type) {
         if (variant == 12) {        // counting-sort gather (msda_bwd_bins.h); the one-kernel fused form stays with tile_lv
@@ -2359,13 +2495,27 @@ int backward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart,
             size_t bins_lds = 0;
             bool planned = false;
             if (variant == 12) {
-                if (make_tile_plan(pl, shapes_host, N, S, M, D, L, Lq, P, value_bytes, opt_bwd_bins_margin.load(), 0, 8, 0,
-                                   lds_all, false)) {
+                if (make_tile_plan(pl, shapes_host, N, S, M, D, L, Lq, P, value_bytes, bins_margin, 0, 8, 0, lds_all, false)) {
                     for (int ni = 2; ni <= 3 && !bins_ni; ++ni)
                         if (make_bins_plan(bp, pl, ni, bins_lds)) bins_ni = ni;
                 }
                 planned = bins_ni != 0;
                 if (!planned) variant = 10;
+                bp.shrink = bins_shrink;
+                bp.level = sel;
+                // (a captured launch would replay one parity for ever: no statistics from inside a capture)
+                hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+                const bool capturing = hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
+                if (slot && !capturing) {
+                    std::lock_guard<std::mutex> lock(g_sel_mu);
+                    bp.stats = slot->dev;
+                    bp.stats_host = slot->host_dev;
+                    bp.parity = (int)(slot->launches++ & 1u);
+                } else {
+                    (void)hipGetLastError();
+                    bp.stats = bp.stats_host = nullptr;
+                    bp.parity = 0;
+                }
             }
             if (!planned)
                 planned = P <= 8 && make_tile_plan(pl, shapes_host, N, S, M, D, L, Lq, P, value_bytes,
@@ -2543,7 +2693,23 @@ int backward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart,
 
 extern "C" {
 
-int msda_abi_version(void) { return 3; }
+int msda_abi_version(void) { return 4; }
+
+void msda_set_call_site(uint64_t site) { g_site = site; }
+
+int msda_selector_last(int *level, float *off_share, float *inner_share) {
+    if (level) *level = g_sel_level;
+    if (off_share) *off_share = g_sel_frac;
+    if (inner_share) *inner_share = g_sel_inner;
+    return MSDA_OK;
+}
+
+int msda_selector_next(int kind, int level, int off_permille, int inner_permille) {
+    SelRule r;
+    if (kind == 0) { r.up0 = opt_sel_fwd_up.load(); r.down1 = opt_sel_fwd_down.load(); r.up1 = r.down2 = 0; }
+    else { r.up0 = opt_sel_up0.load(); r.up1 = opt_sel_up1.load(); r.down1 = opt_sel_down1.load(); r.down2 = opt_sel_down2.load(); }
+    return sel_next_level(kind, level, (float)off_permille, (float)inner_permille, r);
+}
 const char *msda_last_error(void) { return g_err; }
 const char *msda_last_kernel(void) { return g_kernel; }
 
@@ -2731,6 +2897,16 @@ static std::atomic<int> *find_opt(const char *key) {
     if (!strcmp(key, "bwd_wide_log2")) return &opt_bwd_wide_log2;
     if (!strcmp(key, "bwd_split")) return &opt_bwd_split;
     if (!strcmp(key, "bwd_bins_margin")) return &opt_bwd_bins_margin;
+    if (!strcmp(key, "bwd_bins_margin_hi")) return &opt_bwd_bins_margin_hi;
+    if (!strcmp(key, "auto_select")) return &opt_auto_select;
+    if (!strcmp(key, "sel_level")) return &opt_sel_level;
+    if (!strcmp(key, "sel_up0")) return &opt_sel_up0;
+    if (!strcmp(key, "sel_up1")) return &opt_sel_up1;
+    if (!strcmp(key, "sel_down1")) return &opt_sel_down1;
+    if (!strcmp(key, "sel_down2")) return &opt_sel_down2;
+    if (!strcmp(key, "sel_fwd_up")) return &opt_sel_fwd_up;
+    if (!strcmp(key, "sel_fwd_down")) return &opt_sel_fwd_down;
+    if (!strcmp(key, "bwd_bins_strip")) return &opt_bwd_bins_strip;
     if (!strcmp(key, "bwd_rows")) return &opt_bwd_rows;
     if (!strcmp(key, "bwd_rows_block")) return &opt_bwd_rows_block;
     if (!strcmp(key, "fwd_win_rlog")) return &opt_fwd_win_rlog;
@@ -2749,7 +2925,8 @@ static std::atomic<int> *find_opt(const char *key) {
 
 int msda_set_option(const char *key, int value) {
     std::atomic<int> *o = find_opt(key);
-    if (!o || value < 0) return fail(MSDA_EINVAL, "unknown option or negative value");
+    if (!o || (value < 0 && !(o == &opt_sel_level && value == -1)))
+        return fail(MSDA_EINVAL, "unknown option or negative value");
     o->store(value);
     return MSDA_OK;
 }

@@ -18,6 +18,7 @@ class MSDeformAttnFunction(Function):
     def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights,
                 im2col_step):
         ctx.im2col_step = im2col_step
+        ctx.site = MSDA.get_call_site()       # the backward runs on autograd's thread: carry the module's tag over
         # keep the python-side copy of the pyramid with the graph node: the backward must not have to read
         # spatial_shapes back from the device if the saved tensor comes back as a fresh python object
         ctx.shapes_host = getattr(value_spatial_shapes, "_msda_host", None)
@@ -33,9 +34,11 @@ class MSDeformAttnFunction(Function):
         value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights = ctx.saved_tensors
         if ctx.shapes_host is not None and getattr(value_spatial_shapes, "_msda_host", None) is None:
             value_spatial_shapes._msda_host = (ctx.shapes_host[0], value_spatial_shapes._version)
+        MSDA.set_call_site(ctx.site)
         grad_value, grad_sampling_loc, grad_attn_weight = MSDA.ms_deform_attn_backward(
             value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights,
             grad_output.contiguous(), ctx.im2col_step)
+        MSDA.set_call_site(0)
         return grad_value, None, None, grad_sampling_loc, grad_attn_weight, None
 
 
@@ -52,6 +55,7 @@ class MSDeformAttnFusedFunction(Function):
     def forward(ctx, value, value_spatial_shapes, value_level_start_index, proj, reference_points, padding_mask,
                 n_heads, n_points):
         ctx.n_heads, ctx.n_points = int(n_heads), int(n_points)
+        ctx.site = MSDA.get_call_site()
         ctx.shapes_host = getattr(value_spatial_shapes, "_msda_host", None)
         output = MSDA.ms_deform_attn_fused_forward(value, value_spatial_shapes, value_level_start_index, proj,
                                                    reference_points, padding_mask, ctx.n_heads, ctx.n_points)
@@ -65,7 +69,9 @@ class MSDeformAttnFusedFunction(Function):
         value, shapes, level_start, proj, reference_points, padding_mask = ctx.saved_tensors
         if ctx.shapes_host is not None and getattr(shapes, "_msda_host", None) is None:
             shapes._msda_host = (ctx.shapes_host[0], shapes._version)
+        MSDA.set_call_site(ctx.site)
         grad_value, grad_proj, grad_ref = MSDA.ms_deform_attn_fused_backward(
             value, shapes, level_start, proj, reference_points, padding_mask, grad_output.contiguous(), ctx.n_heads,
             ctx.n_points, need_ref_grad=ctx.needs_input_grad[4])
+        MSDA.set_call_site(0)
         return grad_value, None, None, grad_proj, grad_ref, None, None, None

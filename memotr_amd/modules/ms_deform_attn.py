@@ -129,6 +129,7 @@ class MSDeformAttn(nn.Module):
     def __getstate__(self):
         state = dict(self.__dict__)
         state.pop("_fused_qproj", None)
+        state.pop("_msda_site", None)
         return state
 
     def __deepcopy__(self, memo):
@@ -136,7 +137,7 @@ class MSDeformAttn(nn.Module):
         new = self.__class__.__new__(self.__class__)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
-            if k != "_fused_qproj":
+            if k not in ("_fused_qproj", "_msda_site"):
                 new.__dict__[k] = copy.deepcopy(v, memo)
         return new
 
@@ -150,6 +151,12 @@ class MSDeformAttn(nn.Module):
         N, Lq, _ = query.shape
         S = input_flatten.shape[1]
         M, L, P = self.n_heads, self.n_levels, self.n_points
+        if input_flatten.is_cuda:
+            # one kernel-selection record per module: the learnt offsets differ from layer to layer
+            site = self.__dict__.get("_msda_site")
+            if site is None:
+                site = self.__dict__["_msda_site"] = MSDA.new_call_site()
+            MSDA.set_call_site(site)
 
         value = long_linear(input_flatten, self.value_proj.weight, self.value_proj.bias)
 

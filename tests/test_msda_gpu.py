@@ -239,10 +239,28 @@ def test_region_tiled_kernels_match_oracle(msda, hip_lib, case, margin):
             np.testing.assert_allclose(gv, rgv, **tol(np.float32, 8))
             np.testing.assert_allclose(gl, rgl, **tol(np.float32, 100))
             np.testing.assert_allclose(ga, rga, **tol(np.float32, 40))
+        # 12 (round 4): counting sort of the (cell, row, weight) entries + float gather, no fixed point; window margin
+        # `margin` at selector level 0, margin + 3 at level 1 (with the inner-window statistics on)
+        hip_lib.set_option("bwd_variant", 12)
+        hip_lib.set_option("bwd_bins_margin", margin)
+        hip_lib.set_option("bwd_bins_margin_hi", margin + 3)
+        for level in (0, 1):
+            hip_lib.set_option("sel_level", level)
+            for strip in (1, 4):
+                hip_lib.set_option("bwd_bins_strip", strip)
+                gv, gl, ga = run_bwd(msda, g)
+                assert hip_lib.last_kernel() == "msda_bwd_d32_tile_bins", hip_lib.last_kernel()
+                np.testing.assert_allclose(gv, rgv, err_msg=f"bins level {level} strip {strip}", **tol(np.float32, 8))
+                np.testing.assert_allclose(gl, rgl, **tol(np.float32, 100))
+                np.testing.assert_allclose(ga, rga, **tol(np.float32, 40))
     finally:
         hip_lib.set_option("fwd_tile_margin", 3)
         hip_lib.set_option("bwd_tile_margin", 4)
         hip_lib.set_option("fwd_tile_l0", 1)
+        hip_lib.set_option("bwd_bins_margin", 6)
+        hip_lib.set_option("bwd_bins_margin_hi", 9)
+        hip_lib.set_option("bwd_bins_strip", 4)
+        hip_lib.set_option("sel_level", -1)
 
 
 def test_tiled_variant_falls_back_when_queries_are_not_the_pyramid(msda, hip_lib):
@@ -276,10 +294,10 @@ def test_full_size_specialised_equals_generic(msda, hip_lib, full_inputs):
         torch.testing.assert_close(out, ref, rtol=1e-4, atol=2e-5)
     hip_lib.set_option("bwd_variant", 1)
     ref_g = msda.ms_deform_attn_backward(*args, x["grad_out"], 64)
-    for v in (8, 9, 10, 11):
+    for v in (8, 9, 10, 11, 12):
         hip_lib.set_option("bwd_variant", v)
         got = msda.ms_deform_attn_backward(*args, x["grad_out"], 64)
-        assert ("tile_q2" if v < 10 else "tile_lv") in hip_lib.last_kernel()
+        assert ("tile_q2" if v < 10 else ("tile_lv" if v < 12 else "tile_bins")) in hip_lib.last_kernel()
         torch.testing.assert_close(got[0], ref_g[0], rtol=1e-3, atol=2e-4)   # atomics: order-dependent sums
         torch.testing.assert_close(got[1], ref_g[1], rtol=1e-3, atol=5e-3)
         torch.testing.assert_close(got[2], ref_g[2], rtol=1e-3, atol=5e-4)
@@ -379,7 +397,8 @@ def hip_lib_kernel_is_bf16_d32():
 
 def test_bf16_pyramid_self_attention_takes_the_tiled_backward(msda, hip_lib):
     """bf16 value / grad_out on the pyramid: specialised gather forward (4 lanes x 8 channels per 64-byte row) and
-    the fixed-point tiled backward, against the fp32 oracle on the bf16-rounded inputs."""
+    the region-tiled backward (round 4: the counting-sort kernel; the fixed-point tile_lv when forced), against the fp32
+    oracle on the bf16-rounded inputs."""
     from memotr_amd.MultiScaleDeformableAttention import tag_host_shapes
     from oracle import msda_oracle as oracle
     shapes = [(20, 28), (10, 14), (5, 7), (3, 4)]
@@ -389,12 +408,14 @@ def test_bf16_pyramid_self_attention_takes_the_tiled_backward(msda, hip_lib):
     args = (vb, sh, dev(g["level_start"]), dev(g["loc"]), dev(g["attn"]))
     out = msda.ms_deform_attn_forward(*args, 64)
     assert hip_lib.last_kernel() == "msda_fwd_d32_gather<4,bf16>", hip_lib.last_kernel()
-    gv, gl, ga = msda.ms_deform_attn_backward(*args, gob, 64)
-    assert hip_lib.last_kernel() == "msda_bwd_d32_tile_lv<2,bf16>", hip_lib.last_kernel()
     v32, go32 = vb.float().cpu().numpy(), gob.float().cpu().numpy()
     ref = oracle.forward(v32, g["shapes"], g["level_start"], g["loc"], g["attn"])
     rgv, rgl, rga = oracle.backward(v32, g["shapes"], g["level_start"], g["loc"], g["attn"], go32)
     np.testing.assert_allclose(out.float().cpu().numpy(), ref, rtol=1e-2, atol=1e-2)
-    np.testing.assert_allclose(gv.float().cpu().numpy(), rgv, rtol=1e-2, atol=3e-2)
-    np.testing.assert_allclose(gl.cpu().numpy(), rgl, **tol(np.float32, 100))
-    np.testing.assert_allclose(ga.cpu().numpy(), rga, **tol(np.float32, 40))
+    for variant, kernel in ((0, "msda_bwd_d32_tile_bins<bf16>"), (10, "msda_bwd_d32_tile_lv<2,bf16>")):
+        hip_lib.set_option("bwd_variant", variant)
+        gv, gl, ga = msda.ms_deform_attn_backward(*args, gob, 64)
+        assert hip_lib.last_kernel() == kernel, hip_lib.last_kernel()
+        np.testing.assert_allclose(gv.float().cpu().numpy(), rgv, rtol=1e-2, atol=3e-2)
+        np.testing.assert_allclose(gl.cpu().numpy(), rgl, **tol(np.float32, 100))
+        np.testing.assert_allclose(ga.cpu().numpy(), rga, **tol(np.float32, 40))

@@ -39,7 +39,7 @@ def main():
 
     def setopts(**kw):
         for k, v in (("bwd_variant", 0), ("bwd_tile_margin", 4), ("bwd_bins_margin", 4), ("bwd_ablate", 0),
-                     ("bwd_split", 1)):
+                     ("bwd_split", 1), ("bwd_bins_strip", 4)):
             _lib.set_option(k, v)
         for k, v in kw.items():
             _lib.set_option(k, v)
@@ -76,6 +76,10 @@ def main():
         cfgs = [("v10 tile_lv m4", dict(bwd_variant=10))]
         for mg in (3, 4, 6, 8, 10):
             cfgs.append((f"v12 bins m{mg}", dict(bwd_variant=12, bwd_bins_margin=mg)))
+        if dist == "encoder_like":
+            for mg in (4, 8):
+                cfgs.append((f"v12 bins m{mg} raster order", dict(bwd_variant=12, bwd_bins_margin=mg, bwd_bins_strip=1)))
+                cfgs.append((f"v12 bins m{mg} strips of 2", dict(bwd_variant=12, bwd_bins_margin=mg, bwd_bins_strip=2)))
         if osc == 1.0 and dist == "encoder_like":
             for ab in (1, 3, 4, 7):
                 cfgs.append((f"v12 bins m4 ablate={ab}", dict(bwd_variant=12, bwd_ablate=ab)))
