@@ -48,8 +48,14 @@
  *     DESIGN.md.
  *   - Integer/index arithmetic (floor of loc*size-0.5, corner indices, the
  *     (-1,H)x(-1,W) gate, zero padding per corner) is bit-identical to the
- *     reference kernels (.cuh:33-84,285-288); msda_sample_indices_f32 exposes it
- *     for parity tests.
+ *     reference kernels' SOURCE read as two operations -- the product loc*size
+ *     rounded, then 0.5 subtracted (.cuh:33-84,285-288; oracle built with
+ *     -ffp-contract=off).  An nvcc build of the reference with its default
+ *     -fmad=true fuses the two into one FMA; the readings agree on every point of
+ *     both benchmark distributions at the BASELINE shape and differ (neighbouring
+ *     pixel, complementary weight, same interpolated value to an ulp) on ~0.6 % of
+ *     points placed exactly on pixel centres (tests/test_oracle_golden.py).
+ *     msda_sample_indices_f32 exposes the arithmetic for parity tests.
  */
 #ifndef MSDA_HIP_H_
 #define MSDA_HIP_H_

@@ -117,6 +117,11 @@ def get_call_site() -> int:
     return getattr(_SITE, "value", 0)
 
 
+# Kernel the last forward / backward call dispatched to, whatever thread made it (msda_last_kernel() is thread-local
+# and autograd runs backward calls on its own thread: __graft_entry__.smoke() asserts the backward kernel through this)
+LAST_KERNEL = {"forward": "", "backward": ""}
+
+
 def _stream(device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
@@ -142,6 +147,7 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
         del keep
     if rc != 0:
         _raise(rc, "ms_deform_attn_forward")
+    LAST_KERNEL["forward"] = _lib.last_kernel()
     return output
 
 
@@ -170,6 +176,7 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
         del keep
     if rc != 0:
         _raise(rc, "ms_deform_attn_backward")
+    LAST_KERNEL["backward"] = _lib.last_kernel()
     if grad_value.dtype != value.dtype:
         grad_value = grad_value.to(value.dtype)
     return [grad_value, grad_loc, grad_attn]
@@ -242,6 +249,7 @@ def ms_deform_attn_fused_forward(value, spatial_shapes, level_start_index, proj,
         del keep
     if rc != 0:
         _raise(rc, "ms_deform_attn_fused_forward")
+    LAST_KERNEL["forward"] = _lib.last_kernel()
     return output
 
 
@@ -281,6 +289,7 @@ def ms_deform_attn_fused_backward(value, spatial_shapes, level_start_index, proj
         del keep, ws
     if rc != 0:
         _raise(rc, "ms_deform_attn_fused_backward")
+    LAST_KERNEL["backward"] = _lib.last_kernel()
     if grad_value.dtype != value.dtype:
         grad_value = grad_value.to(value.dtype)
     return [grad_value, grad_proj, ref_part.sum(2) if ref_part is not None else None]

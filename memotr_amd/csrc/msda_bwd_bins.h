@@ -49,7 +49,9 @@ struct BinsPlan {
     // flags (at o_fl) until the row phase is over, the sorted entries afterwards; o_st holds the ticket counters and the
     // row tables until the sort is done, the flush transpose afterwards.  o_start: u16 per cell, o_comp: u32 per
     // non-empty cell (cell | count << 16), o_misc: 4 sums + 64 flush offsets + 3 counters.
-    unsigned o_x, o_fl, o_st, o_rowp, o_rowa, o_cnt, o_start, o_comp, o_misc;
+    unsigned o_x, o_fl, o_st, o_rowp, o_rowa, o_rowq, o_cnt, o_start, o_comp, o_misc;
+    int fused_loc;           // split fused backward: locations from the raw projection + reference points (src.proj / src.ref)
+    int offsets_done;        // ... and final offset gradients (2-d reference points: d loc / d offset = 1 / (W, H))
 };
 
 __device__ __forceinline__ unsigned bins_incl_scan(unsigned x, int lane) {
@@ -149,6 +151,7 @@ __global__ __launch_bounds__(kTileThreads, MSDA_BINS_WGS) void msda_bwd_d32_bins
     unsigned *const FL = reinterpret_cast<unsigned *>(s_dyn + bp.o_fl);
     unsigned *const ROWP = reinterpret_cast<unsigned *>(s_dyn + bp.o_rowp);
     unsigned *const ROWA = reinterpret_cast<unsigned *>(s_dyn + bp.o_rowa);
+    unsigned *const ROWQ = reinterpret_cast<unsigned *>(s_dyn + bp.o_rowq);
     unsigned *const CNT = reinterpret_cast<unsigned *>(s_dyn + bp.o_cnt);
     unsigned short *const START = reinterpret_cast<unsigned short *>(s_dyn + bp.o_start);
     unsigned *const COMP = reinterpret_cast<unsigned *>(s_dyn + bp.o_comp);
@@ -172,6 +175,7 @@ __global__ __launch_bounds__(kTileThreads, MSDA_BINS_WGS) void msda_bwd_d32_bins
         // first output element of the row (floats): a row of grad_proj (split fused backward) or of grad_attn (plain;
         // grad_loc is twice that)
         ROWA[tid] = grad_proj != nullptr ? qrow * (unsigned)src.proj_stride : pm * (unsigned)LP;
+        ROWQ[tid] = qrow;
     }
     __syncthreads();      // B0
 
@@ -202,7 +206,9 @@ __global__ __launch_bounds__(kTileThreads, MSDA_BINS_WGS) void msda_bwd_d32_bins
             f32x2 xy = f32x2{0.f, 0.f};
             float a = 0.f;
             if (ok) {
-                xy = *reinterpret_cast<const f32x2 *>(src.loc + (pm * (unsigned)LP + t) * 2u);
+                // (fused_loc: the module's own arithmetic, ms_deform_attn.py:114-120, the bits msda_fused_points_f32 exposes)
+                xy = bp.fused_loc ? fused_location<unsigned>(src, ROWQ[r], m, L, P, (int)t, l, H, W)
+                                  : *reinterpret_cast<const f32x2 *>(src.loc + (pm * (unsigned)LP + t) * 2u);
                 a = src.attn[pm * (unsigned)LP + t];
             }
             const Sample<float> s = sample_setup<float>(xy.x, xy.y, H, W);
@@ -371,7 +377,7 @@ __global__ __launch_bounds__(kTileThreads, MSDA_BINS_WGS) void msda_bwd_d32_bins
     {
         // lane roles inside an item's quad: 0 -> d/dx, 1 -> d/dy, 2 -> d/d(attention), 3 -> none
         const bool role_y = j4 == 1, role_a = j4 == 2;
-        const float size_r = role_y ? (float)H : (float)W;
+        const float size_r = bp.offsets_done ? 1.f : (role_y ? (float)H : (float)W);
         const bool split = grad_proj != nullptr;
         float *const dst_base = split ? grad_proj : (role_a ? grad_attn : grad_loc);
         const unsigned sh_row = (!split && !role_a) ? 1u : 0u;      // plain grad_loc rows are twice as long

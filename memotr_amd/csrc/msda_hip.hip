@@ -357,9 +357,11 @@ __global__ __launch_bounds__(256) void msda_fused_points16_kernel(const int64_t 
         sum += __shfl_xor(sum, 4, 16);
         const float rsum = 1.f / sum;
         if (ok) {
-            const int l = t / P;
-            const f32x2 xy = fused_location(fs, qrow, m, L, P, t, l, (int)shapes[2 * l], (int)shapes[2 * l + 1]);
-            *reinterpret_cast<f32x2 *>(loc_out + (pm * LP + t) * 2) = xy;
+            if (loc_out != nullptr) {     // (null: the consumer computes the locations itself, msda_bwd_bins.h)
+                const int l = t / P;
+                const f32x2 xy = fused_location(fs, qrow, m, L, P, t, l, (int)shapes[2 * l], (int)shapes[2 * l + 1]);
+                *reinterpret_cast<f32x2 *>(loc_out + (pm * LP + t) * 2) = xy;
+            }
             attn_out[pm * LP + t] = e * rsum;
         }
     }
@@ -1917,7 +1919,7 @@ __global__ __launch_bounds__(256) void msda_fused_finish_kernel(const int64_t *_
 // The same for L*P <= 16 with one lane per point: coalesced reads / writes of the three column groups.
 __global__ __launch_bounds__(256) void msda_fused_finish16_kernel(const int64_t *__restrict__ shapes, const PointSrc fs,
                                                                  long n_rows, int M, int L, int P,
-                                                                 float *__restrict__ grad_proj) {
+                                                                 float *__restrict__ grad_proj, int offsets_done) {
     const int LP = L * P;
     const int t = threadIdx.x & 15;
     const long rows_pad = (n_rows + 3) & ~3L;
@@ -1936,6 +1938,7 @@ __global__ __launch_bounds__(256) void msda_fused_finish16_kernel(const int64_t 
         for (int o = 8; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 16);
         if (!ok) continue;
         ga[t] = a * (g - dot);
+        if (offsets_done) continue;       // (the producer wrote the final offset gradients: 2-d reference points)
         const int l = t / P;
         f32x2 d = *reinterpret_cast<f32x2 *>(gl + 2 * t);
         if (fs.ref_dim == 2) {
@@ -2106,7 +2109,8 @@ bool make_bins_plan(BinsPlan &bp, const TilePlan &pl, int ni, size_t &lds) {
     bp.o_cnt = (unsigned)o;
     bp.o_rowp = (unsigned)(o + (size_t)C * 64 * 4);
     bp.o_rowa = (unsigned)(bp.o_rowp + up16((size_t)(pl.rows + 1) * 4));
-    const size_t tab_bytes = (size_t)C * 64 * 4 + 2 * up16((size_t)(pl.rows + 1) * 4);
+    bp.o_rowq = (unsigned)(bp.o_rowa + up16((size_t)(pl.rows + 1) * 4));
+    const size_t tab_bytes = (size_t)C * 64 * 4 + 3 * up16((size_t)(pl.rows + 1) * 4);
     const size_t st_bytes = (size_t)(kTileThreads / 64) * kBinsStageWave;
     o += tab_bytes > st_bytes ? tab_bytes : st_bytes;
     bp.o_start = (unsigned)o;
@@ -2535,11 +2539,19 @@ int backward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart,
                 // workgroups per region -- run the plain kernel on it, finish the Jacobians in place.
                 const bool split = fused && opt_bwd_split.load() != 0 && workspace != nullptr &&
                                    workspace_bytes >= (size_t)n_rows * L * P * 3 * sizeof(float);
+                // The counting-sort kernel computes the locations itself (one lane per point: the arithmetic is
+                // cheap there) and, for 2-d reference points, writes the final offset gradients: the two side
+                // kernels then move a third of the bytes (attention weights out, the softmax Jacobian in place).
+                const bool slim = split && variant == 12 && L * P <= 16;
+                const int offsets_done = slim && fa.ref_dim == 2 ? 1 : 0;
+                bp.fused_loc = slim ? 1 : 0;
+                bp.offsets_done = offsets_done;
                 if (split) {
                     float *loc_ws = workspace, *attn_ws = workspace + (size_t)n_rows * L * P * 2;
                     if (L * P <= 16) {
                         hipLaunchKernelGGL(msda_fused_points16_kernel, dim3(clamp_grid((n_rows * 16 + 255) / 256, 32)),
-                                           dim3(256), 0, stream, shapes, src, n_rows, M, L, P, loc_ws, attn_ws);
+                                           dim3(256), 0, stream, shapes, src, n_rows, M, L, P,
+                                           slim ? (float *)nullptr : loc_ws, attn_ws);
                     } else {
                         hipLaunchKernelGGL(msda_fused_points_kernel, dim3(clamp_grid((n_rows * 8 + 255) / 256, 16)),
                                            dim3(256), 0, stream, shapes, src, n_rows, M, L, P, loc_ws, attn_ws);
@@ -2587,7 +2599,7 @@ int backward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart,
                 if (split) {
                     if (L * P <= 16) {
                         hipLaunchKernelGGL(msda_fused_finish16_kernel, dim3(clamp_grid((n_rows * 16 + 255) / 256, 32)),
-                                           dim3(256), 0, stream, shapes, src, n_rows, M, L, P, grad_proj);
+                                           dim3(256), 0, stream, shapes, src, n_rows, M, L, P, grad_proj, offsets_done);
                     } else {
                         hipLaunchKernelGGL(msda_fused_finish_kernel, dim3(jgrid), dim3(256), 0, stream, shapes, src,
                                            n_rows, M, L, P, grad_proj);

@@ -184,3 +184,28 @@
 
 DEFINE_ORACLE(float, f32)
 DEFINE_ORACLE(double, f64)
+
+/* The OTHER reading of .cuh:285-286.  `loc_h * spatial_h - 0.5` is one multiply and one subtract in the source; the
+ * reference's setup.py (models/ops/setup.py:41-46) passes no -fmad=false, so nvcc's default contracts them into ONE
+ * fused multiply-add: the product is not rounded before the subtraction.  Near an integer boundary floor() can then
+ * differ from the uncontracted reading above (which is what the HIP kernels implement, `fp contract(off)`).  This probe
+ * computes the contracted indices so that tests/test_oracle_golden.py can COUNT the points that flip at the BASELINE
+ * shapes: the "bit-exact index arithmetic" claim is against the uncontracted reading, and the count says how far the
+ * two readings are apart. */
+void msda_oracle_indices_fma_f32(const int64_t *shapes, const float *loc, int N, int M, int L, int Lq, int P,
+                                 int32_t *h_low, int32_t *w_low, uint8_t *gate) {
+    const long n_pairs = (long)N * Lq * M;
+    for (long pm = 0; pm < n_pairs; ++pm)
+        for (int l = 0; l < L; ++l) {
+            const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+            for (int p = 0; p < P; ++p) {
+                const long t = (pm * L + l) * P + p;
+                const float h_im = fmaf(loc[2 * t + 1], (float)H, -0.5f);
+                const float w_im = fmaf(loc[2 * t], (float)W, -0.5f);
+                h_low[t] = (int32_t)floor((double)h_im);
+                w_low[t] = (int32_t)floor((double)w_im);
+                gate[t] = (uint8_t)(h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W);
+            }
+        }
+}
+

@@ -113,6 +113,21 @@ def indices(shapes, loc):
     return h, w, g
 
 
+def indices_fma(shapes, loc):
+    """The same with `loc * size - 0.5` contracted into ONE fused multiply-add (nvcc's default for the reference build,
+    models/ops/setup.py:41-46 passes no -fmad=false): float32 only.  For counting how many points the two readings of
+    .cuh:285-286 put on different pixels."""
+    loc = np.ascontiguousarray(loc, dtype=np.float32)
+    shapes = np.ascontiguousarray(shapes, dtype=np.int64)
+    N, Lq, M, L, P, _ = loc.shape
+    h = np.empty((N, Lq, M, L, P), dtype=np.int32)
+    w = np.empty_like(h)
+    g = np.empty((N, Lq, M, L, P), dtype=np.uint8)
+    _load().msda_oracle_indices_fma_f32(_ptr(shapes), _ptr(loc), *[ctypes.c_int(x) for x in (N, M, L, Lq, P)], _ptr(h),
+                                        _ptr(w), _ptr(g))
+    return h, w, g
+
+
 def grid_sample_forward(value, shapes_hw, loc, attn):
     """torch-CPU restatement of the reference fallback (ms_deform_attn_func.py:44-64).
 

@@ -113,18 +113,23 @@ def _worker_shared_device(rank, world, port, out_path):
     criterion = build_criterion(cfg)
     opt = build_optimizer(cfg, ddp)
     batch = clip_to_device(make_synthetic_clip(clip_len=3, height=192, width=256, n_gts=3 + 2 * rank, seed=7 + rank), dev)
-    losses, counts = [], None
+    losses, counts, step_ms = [], None, []
+    import time
     for _ in range(2):                               # a second step raises if a bucket was left unreduced
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
         loss, _ = clip_forward_backward(ddp, criterion, batch, dev)
         assert all(p.grad is not None for p in ddp.parameters() if p.requires_grad)
         counts = list(criterion.n_gts)
         optimizer_step(ddp, opt, cfg["CLIP_MAX_NORM"])
         losses.append(float(loss))
+        step_ms.append((time.perf_counter() - t0) * 1e3)
     torch.cuda.synchronize()
     g = model.transformer.decoder.graphs()
     flat = torch.cat([p.detach().reshape(-1) for p in ddp.parameters()]).cpu()
     torch.save({"flat": flat, "losses": losses, "captures": g.captures, "replays": g.replays, "eager": g.eager,
-                "n_gts": counts, "backend": dist.get_backend(), "world": dist.get_world_size()}, f"{out_path}.{rank}")
+                "n_gts": counts, "backend": dist.get_backend(), "world": dist.get_world_size(),
+                "step_ms": step_ms}, f"{out_path}.{rank}")
     dist.barrier()
     dist.destroy_process_group()
 
@@ -140,5 +145,11 @@ def test_two_ranks_on_one_device_over_gloo_stay_in_sync(tmp_path):
     assert torch.equal(r0["flat"], r1["flat"]), "replicas diverged"
     assert torch.isfinite(r0["flat"]).all()
     assert r0["losses"][0] != r1["losses"][0]              # the ranks saw different clips
+    # ranks with different ground-truth counts (3 and 5 tracks -> different query buckets) still meet at every
+    # all-reduce: the second (steady-state) step of the two ranks ends within a few milliseconds of each other.  The
+    # spread is printed for the record (both ranks share ONE device here, so it is an upper bound on rank skew)
+    spread = abs(r0["step_ms"][1] - r1["step_ms"][1])
+    print(f"per-rank step time (ms): rank0 {r0['step_ms'][1]:.1f} rank1 {r1['step_ms'][1]:.1f} spread {spread:.1f}")
+    assert spread < 0.5 * max(r0["step_ms"][1], r1["step_ms"][1])
     for r in (r0, r1):                                     # decoder graphs active under DDP: 3 frames x 2 steps
         assert r["captures"] == 3 and r["replays"] == 6 and r["eager"] == 0, r

@@ -579,3 +579,54 @@ def test_inference_graphs_match_the_eager_tracker(monkeypatch):
             assert a.ids.tolist() == b.ids.tolist()
             assert torch.allclose(a.boxes, b.boxes, atol=1e-2, rtol=1e-4)          # pixels
             assert torch.allclose(a.scores, b.scores, atol=1e-4)
+
+
+def test_full_size_frame_real_model_default_kernels_vs_oracle_operator(monkeypatch, hip_lib):
+    """ONE 800 x 1333 frame through the real model (ResNet-50 + 6 encoder / 6 decoder layers, C = 256 -> D = 32, 300
+    queries, train_dancetrack.yaml) forward and backward on the DEFAULT path -- windowed forward, counting-sort
+    backward with kernel selection, fused prologue, decoder hipGraphs, clip_ops kernels -- against the same weights
+    with the oracle's torch statement of the operator (the reference's own fallback formulation,
+    models/ops/functions/ms_deform_attn_func.py:44-64) injected, eager, reference-shaped module boundary."""
+    import memotr_amd.modules.ms_deform_attn as mod
+    from memotr_amd.configs import dancetrack_config
+    from memotr_amd.models import build_model
+    from memotr_amd.structures.track_instances import TrackInstances
+    from memotr_amd.utils.nested_tensor import tensor_list_to_nested_tensor
+    from model_helpers import OracleMSDeformAttnFunction
+    torch.manual_seed(0)
+    cfg = dancetrack_config(DEVICE="cuda", AVAILABLE_GPUS="0", DROPOUT=0.0)
+    model = build_model(cfg).train()
+    with torch.no_grad():    # learnt-looking offsets / attention logits instead of the zero-initialised projections
+        for m in model.modules():
+            if isinstance(m, mod.MSDeformAttn):
+                m.sampling_offsets.weight.normal_(0, 0.01)
+                m.attention_weights.weight.normal_(0, 0.05)
+    frame = tensor_list_to_nested_tensor([torch.randn(3, 800, 1333)]).to("cuda")
+    tracks = [TrackInstances(hidden_dim=256, num_classes=1, use_dab=True).to("cuda")]
+    kernels = []
+
+    def run():
+        from memotr_amd import MultiScaleDeformableAttention as MSDA
+        model.zero_grad()
+        res = model(frame=frame, tracks=tracks)
+        loss = res["pred_bboxes"].square().sum() + res["pred_logits"].sum() * 0.1 + res["outputs"].mean()
+        loss.backward()
+        torch.cuda.synchronize()
+        kernels.append(dict(MSDA.LAST_KERNEL))
+        grads = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+        return res["pred_bboxes"].detach().clone(), res["pred_logits"].detach().clone(), grads
+
+    box_h, log_h, g_h = run()
+    dec = model.transformer.decoder.graphs()
+    assert dec.captures >= 1 and dec.eager == 0 and not dec.failed          # the decoder loop ran from its hipGraph
+    monkeypatch.setenv("MEMOTR_DECODER_GRAPHS", "0")       # (a replay would run the captured HIP kernels)
+    monkeypatch.setattr(mod, "FUSED_PROLOGUE", False)
+    monkeypatch.setattr(mod, "MSDeformAttnFunction", OracleMSDeformAttnFunction)
+    box_o, log_o, g_o = run()
+    torch.testing.assert_close(box_h, box_o, rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(log_h, log_o, rtol=1e-3, atol=5e-4)
+    assert g_h.keys() == g_o.keys()
+    worst = max(float((g_h[n] - g_o[n]).norm()) / (float(g_o[n].norm()) + 1e-6) for n in g_h)
+    assert worst < 1e-2, worst
+    # what the default path ran: the encoder's self-attention calls are the last operator calls of the backward
+    assert "tile_bins" in kernels[0]["backward"], kernels[0]

@@ -92,3 +92,36 @@ def test_gate_and_zero_padding_semantics():
     loc[0, 3, 0, 0, 0] = (1.0 + 1e-9, 0.5)  # x just right of W-0.5: gate w_im < W still true
     out = oracle.forward(value, shapes, lsi, loc, attn).reshape(-1)
     np.testing.assert_allclose(out, [1.0, 0.5, 0.0, 0.5], atol=1e-8)
+
+
+def test_index_claim_is_scoped_to_the_uncontracted_reading_of_the_reference():
+    """.cuh:285-286 is `loc * size - 0.5`; the oracle and the HIP kernels round the product first (two operations), an
+    nvcc build of the reference with its default -fmad=true contracts them into one fused multiply-add
+    (models/ops/setup.py:41-46 sets no -fmad=false).  How far apart are the two readings at the BASELINE encoder shape?
+      * sampling distributions with any noise in them (both bench distributions): no point lands on another pixel;
+      * locations EXACTLY on pixel centres (the encoder's reference points with zero / whole-pixel offsets -- a set of
+        measure zero, but the one a hand-made test would pick): ~1 % of the points floor to the neighbouring pixel, with
+        the fractional weight at the other end of [0, 1), i.e. the same interpolated value to one ulp.
+    The bit-exact index claim (include/msda_hip.h) is therefore a claim against the uncontracted reading."""
+    import torch
+    from memotr_amd.synth import encoder_reference_points, make_inputs, pyramid_shapes, star_offsets, valid_ratios
+    from oracle import msda_oracle as oracle
+    for dist in ("encoder_like", "uniform"):
+        x = make_inputs(dist=dist)
+        loc, sh = x["loc"].numpy(), x["shapes"].numpy()
+        h, w, g = oracle.indices(sh, loc)
+        hf, wf, gf = oracle.indices_fma(sh, loc)
+        assert h.size == 22323 * 8 * 16
+        assert int(((h != hf) | (w != wf)).sum()) == 0 and int((g != gf).sum()) == 0, dist
+    shapes = pyramid_shapes(800, 1333)
+    ref = encoder_reference_points(shapes, valid_ratios(800, 1333, shapes))
+    wh = torch.tensor([[w_, h_] for h_, w_ in shapes], dtype=torch.float32)
+    off = star_offsets(8, 4, 4)[None]
+    loc = (ref[:, None, :, None, :] + off / wh[None, None, :, None, :])[None].contiguous().numpy().astype(np.float32)
+    sh = np.asarray(shapes, dtype=np.int64)
+    h, w, g = oracle.indices(sh, loc)
+    hf, wf, gf = oracle.indices_fma(sh, loc)
+    flips = int(((h != hf) | (w != wf)).sum())
+    assert 0 < flips < 0.02 * h.size, flips          # measured 17,063 of 2,857,344 (0.6 %)
+    assert int((np.abs(h - hf) > 1).sum()) == 0 and int((np.abs(w - wf) > 1).sum()) == 0      # always the neighbour
+    assert int((g != gf).sum()) == 0                 # the (-1, size) gate is the same in both readings here
