@@ -243,15 +243,20 @@ def cpu_baseline_msda(args, enc_shape_kwargs, dec_shape_kwargs):
             reps += 1
         return min(t_enc), min(t_dec), reps
 
-    # the fallback on the node's host cores, core count stated -- all of them (or --cpu-threads)
-    cores = args.cpu_threads if args.cpu_threads > 0 else cpu_total
+    # the fallback on the node's host cores, core count stated -- all the cores this container may use
+    # (its CFS quota; more threads than that only get the process throttled), or --cpu-threads
+    from memotr_amd.utils.host import cpu_quota
+    usable = max(1, min(cpu_total, int(cpu_quota())))
+    cores = args.cpu_threads if args.cpu_threads > 0 else usable
+    threads_before = torch.get_num_threads()
     t_enc, t_dec, reps = measure(cores, args.cpu_budget_s * 0.5)
     per_frame = 6 * t_enc + 6 * t_dec
     result = {
         "value": 1.0 / per_frame, "unit": "frames/s", "cores": cores, "kind": "port",
-        "cpu_model": cpu_model, "host_cores": cpu_total,
+        "cpu_model": cpu_model, "host_cores": cpu_total, "container_cpu_quota": usable,
         "sample": f"{reps} reps of one encoder-shape + one decoder-shape fwd+bwd (torch-CPU grid_sample formulation; "
-                  f"{cpu_model}, {cpu_total} host cores, {cores} threads), best rep x6 calls each per frame",
+                  f"{cpu_model}, {cpu_total} logical host CPUs of which the container may use {usable}, {cores} threads), "
+                  f"best rep x6 calls each per frame",
         "enc_fwd_bwd_s": t_enc, "dec_fwd_bwd_s": t_dec,
     }
     if args.cpu_threads <= 0:
@@ -259,7 +264,7 @@ def cpu_baseline_msda(args, enc_shape_kwargs, dec_shape_kwargs):
         # is also timed at the best thread count of a quick probe on a reduced shape (context, not the baseline)
         probe_kw = dict(dec_shape_kwargs, height=200, width=336)
         best = None
-        for n in sorted({min(cpu_total, 64), min(cpu_total, 32), min(cpu_total, 16)}, reverse=True):
+        for n in sorted({min(usable, 64), min(usable, 32), min(usable, 16), min(usable, 8)}, reverse=True):
             torch.set_num_threads(n)
             xp = make_inputs(device="cpu", **probe_kw)
             oracle.grid_sample_forward(xp["value"], xp["shapes_list"], xp["loc"], xp["attn"])   # warm
@@ -272,6 +277,7 @@ def cpu_baseline_msda(args, enc_shape_kwargs, dec_shape_kwargs):
         if best[1] != cores:
             e2, d2, _ = measure(best[1], args.cpu_budget_s * 0.5)
             result["tuned_threads"] = {"threads": best[1], "value": 1.0 / (6 * e2 + 6 * d2), "unit": "frames/s"}
+    torch.set_num_threads(threads_before)
     return result
 
 
@@ -463,6 +469,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
     rank, _, world = init_dist(args.gpus)
+    # torch sizes its CPU thread pool from the machine, not from the container's CFS quota; the spinning workers then
+    # get the whole process throttled (memotr_amd/utils/host.py: 30.7 -> 95 frames/s on the online-tracking loop)
+    from memotr_amd.utils.host import respect_cpu_quota
+    respect_cpu_quota(processes=int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     if args.workload == "msda":
         result = run_msda(args, rank, world)
     elif args.workload == "infer":

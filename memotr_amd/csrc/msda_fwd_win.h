@@ -47,6 +47,7 @@ struct WinPlan {
     float rcpH[kWinMaxL], rcpW[kWinMaxL], rcpP;   // correctly rounded 1/H, 1/W, 1/P (div_small)
     unsigned value_bytes;
     int n_blocks;
+    unsigned long long *trace;     // profiling only (tools/fwd_win_timeline.py): 32 s_memtime stamps per wavefront, or null
     unsigned *stats, *stats_host;  // msda_select.h records (device / mapped host); null: no statistics
     int sel_parity, sel_level;
     int ablate;                    // profiling only (msda_set_option "fwd_win_ablate"): 1 stop after the prologue, 2 no gather,
@@ -216,6 +217,17 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
     const int L = pl.L, P = pl.P, LP = L * P, M = pl.M;
     const int tid = threadIdx.x, lane = tid & 63, nw = (int)(blockDim.x >> 6);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform, and known to be
+    unsigned long long *const trc = pl.trace ? pl.trace + ((size_t)sw * nw + wave) * 32 : nullptr;
+    int trc_k = 0;
+#define WIN_STAMP()                                                                   \
+    do {                                                                              \
+        if (trc != nullptr && trc_k < 32) {                                           \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();               \
+            if (lane == 0) trc[trc_k] = t_;                                           \
+            ++trc_k;                                                                  \
+        }                                                                             \
+    } while (0)
+    WIN_STAMP();       // 0: start
     if (tid < kWinMaxL) {
         tb.H[tid] = pl.H[tid];
         tb.W[tid] = pl.W[tid];
@@ -237,6 +249,7 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
     const bool stat_wg = pl.stats != nullptr && (sw & 7) == 0;
     unsigned n_live = 0u, n_off = 0u;   // (wave-uniform)
     __syncthreads();
+    WIN_STAMP();       // 1: tables
 
     // staging layout: lane -> (row slot, point)
     const int s_rs = lane >> 4, s_t = lane & 15;
@@ -313,7 +326,9 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
             }
         }
     }
+    WIN_STAMP();       // 2: first rows requested, offsets measured (the loads have returned: the DPP sums used them)
     __syncthreads();
+    WIN_STAMP();       // 3
     if (lwin0 < L) {
         if (tid >= lwin0 && tid < L) {
             const int l = tid;
@@ -368,6 +383,7 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
         }
     }
 
+    WIN_STAMP();       // 4: windows placed, fill issued
     // ---- this lane's point sits on one level for the whole kernel: its constants ----
     const bool c_pt = s_t < LP;
     const int cH = tb.H[s_l], cW = tb.W[s_l];
@@ -467,6 +483,7 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
             const unsigned fold = (unsigned)(bal | (bal >> 32));
             gmask = (fold | (fold >> 16)) & 0xffffu;
         }
+        WIN_STAMP();   // 5 + 3 it: staged
         // -- prefetch the next step's inputs --
         if (step + nw < pl.steps) {
             const int q = s_rowq[(step + nw) * 4 + s_rs];
@@ -494,6 +511,7 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
             if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
+        WIN_STAMP();   // 6 + 3 it: records visible, early loads issued, (first step) windows landed
         if (have && !(pl.ablate & 2)) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             // -- levels read from the LDS windows, four points per batch.  A point some row of the wave could not
@@ -588,7 +606,9 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        WIN_STAMP();   // 7 + 3 it: gathered, stored
     }
+#undef WIN_STAMP
     if (pl.stats != nullptr) {      // kernel selection: this launch's counts out, the previous launch's totals to the host
         if (stat_wg && lane == 0) sel_add(pl.stats, pl.sel_parity, (unsigned)((sw >> 3) * nw + wave), n_live, n_off, 0u);
         if (sw == 0 && wave == 1) sel_publish_previous(pl.stats, pl.stats_host, pl.sel_parity, (unsigned)pl.sel_level, lane);

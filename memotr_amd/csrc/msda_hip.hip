@@ -1992,6 +1992,7 @@ std::atomic<int> opt_fwd_win_margins{0x3333};  // window margin per level, 4 bit
 std::atomic<int> opt_fwd_win_ablate{0};     // profiling only
 std::atomic<int> opt_fwd_win_wps{0};        // 3 / 4: force the 168- / 128-register build
 std::atomic<int> opt_fwd_win_early{2};      // 0 / 1: global points after / around the LDS phase (2: by register budget)
+std::atomic<int> opt_fwd_win_trace_lo{0}, opt_fwd_win_trace_hi{0};   // profiling: device address of the timeline buffer (31 + 31 bits)
 std::atomic<int> opt_fwd_win_dma{1};        // fill the windows with buffer_load ... lds       // profiling only: drop parts of the tiled backward (results are then wrong)
 
 int fail(int code, const char *msg) {
@@ -2330,6 +2331,8 @@ int forward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart, 
                            (const float *)value, lstart, src, (float *)out, wp);                                     \
     } while (0)
                     wp.ablate = opt_fwd_win_ablate.load();
+                    wp.trace = reinterpret_cast<unsigned long long *>(((unsigned long long)opt_fwd_win_trace_hi.load() << 31) |
+                                                                      (unsigned long long)opt_fwd_win_trace_lo.load());
                     {       // (a captured launch would replay one parity for ever: no statistics from inside a capture)
                         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
                         const bool capturing = hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
@@ -2929,6 +2932,8 @@ static std::atomic<int> *find_opt(const char *key) {
     if (!strcmp(key, "fwd_win_l0")) return &opt_fwd_win_l0;
     if (!strcmp(key, "fwd_win_margins")) return &opt_fwd_win_margins;
     if (!strcmp(key, "fwd_win_dma")) return &opt_fwd_win_dma;
+    if (!strcmp(key, "fwd_win_trace_lo")) return &opt_fwd_win_trace_lo;
+    if (!strcmp(key, "fwd_win_trace_hi")) return &opt_fwd_win_trace_hi;
     if (!strcmp(key, "fwd_win_ablate")) return &opt_fwd_win_ablate;
     if (!strcmp(key, "fwd_win_wps")) return &opt_fwd_win_wps;
     if (!strcmp(key, "fwd_win_early")) return &opt_fwd_win_early;

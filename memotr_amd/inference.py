@@ -32,6 +32,8 @@ class SequenceTracker:
     def __init__(self, model, dataset_name: str = "DanceTrack", det_score_thresh: float = 0.7,
                  track_score_thresh: float = 0.6, result_score_thresh: float = 0.7, miss_tolerance: int = 5,
                  use_dab: bool = True, area_thresh: int = 100):
+        from .utils.host import respect_cpu_quota
+        respect_cpu_quota()           # (a container's CFS quota vs torch's machine-sized thread pool: utils/host.py)
         self.model = model.eval()
         self.core = get_model(model)
         self.dataset_name = dataset_name

@@ -112,6 +112,9 @@ def _thread_local_capture(census=None):
                 def __new__(cls, *a, **k):
                     return orig_graph_cls.__new__(cls, keep_graph=True)
 
+                def __init__(self, *a, **k):       # (the binding constructs in __init__, from the CALL's arguments)
+                    super().__init__(True)
+
             torch.cuda.CUDAGraph = _KeepGraph
         torch.cuda.graph = _Graph
         try:
