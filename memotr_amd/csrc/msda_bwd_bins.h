@@ -490,16 +490,21 @@ __global__ __launch_bounds__(kTileThreads, MSDA_BINS_WGS) void msda_bwd_d32_bins
         const unsigned nmax = max(max((unsigned)__builtin_amdgcn_readlane((int)nm, 0), (unsigned)__builtin_amdgcn_readlane((int)nm, 16)),
                                   max((unsigned)__builtin_amdgcn_readlane((int)nm, 32), (unsigned)__builtin_amdgcn_readlane((int)nm, 48)));
         const unsigned lim = pe + n * 8u;          // one past this cell's last entry
-        for (unsigned i = 0; i < nmax; i += 2, pe += 16u) {
-            const unsigned a0 = pe < lim ? pe : sent, a1 = pe + 8u < lim ? pe + 8u : sent;
-            const u32x2 e0 = *reinterpret_cast<const u32x2 *>(s_dyn + a0);
-            const u32x2 e1 = *reinterpret_cast<const u32x2 *>(s_dyn + a1);
+        // (the entries of iteration i + 1 are requested before the rows of iteration i are used: one LDS round trip per
+        //  iteration instead of two)
+        u32x2 e0 = *reinterpret_cast<const u32x2 *>(s_dyn + (pe < lim ? pe : sent));
+        u32x2 e1 = *reinterpret_cast<const u32x2 *>(s_dyn + (pe + 8u < lim ? pe + 8u : sent));
+        for (unsigned i = 0; i < nmax; i += 2) {
+            pe += 16u;
             const unsigned char *const g0 = G + e0.x + g_a, *const g1 = G + e1.x + g_a;
             const f32x4 x0 = *reinterpret_cast<const f32x4 *>(g0);
             const f32x4 y0 = *reinterpret_cast<const f32x4 *>(g0 + kChunkDelta);
             const f32x4 x1 = *reinterpret_cast<const f32x4 *>(g1);
             const f32x4 y1 = *reinterpret_cast<const f32x4 *>(g1 + kChunkDelta);
             const float w0 = __uint_as_float(e0.y), w1 = __uint_as_float(e1.y);
+            e0 = *reinterpret_cast<const u32x2 *>(s_dyn + (pe < lim ? pe : sent));
+            e1 = *reinterpret_cast<const u32x2 *>(s_dyn + (pe + 8u < lim ? pe + 8u : sent));
+            __builtin_amdgcn_sched_barrier(0);      // (keep the requests above the FMAs: the scheduler sinks them otherwise)
             acc_a += w0 * x0;
             acc_b += w0 * y0;
             acc_a += w1 * x1;
@@ -520,13 +525,16 @@ __global__ __launch_bounds__(kTileThreads, MSDA_BINS_WGS) void msda_bwd_d32_bins
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            float fv[4];
+            unsigned fo[4];
 #pragma unroll
-            for (int h = 0; h < 4; ++h) {
+            for (int h = 0; h < 4; ++h) {       // (eight reads in flight, then the four rows leave)
                 const int slot = 2 * h + half;
-                const float v = *reinterpret_cast<const float *>(ST + (unsigned)slot * 128u + (unsigned)c32 * 4u);
-                const unsigned goff = s_off[pass * 8 + slot] + (unsigned)c32 * 4u;    // (kOobOffset + 124: still out of range)
-                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, gr, (int)goff, 0, 0);
+                fv[h] = *reinterpret_cast<const float *>(ST + (unsigned)slot * 128u + (unsigned)c32 * 4u);
+                fo[h] = s_off[pass * 8 + slot] + (unsigned)c32 * 4u;      // (kOobOffset + 124: still out of range)
             }
+#pragma unroll
+            for (int h = 0; h < 4; ++h) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(fv[h], gr, (int)fo[h], 0, 0);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
