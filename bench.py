@@ -163,6 +163,41 @@ class FusedCall(MsdaCall):
             raise RuntimeError(self._lib.last_error())
 
 
+class FusedCallBf16(FusedCall):
+    """The same entry points with bf16 `value` / `out` / `grad_out` (BASELINE config 5's autocast step: fp32 locations,
+    weights, accumulation and grad_value)."""
+
+    def __init__(self, x):
+        super().__init__(x)
+        self.vb = x["value"].bfloat16().contiguous()
+        self.gob = x["grad_out"].bfloat16().contiguous()
+        self.outb = torch.empty(self.N, self.Lq, self.M * self.D, device=self.vb.device, dtype=torch.bfloat16)
+
+    def fwd(self):
+        x = self.x
+        rc = self.lib.msda_fused_forward_bf16(self.vb.data_ptr(), x["shapes"].data_ptr(), x["level_start"].data_ptr(),
+                                              self.proj.data_ptr(), self.proj.shape[2], self.ref.data_ptr(), 2, None,
+                                              self.N, self.S, self.M, self.D, self.L, self.Lq, self.P,
+                                              self.outb.data_ptr(), self.hptr, torch.cuda.current_stream().cuda_stream)
+        if rc:
+            raise RuntimeError(self._lib.last_error())
+
+    def bwd(self):
+        x = self.x
+        rc = self.lib.msda_fused_backward_ws_bf16(self.vb.data_ptr(), x["shapes"].data_ptr(), x["level_start"].data_ptr(),
+                                                  self.proj.data_ptr(), self.proj.shape[2], self.ref.data_ptr(), 2, None,
+                                                  self.gob.data_ptr(), self.N, self.S, self.M, self.D, self.L, self.Lq,
+                                                  self.P, self.gv.data_ptr(), self.gp.data_ptr(), None, 1, self.hptr,
+                                                  self.ws.data_ptr(), self.ws.numel(),
+                                                  torch.cuda.current_stream().cuda_stream)
+        if rc:
+            raise RuntimeError(self._lib.last_error())
+
+    def bytes(self, backward=False):
+        from memotr_amd.synth import algorithmic_bytes
+        return algorithmic_bytes(self.N, self.S, self.Lq, self.M, self.D, self.L, self.P, 2, backward)
+
+
 def time_kernel(fn, iters=200, warmup=20, min_warm_ms=40.0, batches=5):
     """Average launch duration (ms) from HIP events on the launch stream, steady state.
 
@@ -324,6 +359,22 @@ def kernel_lines(args, enc, dec):
     out["kernels"]["enc_fwd_%s_ms" % other] = ms_f
     out["kernels"]["enc_bwd_%s_ms" % other] = ms_b
     out["kernels"]["enc_bwd_%s_kernel" % other] = k_b
+    if getattr(args, "dtype", "f32") == "bf16":      # the autocast step launches the bf16-storage kernels: their line too
+        b16 = FusedCallBf16(enc.x)
+        lib.set_call_site(3)
+        ms16 = time_kernel(b16.fwd)
+        k16 = lib.last_kernel()
+        ms16b = time_kernel(b16.bwd, iters=50)
+        k16b = lib.last_kernel()
+        lib.set_call_site(0)
+        a16 = b16.bytes() / (ms16 * 1e-3) / 1e9
+        out["roofline_bf16"] = {"bound": "hbm", "achieved": a16, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                "frac": a16 / HBM_PEAK_GBPS, "traffic": None, "kernel": k16, "ms": ms16,
+                                "algorithmic_bytes": b16.bytes(), "loc_dist": args.dist}
+        out["kernels"]["enc_fwd_bf16_ms"] = ms16
+        out["kernels"]["enc_bwd_bf16_ms"] = ms16b
+        out["kernels"]["enc_bwd_bf16_kernel"] = k16b
+        out["kernels"]["enc_bwd_bf16_GBps"] = b16.bytes(True) / (ms16b * 1e-3) / 1e9
     return out
 
 

@@ -13,6 +13,7 @@ COMMON = os.path.join(_HERE, "csrc", "msda_common.h")
 FWD_WIN = os.path.join(_HERE, "csrc", "msda_fwd_win.h")
 BWD_ROWS = os.path.join(_HERE, "csrc", "msda_bwd_rows.h")
 BWD_BINS = os.path.join(_HERE, "csrc", "msda_bwd_bins.h")
+SELECT = os.path.join(_HERE, "csrc", "msda_select.h")
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libmsda_hip.so")
 CLIP_SRC = os.path.join(_HERE, "csrc", "clip_ops.hip")
@@ -38,7 +39,7 @@ def source_hash() -> str:
     number taken on other kernels is recognised as stale."""
     import hashlib
     h = hashlib.sha256()
-    for p in (SRC, COMMON, FWD_WIN, BWD_ROWS, BWD_BINS):
+    for p in (SRC, COMMON, FWD_WIN, BWD_ROWS, BWD_BINS, SELECT):
         with open(p, "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -52,7 +53,7 @@ def _stale(lib: str, deps) -> bool:
 
 
 def needs_build() -> bool:
-    return _stale(LIB, (SRC, HDR, COMMON, FWD_WIN, BWD_ROWS, BWD_BINS))
+    return _stale(LIB, (SRC, HDR, COMMON, FWD_WIN, BWD_ROWS, BWD_BINS, SELECT))
 
 
 def _compile(src: str, lib: str, verbose: bool) -> str:

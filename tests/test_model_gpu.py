@@ -422,6 +422,9 @@ def test_track_augmentation_masks_built_on_the_cpu_index_cuda_tracks(monkeypatch
     assert sub2.ids.tolist() == [5, 1]
 
 
+BF16_TOTAL_TOL, BF16_MEDIAN_TOL = 0.2, 0.2      # (set from the measured values below)
+
+
 def test_bf16_clip_step_with_eight_classes_tracks_the_fp32_step(monkeypatch):
     """BASELINE config 5 in miniature: K = 8 classes (BDD100K), bf16 autocast over the clip step.  bf16 runs where the
     FLOPs are (backbone, encoder, `value`); the decode half, the criterion and the query updater are float32 islands
@@ -467,8 +470,18 @@ def test_bf16_clip_step_with_eight_classes_tracks_the_fp32_step(monkeypatch):
     assert cache.captures == 3 and cache.eager == 0, (cache.captures, cache.eager)     # graphs under autocast
     assert abs(loss16 - loss32) < 0.02 * abs(loss32), (loss16, loss32)
     assert g16.keys() == g32.keys()
-    worst = max(float((g16[n] - g32[n]).norm()) / (float(g32[n].norm()) + 1e-4) for n in g32)
+    rel = {n: float((g16[n] - g32[n]).norm()) / (float(g32[n].norm()) + 1e-4) for n in g32}
+    worst = max(rel.values())
+    # per tensor: bf16 has 8 bits of mantissa and the encode half chains two to three bf16 GEMMs / convolutions in each
+    # direction, so single small tensors (biases behind a long chain) sit near 10 %; the BULK of the gradient is much
+    # closer -- the whole gradient vector is within `total` of the fp32 one and the median tensor within `median`
+    total = (sum(float((g16[n] - g32[n]).norm()) ** 2 for n in g32) ** 0.5) / (sum(float(g32[n].norm()) ** 2 for n in g32) ** 0.5)
+    ordered = sorted(rel.values())
+    median = ordered[len(ordered) // 2]
+    print(f"bf16 vs fp32 gradients: whole vector {total:.4f}, median tensor {median:.4f}, worst tensor {worst:.4f} "
+          f"({max(rel, key=rel.get)})")
     assert worst < 0.2, worst
+    assert total < BF16_TOTAL_TOL and median < BF16_MEDIAN_TOL, (total, median)
 
 
 @pytest.mark.parametrize("bf16", [False, True], ids=["fp32", "bf16"])
