@@ -44,6 +44,7 @@ struct WinPlan {
     int wbase[kWinMaxL + 1];       // first window pixel of level l; [kWinMaxL] = all window pixels = the zero row
     float ratw[kWinMaxL][kWinMaxL], rath[kWinMaxL][kWinMaxL];   // [lq][l] = W_l / W_lq, H_l / H_lq
     int groups;                    // 8-pixel fill groups (window pixels + the zero row, rounded up)
+    int wgroups_max;               // ... of the largest window (a masked call needs <= 8 per wavefront)
     float rcpH[kWinMaxL], rcpW[kWinMaxL], rcpP;   // correctly rounded 1/H, 1/W, 1/P (div_small)
     unsigned value_bytes;
     int n_blocks;
@@ -197,7 +198,9 @@ typedef __attribute__((address_space(3))) void lds_void;
 // workgroups per CU; 3: 168 VGPRs -- three 256-thread workgroups per CU, what 40-53 KB of LDS admits)
 // EARLY: the corner rows of the first four global points are requested before the LDS-served points and used after
 // them (their latency hides behind the LDS phase at the price of 40 registers held across it).
-template <bool FUSED, bool DMA, int WPS, bool EARLY>
+// TRACE: the timeline build (tools/fwd_win_timeline.py) -- s_memtime stamps at the phase boundaries; the production
+// instantiations hold none of it (as a run-time test the stamps cost 1.1 us per launch, round 4).
+template <bool FUSED, bool DMA, int WPS, bool EARLY, bool TRACE = false>
 __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(const float *__restrict__ value,
                                                            const int64_t *__restrict__ lstart, const PointSrc src,
                                                            float *__restrict__ out, const WinPlan pl) {
@@ -217,11 +220,11 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
     const int L = pl.L, P = pl.P, LP = L * P, M = pl.M;
     const int tid = threadIdx.x, lane = tid & 63, nw = (int)(blockDim.x >> 6);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform, and known to be
-    unsigned long long *const trc = pl.trace ? pl.trace + ((size_t)sw * nw + wave) * 32 : nullptr;
+    unsigned long long *const trc = (TRACE && pl.trace) ? pl.trace + ((size_t)sw * nw + wave) * 32 : nullptr;
     int trc_k = 0;
 #define WIN_STAMP()                                                                   \
     do {                                                                              \
-        if (trc != nullptr && trc_k < 32) {                                           \
+        if (TRACE && trc != nullptr && trc_k < 32) {                                  \
             const unsigned long long t_ = __builtin_amdgcn_s_memtime();               \
             if (lane == 0) trc[trc_k] = t_;                                           \
             ++trc_k;                                                                  \
@@ -237,7 +240,15 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
         tb.ww[tid] = pl.ww[tid];
         tb.wh[tid] = pl.wh[tid];
         tb.wmagic[tid] = pl.wmagic[tid];
-        tb.lstart[tid] = tid < L ? (int)lstart[tid] : 0;
+        // (uniform indices: scalar loads through the constant cache, not a vector load every wave waits a
+        //  memory round trip for before the first barrier)
+        int ls = 0;
+#pragma unroll
+        for (int i = 0; i < kWinMaxL; ++i) {
+            const int v = i < L ? (int)lstart[i] : 0;
+            ls = tid == i ? v : ls;
+        }
+        tb.lstart[tid] = ls;
         tb.ox[tid] = tb.oy[tid] = 0;
     }
     if (tid <= kWinMaxL) {
@@ -246,8 +257,12 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
     }
     if (tid >= 64 && tid < 80) tb.lvl[tid - 64] = (tid - 64) < LP ? (tid - 64) / P : 0;
     // statistics (msda_select.h): one workgroup in eight counts, every wavefront for itself
-    const bool stat_wg = pl.stats != nullptr && (sw & 7) == 0;
+#ifndef MSDA_WIN_STATS
+#define MSDA_WIN_STATS 1      // (0: A/B builds without the selector's counting)
+#endif
+    const bool stat_wg = MSDA_WIN_STATS && pl.stats != nullptr && (sw & 7) == 0;
     unsigned n_live = 0u, n_off = 0u;   // (wave-uniform)
+    unsigned char mpad[kWinMaxL] = {0, 0, 0, 0};      // fused + mask: "the window pixel this lane answers for is padded"
     __syncthreads();
     WIN_STAMP();       // 1: tables
 
@@ -352,13 +367,17 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
             tb.ox[l] = ox < -1 ? -1 : ox;
             tb.oy[l] = oy < -1 ? -1 : oy;
         }
+        WIN_STAMP();   // 4: (threads 1..3 of wavefront 0: placement done; everyone else: nothing)
         __syncthreads();
+        WIN_STAMP();   // 5: placement visible
 
         // ---- fill the windows: 8 pixels (1 KiB) per wave instruction; cells outside the level / padded read 0.
         //      Every level's window starts on a group boundary, so the level is uniform per instruction.  (One
         //      instruction per window ROW needs a third of the address arithmetic but 40 % more, partly filled,
         //      DMA instructions: measured slower, 16.6 vs 14.7 us for the start-up phase alone) ----
-        const unsigned char *mk = (FUSED && src.mask != nullptr) ? src.mask + (size_t)b * pl.S : nullptr;
+        //      The padding mask is NOT consulted here: a mask byte ahead of every DMA address makes each fill
+        //      instruction wait a memory round trip (and, vmcnt being in-order, for every DMA before it).  The bytes
+        //      are requested below, next to the fill, and padded pixels are zeroed in LDS once both have landed.
         for (int l = lwin0; l <= L; ++l) {        // l == L: the group that holds the zero row
             const int g0 = tb.wbase[l < L ? l : kWinMaxL] >> 3;
             const int g1 = l < L ? (tb.wbase[l + 1 < L ? l + 1 : kWinMaxL] >> 3) : pl.groups;
@@ -370,9 +389,8 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
                 const int local = (g - g0) * 8 + (lane >> 3);
                 const int wy = (local * magic) >> 16, wx = local - wy * ww;
                 const int gy = oy + wy, gx = ox + wx;
-                bool inside = (local < npx) & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
+                const bool inside = (local < npx) & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
                 const int cell = gy * W + gx;
-                if (mk != nullptr && inside) inside = !mk[tb.lstart[lc] + cell];
                 const unsigned off = inside ? lbase + (unsigned)cell * pix_stride : kOobOffset;
                 if (DMA) {
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(vr, (lds_void *)(s_dyn + (size_t)g * 1024), 16, (int)off, 0, 0, 0);
@@ -381,9 +399,28 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
                 }
             }
         }
+        // the mask bytes of the pixels THIS wavefront filled (8 lanes x 8 groups per level: make_win_plan's
+        // wgroups_max keeps a level's window within 64 * nw pixels when there is a mask), in flight with the fill
+        if (FUSED && src.mask != nullptr) {
+            const unsigned char *mk = src.mask + (size_t)b * pl.S;
+#pragma unroll
+            for (int l = 0; l < kWinMaxL; ++l) {
+                mpad[l] = 0;
+                if (l >= lwin0 && l < L) {
+                    const int g0 = tb.wbase[l] >> 3, g1 = tb.wbase[l + 1 < L ? l + 1 : kWinMaxL] >> 3;
+                    const int g = g0 + wave + (lane >> 3) * nw;
+                    const int local = (g - g0) * 8 + (lane & 7);
+                    const int ww = tb.ww[l], wy = (local * tb.wmagic[l]) >> 16, wx = local - wy * ww;
+                    const int gy = tb.oy[l] + wy, gx = tb.ox[l] + wx;
+                    const bool inside = (g < g1) & (local < ww * tb.wh[l]) & ((unsigned)gy < (unsigned)tb.H[l]) &
+                                        ((unsigned)gx < (unsigned)tb.W[l]);
+                    if (inside) mpad[l] = mk[tb.lstart[l] + gy * tb.W[l] + gx];
+                }
+            }
+        }
     }
 
-    WIN_STAMP();       // 4: windows placed, fill issued
+    WIN_STAMP();       // 6: fill issued
     // ---- this lane's point sits on one level for the whole kernel: its constants ----
     const bool c_pt = s_t < LP;
     const int cH = tb.H[s_l], cW = tb.W[s_l];
@@ -476,14 +513,11 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
                 rec_w[2 * lane + 1] = rb;
             }
             const unsigned long long bal = __builtin_amdgcn_ballot_w64(need && c_windowed);
-            if (stat_wg) {
-                n_off += (unsigned)__builtin_popcountll(bal);
-                n_live += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(live && c_windowed));
-            }
+            if (stat_wg) n_off += (unsigned)__builtin_popcountll(bal);
             const unsigned fold = (unsigned)(bal | (bal >> 32));
             gmask = (fold | (fold >> 16)) & 0xffffu;
         }
-        WIN_STAMP();   // 5 + 3 it: staged
+        WIN_STAMP();   // 7 + 3 it: staged
         // -- prefetch the next step's inputs --
         if (step + nw < pl.steps) {
             const int q = s_rowq[(step + nw) * 4 + s_rs];
@@ -509,9 +543,20 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
         }
         if (it == 0 && lwin0 < L) {            // the windows must have landed before the first LDS-served point
             if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (FUSED && src.mask != nullptr) {       // this wavefront's fill has landed: zero its padded pixels
+#pragma unroll
+                for (int l = 0; l < kWinMaxL; ++l) {
+                    if (mpad[l]) {
+                        const int g = (tb.wbase[l] >> 3) + wave + (lane >> 3) * nw;
+                        f32x4 *px = reinterpret_cast<f32x4 *>(s_dyn + ((size_t)g * 8 + (size_t)(lane & 7)) * 128);
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) px[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+            }
             __syncthreads();
         }
-        WIN_STAMP();   // 6 + 3 it: records visible, early loads issued, (first step) windows landed
+        WIN_STAMP();   // 8 + 3 it: records visible, early loads issued, (first step) windows landed
         if (have && !(pl.ablate & 2)) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             // -- levels read from the LDS windows, four points per batch.  A point some row of the wave could not
@@ -606,11 +651,18 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        WIN_STAMP();   // 7 + 3 it: gathered, stored
+        WIN_STAMP();   // 9 + 3 it: gathered, stored
     }
 #undef WIN_STAMP
     if (pl.stats != nullptr) {      // kernel selection: this launch's counts out, the previous launch's totals to the host
-        if (stat_wg && lane == 0) sel_add(pl.stats, pl.sel_parity, (unsigned)((sw >> 3) * nw + wave), n_live, n_off, 0u);
+        if (stat_wg) {
+            // the share's denominator: the windowed points of the rows this wavefront staged (counted once, here --
+            // a second ballot per step in the staging loop cost 0.5 us per launch)
+            const int st = wave + (lane >> 2) * nw;
+            const bool mine = lane < iters * 4 && st < pl.steps && s_rowq[st * 4 + (lane & 3)] >= 0;
+            n_live = (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(mine)) * (unsigned)(LP - T0);
+            if (lane == 0) sel_add(pl.stats, pl.sel_parity, (unsigned)((sw >> 3) * nw + wave), n_live, n_off, 0u);
+        }
         if (sw == 0 && wave == 1) sel_publish_previous(pl.stats, pl.stats_host, pl.sel_parity, (unsigned)pl.sel_level, lane);
     }
 }
@@ -659,6 +711,7 @@ inline bool make_win_plan(WinPlan &pl, const int64_t *shapes_host, int N, int S,
             }
             pl.wmagic[l] = magic;
             q += H * W; rows += side_x * side_y; px += (ww * wh + 7) & ~7;     // windows start on 8-pixel groups
+            if ((ww * wh + 7) / 8 > pl.wgroups_max) pl.wgroups_max = (ww * wh + 7) / 8;
             const int ry = (int)((H + side_y - 1) / side_y), rx = (int)((W + side_x - 1) / side_x);
             RY = ry > RY ? ry : RY;
             RX = rx > RX ? rx : RX;

@@ -2319,7 +2319,8 @@ int forward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart, 
                 int threads = opt_fwd_win_block.load();
                 if (threads != 512 && threads != 384 && threads != 128) threads = 256;
                 if (make_win_plan(wp, shapes_host, N, S, M, D, L, Lq, P, value_bytes, opt_fwd_win_rlogx.load(),
-                                  opt_fwd_win_rlog.load(), opt_fwd_win_l0.load(), margins, threads, lds)) {
+                                  opt_fwd_win_rlog.load(), opt_fwd_win_l0.load(), margins, threads, lds) &&
+                    !(src.mask != nullptr && wp.wgroups_max > 8 * (threads / 64))) {
                     const int grid = (wp.n_blocks + 7) & ~7;
                     const bool dma = opt_fwd_win_dma.load() != 0;
 #define MSDA_LAUNCH_WIN(FU, DM, WPS, EA, NAME)                                                                       \
@@ -2328,6 +2329,14 @@ int forward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart, 
         if (rc) return rc;                                                                                           \
         g_kernel = NAME;                                                                                             \
         hipLaunchKernelGGL((msda_fwd_d32_win<FU, DM, WPS, EA>), dim3(grid), dim3(threads), lds, stream,              \
+                           (const float *)value, lstart, src, (float *)out, wp);                                     \
+    } while (0)
+#define MSDA_LAUNCH_WIN_T(FU, NAME)                                                                                  \
+    do {                                                                                                             \
+        rc = allow_big_lds(msda_fwd_d32_win<FU, true, 3, true, true>, lds);                                          \
+        if (rc) return rc;                                                                                           \
+        g_kernel = NAME;                                                                                             \
+        hipLaunchKernelGGL((msda_fwd_d32_win<FU, true, 3, true, true>), dim3(grid), dim3(threads), lds, stream,      \
                            (const float *)value, lstart, src, (float *)out, wp);                                     \
     } while (0)
                     wp.ablate = opt_fwd_win_ablate.load();
@@ -2357,17 +2366,20 @@ int forward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart, 
                         if (fused) MSDA_LAUNCH_WIN(true, false, 4, false, "msda_fwd_d32_win<fused,nodma>");
                         else MSDA_LAUNCH_WIN(false, false, 4, false, "msda_fwd_d32_win<nodma>");
                     } else if (fused) {
-                        if (wps == 3 && early) MSDA_LAUNCH_WIN(true, true, 3, true, "msda_fwd_d32_win<fused,w3,early>");
+                        if (wps == 3 && early && wp.trace) MSDA_LAUNCH_WIN_T(true, "msda_fwd_d32_win<fused,w3,early>");
+                        else if (wps == 3 && early) MSDA_LAUNCH_WIN(true, true, 3, true, "msda_fwd_d32_win<fused,w3,early>");
                         else if (wps == 3) MSDA_LAUNCH_WIN(true, true, 3, false, "msda_fwd_d32_win<fused,w3>");
                         else if (early) MSDA_LAUNCH_WIN(true, true, 4, true, "msda_fwd_d32_win<fused,w4,early>");
                         else MSDA_LAUNCH_WIN(true, true, 4, false, "msda_fwd_d32_win<fused,w4>");
                     } else {
-                        if (wps == 3 && early) MSDA_LAUNCH_WIN(false, true, 3, true, "msda_fwd_d32_win<w3,early>");
+                        if (wps == 3 && early && wp.trace) MSDA_LAUNCH_WIN_T(false, "msda_fwd_d32_win<w3,early>");
+                        else if (wps == 3 && early) MSDA_LAUNCH_WIN(false, true, 3, true, "msda_fwd_d32_win<w3,early>");
                         else if (wps == 3) MSDA_LAUNCH_WIN(false, true, 3, false, "msda_fwd_d32_win<w3>");
                         else if (early) MSDA_LAUNCH_WIN(false, true, 4, true, "msda_fwd_d32_win<w4,early>");
                         else MSDA_LAUNCH_WIN(false, true, 4, false, "msda_fwd_d32_win<w4>");
                     }
 #undef MSDA_LAUNCH_WIN
+#undef MSDA_LAUNCH_WIN_T
                     return check_launch(g_kernel);
                 }
                 variant = 3;  // the windowed kernel does not apply to this call

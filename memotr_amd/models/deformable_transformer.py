@@ -2,6 +2,7 @@
 two-stage branch there is dead code -- it raises at :234 -- and is not reproduced)."""
 from __future__ import annotations
 
+import os
 from typing import List
 
 import torch
@@ -13,6 +14,7 @@ from ..functions.clip_ops import add_row_bias
 
 from .. import MultiScaleDeformableAttention as MSDA
 from ..modules import MSDeformAttn
+from ..modules.ms_deform_attn import tag_masked_rows
 from .deformable_decoder import DeformableDecoder, DeformableDecoderLayer
 from .deformable_encoder import DeformableEncoder, DeformableEncoderLayer
 
@@ -122,6 +124,8 @@ class DeformableTransformer(nn.Module):
                     enc_ref = self.encoder.get_reference_points(shapes_list, valid_ratios, src_flatten.device)
                 if len(cache) >= 16:
                     cache.clear()
+                if os.environ.get("MEMOTR_MASKED_ROWS", "1") != "0":
+                    tag_masked_rows(mask_flatten)      # once per geometry: the modules zero these rows of `value`
                 cache[key] = (mask_flatten, valid_ratios, enc_ref)
 
         if self.use_checkpoint and self.checkpoint_level in (2, 3):

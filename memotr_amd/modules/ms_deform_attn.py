@@ -46,6 +46,44 @@ def _level_sizes(spatial_shapes: torch.Tensor, dtype: torch.dtype) -> torch.Tens
     return cached[1]
 
 
+MASKED_ROWS_ATTR = "_msda_masked_rows"
+
+
+def tag_masked_rows(mask: torch.Tensor) -> torch.Tensor:
+    """Attach to a padding mask (N, S) the flat indices of its padded rows (one host read-back, so: callers that cache
+    the mask per image geometry -- ``DeformableTransformer.encode``).  A module that finds the tag zeroes exactly those
+    rows of ``value`` where the projection GEMM wrote them (and of ``grad_value`` on the way back) and calls the
+    kernels WITHOUT a mask: same results as the reference's ``value.masked_fill(mask[..., None], 0)``
+    (models/ops/modules/ms_deform_attn.py:107-108), but the kernels lose the dependent mask-byte loads in front of
+    their gathers -- measured at the encoder shape with the 800 x 1333 frame's own mask (1344-wide padding):
+    forward 73.4 -> 56.6 us, backward 174.4 -> 163.1 us per image (profiles/r04_lib_ab_mask.txt)."""
+    if mask is not None and mask.is_cuda and not torch.cuda.is_current_stream_capturing():
+        setattr(mask, MASKED_ROWS_ATTR, mask.reshape(-1).nonzero().squeeze(1))
+    return mask
+
+
+class _ZeroRows(torch.autograd.Function):
+    """``x[rows] = 0`` -- in place when ``x`` is a freshly produced tensor (the 2-d product inside ``long_linear``: an
+    in-place op on a VIEW of a custom Function's output would make autograd rebase the graph and copy the whole
+    gradient), a copy otherwise; the gradient of those rows is zero."""
+
+    @staticmethod
+    def forward(ctx, x, rows):
+        ctx.rows = rows
+        if x._is_view() or not x.is_contiguous():
+            return x.reshape(-1, x.shape[-1]).index_fill(0, rows, 0).view(x.shape)
+        x.view(-1, x.shape[-1]).index_fill_(0, rows, 0)
+        ctx.mark_dirty(x)
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        # (g is the operator's own grad_value buffer, consumed by nothing else: zeroed in place like the kernels did)
+        g = g.contiguous()
+        g.view(-1, g.shape[-1]).index_fill_(0, ctx.rows, 0)
+        return g, None
+
+
 class MSDeformAttn(nn.Module):
     def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4, sigmoid_attn=False, visualize=False):
         super().__init__()
@@ -158,7 +196,18 @@ class MSDeformAttn(nn.Module):
                 site = self.__dict__["_msda_site"] = MSDA.new_call_site()
             MSDA.set_call_site(site)
 
-        value = long_linear(input_flatten, self.value_proj.weight, self.value_proj.bias)
+        # (tag_masked_rows: the padded rows of the mask are known -- zeroed where the projection writes them, and the
+        #  kernels run without a mask; the conditions are those of the fused branch below)
+        mask = input_padding_mask
+        rows = getattr(mask, MASKED_ROWS_ATTR, None) if mask is not None else None
+        if rows is not None and not (FUSED_PROLOGUE and input_flatten.is_cuda and not self.sigmoid_attn):
+            rows = None
+        zero = None
+        if rows is not None:
+            mask = None
+            if rows.numel():
+                zero = lambda y: _ZeroRows.apply(y, rows)      # noqa: E731
+        value = long_linear(input_flatten, self.value_proj.weight, self.value_proj.bias, activation=zero)
 
         # one GEMM for both query projections
         n_off = M * L * P * 2
@@ -181,12 +230,12 @@ class MSDeformAttn(nn.Module):
             out = MSDeformAttnFusedFunction.apply(value.view(N, S, M, self.d_model // M), input_spatial_shapes,
                                                   input_level_start_index, proj.contiguous(),
                                                   reference_points.contiguous(),
-                                                  None if input_padding_mask is None else input_padding_mask.contiguous(),
+                                                  None if mask is None else mask.contiguous(),
                                                   M, P)
             return long_linear(out, self.output_proj.weight, self.output_proj.bias)
 
-        if input_padding_mask is not None:
-            value = value.masked_fill(input_padding_mask[..., None], 0.0)
+        if mask is not None:
+            value = value.masked_fill(mask[..., None], 0.0)
         value = value.view(N, S, M, self.d_model // M)
         # views (only the last dim is split), not reshape copies: the ops below write contiguous results anyway
         offsets = proj[..., :n_off].unflatten(-1, (M, L, P, 2))

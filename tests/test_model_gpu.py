@@ -621,7 +621,9 @@ def test_full_size_frame_real_model_default_kernels_vs_oracle_operator(monkeypat
     def run():
         from memotr_amd import MultiScaleDeformableAttention as MSDA
         model.zero_grad()
-        res = model(frame=frame, tracks=tracks)
+        enc = model(frame=frame, stage="encode")
+        enc = dict(enc, frame_slot=0, clip_key=object())      # as engine.clip_forward_backward hands a frame over
+        res = model(tracks=tracks, encoded=enc)
         loss = res["pred_bboxes"].square().sum() + res["pred_logits"].sum() * 0.1 + res["outputs"].mean()
         loss.backward()
         torch.cuda.synchronize()

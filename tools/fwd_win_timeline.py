@@ -15,7 +15,7 @@ from bench import FusedCall, MsdaCall, time_kernel  # noqa: E402
 from memotr_amd import _lib  # noqa: E402
 from memotr_amd.synth import make_inputs  # noqa: E402
 
-NAMES = ["tables+sync", "first loads + offsets", "sync", "place + fill issue"]
+NAMES = ["tables+sync", "first loads + offsets", "sync", "placement (3 threads)", "sync", "fill issue"]
 
 
 def main():
@@ -45,10 +45,10 @@ def main():
     lines.append(f"launch span (first stamp -> last stamp anywhere): {(t.max() - launch):.0f} ticks; "
                  f"workgroup start times: median {np.median(t[:, 0, 0] - launch):.0f}, 90 % {np.percentile(t[:, 0, 0] - launch, 90):.0f}")
     d = np.diff(t, axis=2)
-    for k in range(4):
+    for k in range(len(NAMES)):
         lines.append(f"  {NAMES[k]:28s} {d[:, :, k].mean():8.0f}")
     for it in range(6):
-        base = 4 + 3 * it
+        base = len(NAMES) + 3 * it
         valid = t[:, :, base + 3] > 0
         if not valid.any():
             break
