@@ -322,6 +322,9 @@ def kernel_lines(args, enc, dec):
     models/ops/test.py:33, worst-case locality).  Each distribution gets its own call site, so the kernel selection
     (memotr_amd/csrc/msda_select.h) judges them separately; it is given 40 calls to settle before the timing."""
     from memotr_amd.synth import make_inputs
+    if os.environ.get("MEMOTR_BENCH_NO_KERNEL_LEGS", "0") == "1":
+        # profiling runs only (tools/prof.sh train): the kernel table of the STEP, without ~1500 timing launches
+        return {"roofline": None, "kernels": {}}
     lib = enc._lib
     lib.set_call_site(1)
     ms_fwd = time_kernel(enc.fwd)

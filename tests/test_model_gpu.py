@@ -422,13 +422,15 @@ def test_track_augmentation_masks_built_on_the_cpu_index_cuda_tracks(monkeypatch
     assert sub2.ids.tolist() == [5, 1]
 
 
-BF16_TOTAL_TOL, BF16_MEDIAN_TOL = 0.2, 0.2      # (set from the measured values below)
+# measured on MI355X (round 4): whole gradient vector 0.0034, median tensor 0.0078, worst tensor 0.096 (the sampling-offset
+# projection of encoder layer 0: a small-norm gradient behind the longest bf16 chain); the bounds leave 2-3x for seeds
+BF16_TOTAL_TOL, BF16_MEDIAN_TOL, BF16_WORST_TOL = 0.01, 0.02, 0.15
 
 
 def test_bf16_clip_step_with_eight_classes_tracks_the_fp32_step(monkeypatch):
     """BASELINE config 5 in miniature: K = 8 classes (BDD100K), bf16 autocast over the clip step.  bf16 runs where the
     FLOPs are (backbone, encoder, `value`); the decode half, the criterion and the query updater are float32 islands
-    with the decoder hipGraphs active.  Loss within 2 % of the fp32 step; per-parameter gradients within 20 % of the
+    with the decoder hipGraphs active.  Loss within 2 % of the fp32 step; per-parameter gradients within 15 % of the
     fp32 gradient's norm (two bf16 GEMM chains: ~3 significant digits)."""
     from memotr_amd.engine import clip_forward_backward, make_synthetic_clip, clip_to_device
     from memotr_amd.models.criterion import build as build_criterion
@@ -480,7 +482,7 @@ def test_bf16_clip_step_with_eight_classes_tracks_the_fp32_step(monkeypatch):
     median = ordered[len(ordered) // 2]
     print(f"bf16 vs fp32 gradients: whole vector {total:.4f}, median tensor {median:.4f}, worst tensor {worst:.4f} "
           f"({max(rel, key=rel.get)})")
-    assert worst < 0.2, worst
+    assert worst < BF16_WORST_TOL, worst
     assert total < BF16_TOTAL_TOL and median < BF16_MEDIAN_TOL, (total, median)
 
 

@@ -98,11 +98,8 @@ def main():
     # gfx950 for wide coalesced reads per MI355X_MICROARCH.md) + WRITE_SIZE (KiB)
     fwd = {k: v for k, v in traffic.get("fetch", {}).items() if "msda_fwd" in k}
     if fwd:
-        key = max(fwd, key=lambda k: int(k.split("@grid")[-1]) if k.split("@grid")[-1].isdigit() else 0)
-        fe = fwd[key]["mean"]
-        wr = traffic.get("write", {}).get(key, {}).get("mean", 0.0)
-        # stamp: the label bench.py prints for this kernel (msda_last_kernel) and the hash of the kernel sources,
-        # so bench.py can refuse the number once the dominant kernel or its source has changed
+        # stamp: the label bench.py prints for its `roofline` kernel (msda_last_kernel) and the hash of the kernel
+        # sources, so bench.py can refuse the number once the dominant kernel or its source has changed
         label, sha = None, None
         try:
             sys.path.insert(0, repo)
@@ -113,6 +110,13 @@ def main():
                     label = json.loads(ln)["roofline"].get("kernel")
         except Exception as exc:  # noqa: BLE001
             print("traffic stamp incomplete:", exc)
+        # the launches of THAT kernel (bench.py also times the other location distribution, which may select another
+        # forward kernel at the same shape): same base name, largest grid
+        base = label.split("<")[0] if label else "msda_fwd"
+        cand = {k: v for k, v in fwd.items() if base in k} or fwd
+        key = max(cand, key=lambda k: int(k.split("@grid")[-1]) if k.split("@grid")[-1].isdigit() else 0)
+        fe = fwd[key]["mean"]
+        wr = traffic.get("write", {}).get(key, {}).get("mean", 0.0)
         with open(os.path.join(out_dir, "traffic.json"), "w") as f:
             json.dump({"msda_fwd_encoder_bytes_per_launch": int((2 * fe + wr) * 1024), "kernel": key,
                        "kernel_label": label, "source_sha16": sha,
