@@ -261,7 +261,7 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
 #define MSDA_WIN_STATS 1      // (0: A/B builds without the selector's counting)
 #endif
     const bool stat_wg = MSDA_WIN_STATS && pl.stats != nullptr && (sw & 7) == 0;
-    unsigned n_live = 0u, n_off = 0u;   // (wave-uniform)
+    unsigned v_off = 0u;                // statistics: windowed points of this lane that left their window
     unsigned char mpad[kWinMaxL] = {0, 0, 0, 0};      // fused + mask: "the window pixel this lane answers for is padded"
     __syncthreads();
     WIN_STAMP();       // 1: tables
@@ -441,7 +441,10 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
     const bool early = EARLY && T0 >= 4;
 
     // ---- the steps: stage 64 (row, point) records, gather, store ----
-    if (pl.ablate & 1) {
+    // (the profiling switches exist in the TRACE instantiation only: as run-time tests in the step loop they hold
+    //  scalar registers the production kernel has none to spare of -- 106 of 106 with six spilled, round 4)
+    const int ablate = TRACE ? pl.ablate : 0;
+    if (ablate & 1) {
         if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         return;
     }
@@ -497,7 +500,7 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
                 ok10 = ok10 && !c_mask[ok10 ? cell + cW : 0];
                 ok11 = ok11 && !c_mask[ok11 ? cell + cW + 1 : 0];
             }
-            if (pl.ablate & 4) {      // profiling only (tools/fwd_offset_sweep.py): which points left their window
+            if (ablate & 4) {      // profiling only (tools/fwd_offset_sweep.py): which points left their window
                 const int qq = s_rowq[step * 4 + s_rs];
                 if (c_pt && qq >= 0)
                     out[(size_t)((q_base + (unsigned)qq) * (unsigned)M + (unsigned)m) * 32u + (unsigned)s_t] =
@@ -513,7 +516,7 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
                 rec_w[2 * lane + 1] = rb;
             }
             const unsigned long long bal = __builtin_amdgcn_ballot_w64(need && c_windowed);
-            if (stat_wg) n_off += (unsigned)__builtin_popcountll(bal);
+            v_off += (need && c_windowed) ? 1u : 0u;      // (statistics: per lane, summed once at the end)
             const unsigned fold = (unsigned)(bal | (bal >> 32));
             gmask = (fold | (fold >> 16)) & 0xffffu;
         }
@@ -532,7 +535,7 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
         //    LDS-served points (fewer than four such points: they all go through the late loop) --
         u32x4 gr[4];
         f32x4 gv[4][2];
-        if (have && early && !(pl.ablate & 2)) {
+        if (have && early && !(ablate & 2)) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) gr[i] = rec_g[2 * i];
 #pragma unroll
@@ -557,7 +560,7 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
             __syncthreads();
         }
         WIN_STAMP();   // 8 + 3 it: records visible, early loads issued, (first step) windows landed
-        if (have && !(pl.ablate & 2)) {
+        if (have && !(ablate & 2)) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             // -- levels read from the LDS windows, four points per batch.  A point some row of the wave could not
             //    serve from its window (bit in gmask) is handled on the spot, loads and FMAs, so that the common path
@@ -660,7 +663,10 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
             // a second ballot per step in the staging loop cost 0.5 us per launch)
             const int st = wave + (lane >> 2) * nw;
             const bool mine = lane < iters * 4 && st < pl.steps && s_rowq[st * 4 + (lane & 3)] >= 0;
-            n_live = (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(mine)) * (unsigned)(LP - T0);
+            const unsigned n_live = (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(mine)) * (unsigned)(LP - T0);
+            unsigned n_off = v_off;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) n_off += __shfl_xor(n_off, o, 64);
             if (lane == 0) sel_add(pl.stats, pl.sel_parity, (unsigned)((sw >> 3) * nw + wave), n_live, n_off, 0u);
         }
         if (sw == 0 && wave == 1) sel_publish_previous(pl.stats, pl.stats_host, pl.sel_parity, (unsigned)pl.sel_level, lane);

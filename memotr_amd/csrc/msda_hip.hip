@@ -2366,13 +2366,13 @@ int forward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart, 
                         if (fused) MSDA_LAUNCH_WIN(true, false, 4, false, "msda_fwd_d32_win<fused,nodma>");
                         else MSDA_LAUNCH_WIN(false, false, 4, false, "msda_fwd_d32_win<nodma>");
                     } else if (fused) {
-                        if (wps == 3 && early && wp.trace) MSDA_LAUNCH_WIN_T(true, "msda_fwd_d32_win<fused,w3,early>");
+                        if (wps == 3 && early && (wp.trace || wp.ablate)) MSDA_LAUNCH_WIN_T(true, "msda_fwd_d32_win<fused,w3,early>");
                         else if (wps == 3 && early) MSDA_LAUNCH_WIN(true, true, 3, true, "msda_fwd_d32_win<fused,w3,early>");
                         else if (wps == 3) MSDA_LAUNCH_WIN(true, true, 3, false, "msda_fwd_d32_win<fused,w3>");
                         else if (early) MSDA_LAUNCH_WIN(true, true, 4, true, "msda_fwd_d32_win<fused,w4,early>");
                         else MSDA_LAUNCH_WIN(true, true, 4, false, "msda_fwd_d32_win<fused,w4>");
                     } else {
-                        if (wps == 3 && early && wp.trace) MSDA_LAUNCH_WIN_T(false, "msda_fwd_d32_win<w3,early>");
+                        if (wps == 3 && early && (wp.trace || wp.ablate)) MSDA_LAUNCH_WIN_T(false, "msda_fwd_d32_win<w3,early>");
                         else if (wps == 3 && early) MSDA_LAUNCH_WIN(false, true, 3, true, "msda_fwd_d32_win<w3,early>");
                         else if (wps == 3) MSDA_LAUNCH_WIN(false, true, 3, false, "msda_fwd_d32_win<w3>");
                         else if (early) MSDA_LAUNCH_WIN(false, true, 4, true, "msda_fwd_d32_win<w4,early>");
