@@ -122,7 +122,7 @@ def run_train(args, rank: int, world: int, clip_len: int = None, height: int = 8
                    "parallelism": f"dp{world}", "trainable_params": n_params, "tuned_gemms": n_tuned,
                    "frames_per_gpu_per_sec": clip_len * args.steps / dt, "final_loss": float(loss.detach())},
         "max_memory_MB": torch.cuda.max_memory_allocated() // (1024 ** 2),
-        "per_rank_ms_per_step": per_rank, "process_group": backend,
+        "per_rank_ms_per_step": per_rank, "rank_skew_ms": max(per_rank) - min(per_rank), "process_group": backend,
         "decoder_graphs": _graph_stats(model)["captures"], "decoder_graph_stats": _graph_stats(model),
     }
 
