@@ -137,7 +137,10 @@ int clipops_add_layer_norm_bwd_f32(const float *grad_y, const float *sum, const 
  * problem, all state in LDS, max(n_rows, n_cols) <= CLIPOPS_ASSIGN_MAX_DIM.  Outputs, k = min(n_rows, n_cols):
  * row_ind, col_ind (n_problems, k) int32 -- pairs ordered by row like scipy's result; status (n_problems) int32,
  * may be NULL: k, or -1 for an infeasible matrix (every completion costs +inf: scipy raises ValueError).
- * Round 3: the solver and its parity tests; the criterion still consumes scipy's result on the host. */
+ * NOT checked: NaN or -inf entries (scipy raises ValueError on them; this kernel returns some pairing) -- a caller
+ * that cannot rule them out tests the matrix first.  Dynamic LDS is 13 n_r + 29 n_c bytes: past 64 KB (n ~ 1560) the
+ * launcher raises the kernel's limit itself (round 4).
+ * The solver and its parity tests; the model's criterion consumes scipy's result on the host (shelved). */
 #define CLIPOPS_ASSIGN_MAX_DIM 2048
 int clipops_assign_f32(const float *cost, long stride_problem, long stride_row, long stride_col, int n_problems,
                        int n_rows, int n_cols, int32_t *row_ind, int32_t *col_ind, int32_t *status, void *stream);

@@ -1018,6 +1018,18 @@ int clipops_assign_f32(const float *cost, long stride_problem, long stride_row, 
     const int nr = n_rows < n_cols ? n_rows : n_cols, nc = n_rows < n_cols ? n_cols : n_rows;
     if (nc > CLIPOPS_ASSIGN_MAX_DIM) return fail(2, "clipops_assign_f32: problem exceeds CLIPOPS_ASSIGN_MAX_DIM");
     const size_t lds = (assign::work_bytes(nr, nc) + 15) & ~(size_t)15;
+    if (lds > 64 * 1024) {       // beyond the default limit of a launch: opt in (gfx950 has 160 KB per CU), once per process
+        static std::atomic<size_t> allowed{0};
+        if (lds > 160 * 1024) return fail(2, "clipops_assign_f32: problem does not fit the LDS of a CU");
+        if (lds > allowed.load()) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(assign_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                (void)hipGetLastError();
+                return fail(3, "clipops_assign_f32: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+            }
+            allowed.store(160 * 1024);
+        }
+    }
     hipLaunchKernelGGL(assign_kernel, dim3(n_problems), dim3(64), lds, (hipStream_t)stream, cost, stride_problem,
                        stride_row, stride_col, n_rows, n_cols, row_ind, col_ind, status);
     return check_launch("assign_kernel");

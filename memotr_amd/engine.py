@@ -248,7 +248,8 @@ def clip_forward_backward(model: nn.Module, criterion, batch: dict, device, use_
             previous, new, unmatched = criterion.finish_frame(pending)
         if frame_idx < clip_len - 1:
             tracks = core.postprocess_single_frame(previous, new, unmatched)
-    loss_dict, _ = criterion.get_mean_by_n_gts()
+    # (no log values here: each is a device->host read, i.e. a stream synchronisation in front of the backward)
+    loss_dict, _ = criterion.get_mean_by_n_gts(with_log=os.environ.get("MEMOTR_LOSS_LOG_SYNC", "0") == "1")
     loss = criterion.get_sum_loss_dict(loss_dict=loss_dict)
     if backward:
         # the backward pass never runs under autocast (the engine's threads inherit the caller's autocast state):

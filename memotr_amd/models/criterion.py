@@ -124,20 +124,32 @@ class ClipCriterion:
                     return self.weight[k]
         return sum(w(k) * v for k, v in loss_dict.items())
 
-    def get_mean_by_n_gts(self) -> Tuple[Dict, Dict]:
-        counts = torch.as_tensor([float(sum(self.n_gts))] + [float(n) for n in self.n_gts], dtype=torch.float,
-                                 device=self.device)
+    def get_mean_by_n_gts(self, with_log: bool = True) -> Tuple[Dict, Dict]:
+        """Losses divided by the clip's (world-averaged) ground-truth count (reference models/criterion.py:196-216) and,
+        with ``with_log``, the per-frame log values as python floats.  The counts are host numbers: a single process
+        divides by them directly; under torch.distributed ONE all-reduce of 1 + T floats runs and the total stays on
+        the device.  ``with_log=False`` (the training loop) therefore reads nothing back: every float() here is a
+        stream synchronisation between the forward and the backward of the step."""
+        host = [float(sum(self.n_gts))] + [float(n) for n in self.n_gts]
+        per_frame = None
         if is_distributed():
+            counts = torch.as_tensor(host, dtype=torch.float, device=self.device)
             torch.distributed.all_reduce(counts)
-        counts = torch.clamp(counts / distributed_world_size(), min=1).tolist()
-        total, per_frame = counts[0], counts[1:]
+            counts = torch.clamp(counts / distributed_world_size(), min=1)
+            total = counts[0]
+            if with_log:
+                per_frame = counts[1:].tolist()
+        else:
+            total = max(host[0], 1.0)
+            per_frame = [max(c, 1.0) for c in host[1:]]
         loss = {k: v / total for k, v in self.loss.items()}
         log = {}
-        for k, v in self.log.items():
-            for i, n in enumerate(per_frame):
-                if f"frame{i}" in k:
-                    log[k] = (float(v) / n, 1)
-                    break
+        if with_log:
+            for k, v in self.log.items():
+                for i, n in enumerate(per_frame):
+                    if f"frame{i}" in k:
+                        log[k] = (float(v) / n, 1)
+                        break
         return loss, log
 
     # ------------------------------------------------------------------ one frame

@@ -386,3 +386,9 @@ def test_device_assignment_batches_the_layers_of_a_frame_and_flags_infeasible_co
     big = torch.zeros(1, 4, 3000).cuda()
     with pytest.raises(RuntimeError, match="CLIPOPS_ASSIGN_MAX_DIM"):
         clip_ops.assign(big)
+    # 13 n_r + 29 n_c bytes of LDS: (1700, 1800) needs 74 KB -- past the default 64 KB of a launch, the launcher opts in
+    wide = torch.rand(1, 1700, 1800, generator=g).cuda()
+    r, c, st = clip_ops.assign(wide)
+    wr, wc = linear_sum_assignment(wide[0].cpu().numpy())
+    assert st.tolist() == [1700]
+    assert np.array_equal(r[0].cpu().numpy(), wr) and np.array_equal(c[0].cpu().numpy(), wc)

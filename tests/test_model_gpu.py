@@ -596,6 +596,51 @@ def test_inference_graphs_match_the_eager_tracker(monkeypatch):
             assert torch.allclose(a.scores, b.scores, atol=1e-4)
 
 
+def test_inference_encode_graph_follows_a_checkpoint_loaded_in_place(monkeypatch):
+    """The folded batch-norm constants are baked into a captured encode graph (advisor, round 3): a forward, then
+    `load_state_dict` with other running statistics IN PLACE (same storages: the parameter fingerprint cannot see it),
+    then a forward must give what the eager model gives -- the key carries the buffers' version counters.  And two
+    encode results of one slot held at the same time are two tensors, not one static buffer seen twice."""
+    from memotr_amd.utils.nested_tensor import tensor_list_to_nested_tensor
+    monkeypatch.setenv("MEMOTR_REQUIRE_GRAPHS", "1")
+    from memotr_amd.configs import dancetrack_config
+    from memotr_amd.models import build_model
+    torch.manual_seed(7)
+    cfg = dancetrack_config(DEVICE="cuda", AVAILABLE_GPUS="0", DROPOUT=0.0, NUM_ENC_LAYERS=1, NUM_DEC_LAYERS=1)
+    model = build_model(cfg).eval()              # the real backbone: ResNet-50 with frozen batch norms
+    g = torch.Generator().manual_seed(3)
+    fa = tensor_list_to_nested_tensor([torch.randn(3, 192, 256, generator=g)]).to(torch.device("cuda"))
+    fb = tensor_list_to_nested_tensor([torch.randn(3, 192, 256, generator=g)]).to(torch.device("cuda"))
+
+    def encode(frame, graphs):
+        monkeypatch.setenv("MEMOTR_INFER_GRAPHS", "1" if graphs else "0")
+        with torch.no_grad():
+            return model(frame=frame, stage="encode")["memory"]
+
+    m_a = encode(fa, True)
+    keep_a = m_a.clone()
+    m_b = encode(fb, True)                       # same slot, same shape: must not overwrite what the caller still holds
+    enc = model.infer_graphs().encode
+    assert enc.captures == 1 and enc.replays >= 2 and enc.eager == 0
+    assert m_a.data_ptr() != m_b.data_ptr() and torch.equal(m_a, keep_a)
+    assert not torch.allclose(m_a, m_b)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    changed = 0
+    for k, v in state.items():
+        if k.startswith("backbone") and (k.endswith("running_mean") or k.endswith("running_var")):
+            state[k] = v * 1.5 + (0.1 if k.endswith("running_mean") else 0.0)
+            changed += 1
+    assert changed > 50
+    ptrs = [p.data_ptr() for p in model.parameters()]
+    model.load_state_dict(state, strict=True)
+    assert ptrs == [p.data_ptr() for p in model.parameters()]          # in place: the fingerprint sees nothing
+    got = encode(fa, True)
+    want = encode(fa, False)
+    assert enc.captures == 2                     # a new capture for the new constants
+    assert not torch.allclose(got, keep_a, atol=1e-3)
+    torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-4)
+
+
 def test_full_size_frame_real_model_default_kernels_vs_oracle_operator(monkeypatch, hip_lib):
     """ONE 800 x 1333 frame through the real model (ResNet-50 + 6 encoder / 6 decoder layers, C = 256 -> D = 32, 300
     queries, train_dancetrack.yaml) forward and backward on the DEFAULT path -- windowed forward, counting-sort
