@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define CLIPOPS_ABI_VERSION 8
+#define CLIPOPS_ABI_VERSION 9
 
 int clipops_abi_version(void);
 const char *clipops_last_error(void);
@@ -144,6 +144,27 @@ int clipops_add_layer_norm_bwd_f32(const float *grad_y, const float *sum, const 
 #define CLIPOPS_ASSIGN_MAX_DIM 2048
 int clipops_assign_f32(const float *cost, long stride_problem, long stride_row, long stride_col, int n_problems,
                        int n_rows, int n_cols, int32_t *row_ind, int32_t *col_ind, int32_t *status, void *stream);
+
+/* ---- the backbone's element-wise tail (round 4, ABI 9) ----
+ * x = relu(x + shift[c] (+ res)) in place on a convolution's output, NCHW contiguous, `planes` = N * C planes of HW
+ * elements; `res` (same shape) may be NULL.  Replaces, in ONE pass, what torchvision's Bottleneck.forward does with a
+ * frozen batch norm folded into the convolution (reference models/backbone.py:70-76, FrozenBatchNorm2d :20-60): the
+ * per-channel bias add, `out += identity` and the ReLU -- three passes over up to 344 MB per layer and clip.  The bf16
+ * form rounds after the bias add and after the residual add like the kernels it replaces.  NaN propagates (x < 0 ? 0 : x). */
+int clipops_shift_relu_f32(float *x, const float *shift, const float *res, long planes, int C, long HW, void *stream);
+int clipops_shift_relu_bf16(uint16_t *x, const float *shift, const uint16_t *res, long planes, int C, long HW,
+                            void *stream);
+
+/* Backward of a query-sized Linear y = x W^T + b (x (rows, in), W (out, in), all contiguous fp32) in one launch:
+ * grad_x (rows, in) = G' W, grad_w (out, in) = G'^T x, grad_b (out) = column sums of G', with G' = grad_y or, when the
+ * forward fused a ReLU (`y_relu` = its output), grad_y masked by y > 0 -- torch.nn.functional.linear's backward as the
+ * reference's decoder / heads / query updater run it a few hundred times per train step on 300-odd rows
+ * (models/deformable_decoder.py, models/mlp.py, models/query_updater.py), where it is four dependent launches.  fp32 MFMA
+ * (exact fp32 products and sums; the contraction order differs from a library GEMM's).  grad_x / grad_w / grad_b may be
+ * NULL (grad_b needs grad_w). */
+int clipops_linear_bwd_f32(const float *grad_y, const float *y_relu, const float *x, const float *w, int rows,
+                           int in_features, int out_features, float *grad_x, float *grad_w, float *grad_b,
+                           void *stream);
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libclip_ops_hip.so")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 c_int, c_long, c_float, c_void_p = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_void_p
 
@@ -45,6 +45,9 @@ SYMBOLS = {
     "clipops_inverse_sigmoid_fwd_f32": ([c_void_p, c_long, c_float, c_void_p, c_void_p], c_int),
     "clipops_inverse_sigmoid_bwd_f32": ([c_void_p, c_void_p, c_long, c_float, c_void_p, c_void_p], c_int),
     "clipops_refine_boxes_fwd_f32": ([c_void_p, c_void_p, c_long, c_float, c_void_p, c_void_p], c_int),
+    "clipops_linear_bwd_f32": ([c_void_p] * 4 + [c_int] * 3 + [c_void_p] * 4, c_int),
+    "clipops_shift_relu_f32": ([c_void_p, c_void_p, c_void_p, c_long, c_int, c_long, c_void_p], c_int),
+    "clipops_shift_relu_bf16": ([c_void_p, c_void_p, c_void_p, c_long, c_int, c_long, c_void_p], c_int),
     "clipops_refine_boxes_bwd_f32": ([c_void_p, c_void_p, c_void_p, c_long, c_float, c_void_p, c_void_p, c_void_p],
                                      c_int),
 }

@@ -788,6 +788,197 @@ int grid_for(long total) {
     return (int)(g > 4096 ? 4096 : g);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Frozen-BN shift + (residual) + ReLU of a ResNet bottleneck in ONE pass over the convolution's output, in place.
+// The backbone (reference models/backbone.py:70-76: torchvision's resnet50 with FrozenBatchNorm2d) does this as three
+// element-wise passes over activations of up to 344 MB each (5 frames x 256 x 200 x 336): conv bias, `out += identity`,
+// ReLU.  NCHW: one (image, channel) plane per blockIdx.y, so the shift is a scalar of the block.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sr_bf16(uint16_t h) { return __uint_as_float((unsigned)h << 16); }
+__device__ __forceinline__ uint16_t sr_to_bf16(float f) {          // round to nearest even (NaN stays NaN)
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+template <bool RES>
+__global__ __launch_bounds__(256) void shift_relu_f32_kernel(float *__restrict__ x, const float *__restrict__ shift,
+                                                             const float *__restrict__ res, long planes, int C, long HW,
+                                                             int vec) {
+    for (long plane = blockIdx.y; plane < planes; plane += gridDim.y) {
+        const float b = shift[plane % C];
+        float *xp = x + plane * HW;
+        const float *rp = RES ? res + plane * HW : nullptr;
+        if (vec) {
+            const long n4 = HW >> 2;
+            for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+                float4 v = reinterpret_cast<float4 *>(xp)[i];
+                if (RES) {
+                    const float4 r = reinterpret_cast<const float4 *>(rp)[i];
+                    v.x = (v.x + b) + r.x; v.y = (v.y + b) + r.y; v.z = (v.z + b) + r.z; v.w = (v.w + b) + r.w;
+                } else {
+                    v.x += b; v.y += b; v.z += b; v.w += b;
+                }
+                // (max(v, 0) would turn NaN into 0; torch's relu keeps it: v < 0 ? 0 : v)
+                v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y;
+                v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w;
+                reinterpret_cast<float4 *>(xp)[i] = v;
+            }
+        } else {
+            for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += (long)gridDim.x * blockDim.x) {
+                float v = xp[i] + b;
+                if (RES) v += rp[i];
+                xp[i] = v < 0.f ? 0.f : v;
+            }
+        }
+    }
+}
+
+// bf16 storage (the autocast step): the bias add and the residual add round to bf16 one after the other, like the two
+// torch kernels they replace
+template <bool RES>
+__global__ __launch_bounds__(256) void shift_relu_bf16_kernel(uint16_t *__restrict__ x, const float *__restrict__ shift,
+                                                              const uint16_t *__restrict__ res, long planes, int C,
+                                                              long HW, int vec) {
+    for (long plane = blockIdx.y; plane < planes; plane += gridDim.y) {
+        const float b = sr_bf16(sr_to_bf16(shift[plane % C]));          // autocast hands the convolution a bf16 bias
+        uint16_t *xp = x + plane * HW;
+        const uint16_t *rp = RES ? res + plane * HW : nullptr;
+        if (vec) {
+            const long n8 = HW >> 3;
+            for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+                uint4 v = reinterpret_cast<uint4 *>(xp)[i];
+                uint4 r = {0u, 0u, 0u, 0u};
+                if (RES) r = reinterpret_cast<const uint4 *>(rp)[i];
+                unsigned *vw = reinterpret_cast<unsigned *>(&v);
+                const unsigned *rw = reinterpret_cast<const unsigned *>(&r);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float lo = sr_bf16((uint16_t)(vw[k] & 0xffffu)) + b, hi = sr_bf16((uint16_t)(vw[k] >> 16)) + b;
+                    if (RES) {
+                        lo = sr_bf16(sr_to_bf16(lo)) + sr_bf16((uint16_t)(rw[k] & 0xffffu));
+                        hi = sr_bf16(sr_to_bf16(hi)) + sr_bf16((uint16_t)(rw[k] >> 16));
+                    }
+                    lo = lo < 0.f ? 0.f : lo;
+                    hi = hi < 0.f ? 0.f : hi;
+                    vw[k] = (unsigned)sr_to_bf16(lo) | ((unsigned)sr_to_bf16(hi) << 16);
+                }
+                reinterpret_cast<uint4 *>(xp)[i] = v;
+            }
+        } else {
+            for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += (long)gridDim.x * blockDim.x) {
+                float v = sr_bf16(xp[i]) + b;
+                if (RES) v = sr_bf16(sr_to_bf16(v)) + sr_bf16(rp[i]);
+                xp[i] = sr_to_bf16(v < 0.f ? 0.f : v);
+            }
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Backward of a query-sized Linear (a few hundred rows) in ONE launch: grad_x = G' W, grad_w = G'^T X, grad_b = colsum G',
+// G' = grad_y (masked by y > 0 when the forward fused a ReLU).  torch issues [threshold_backward,] two GEMMs and a
+// reduction -- four dependent launches of ~5 us each inside the decoder's hipGraphs for ~0.1 GFLOP; the three results
+// depend on the same inputs only, so they are tiles of one grid here.
+//   * one 32 x 32 output tile per workgroup, fp32 MFMA 32x32x2 (bit-for-bit a k-ordered fmaf chain), the contraction
+//     split over the four wavefronts and added up through LDS;
+//   * lane l feeds A[i = l & 31][k] and B[k][j = l & 31] for k = 8 c + 4 (l >> 5) + {0..3}: four MFMAs per 8 k;
+//   * operands straight from global memory (the whole problem sits in L2), zero-filled past the edges.
+// ---------------------------------------------------------------------------------------------------------------
+typedef float lb_f32x16 __attribute__((ext_vector_type(16)));
+
+// One workgroup's tile.  GX: C = G' W (A rows are rows of G: one 16-byte load per lane and chunk when OUT % 4 == 0);
+// else C = G'^T X (A columns are rows of G: coalesced dwords).  LB_U chunks of 8 k are requested before the first MFMA
+// of the group -- without that every chunk waits a memory round trip and the kernel takes 40 us at K = 1024.
+constexpr int LB_U = 4;
+
+template <bool GX, bool RELU>
+__device__ __forceinline__ void linear_bwd_tile(const float *__restrict__ g, const float *__restrict__ y,
+                                                const float *__restrict__ Bp, int M, int N, int K, int OUT, int i0, int j0,
+                                                float *__restrict__ C, float *__restrict__ gb, float (*s_c)[16][64],
+                                                float (*s_b)[32]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = i0 + (lane & 31), j = j0 + (lane & 31), kq = (lane >> 5) * 4;
+    const bool iok = i < M, jok = j < N;
+    const int chunks = (K + 7) / 8, per = (chunks + 3) / 4;
+    const int c_lo = wave * per, c_hi = (c_lo + per) < chunks ? (c_lo + per) : chunks;
+    const bool vec = GX && (OUT % 4 == 0);
+    lb_f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    for (int c = c_lo; c < c_hi; c += LB_U) {
+        float a[LB_U][4], b[LB_U][4], m[LB_U][4];
+#pragma unroll
+        for (int u = 0; u < LB_U; ++u) {
+            const int k0 = (c + u) * 8 + kq;
+            const bool cok = c + u < c_hi;
+            if (vec) {
+                float4 av = {0.f, 0.f, 0.f, 0.f}, mv = {1.f, 1.f, 1.f, 1.f};
+                if (cok && iok && k0 < K) {          // (K = OUT is a multiple of 4 and k0 one too: all four or none)
+                    av = *reinterpret_cast<const float4 *>(g + (long)i * OUT + k0);
+                    if (RELU) mv = *reinterpret_cast<const float4 *>(y + (long)i * OUT + k0);
+                }
+                a[u][0] = av.x; a[u][1] = av.y; a[u][2] = av.z; a[u][3] = av.w;
+                m[u][0] = mv.x; m[u][1] = mv.y; m[u][2] = mv.z; m[u][3] = mv.w;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = k0 + q;
+                const bool kok = cok && k < K;
+                if (!vec) {
+                    const long idx = GX ? (long)i * OUT + k : (long)k * OUT + i;
+                    a[u][q] = (iok && kok) ? g[idx] : 0.f;
+                    m[u][q] = (RELU && iok && kok) ? y[idx] : 1.f;
+                }
+                b[u][q] = (jok && kok) ? Bp[(long)k * N + j] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < LB_U; ++u) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float av = RELU ? (m[u][q] > 0.f ? a[u][q] : 0.f) : a[u][q];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[u][q], acc, 0, 0, 0);
+                bsum += av;
+            }
+        }
+    }
+    // add the four partial tiles (and bias sums) up; wavefront v finishes accumulator registers 4v .. 4v + 3
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s_c[wave][r][lane] = acc[r];
+    bsum += __shfl_xor(bsum, 32, 64);
+    if (lane < 32) s_b[wave][lane] = bsum;
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int r = wave * 4 + rr;
+        const float v = (s_c[0][r][lane] + s_c[1][r][lane]) + (s_c[2][r][lane] + s_c[3][r][lane]);
+        const int row = i0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < M && jok) C[(long)row * N + j] = v;
+    }
+    if (!GX && gb != nullptr && j0 == 0 && wave == 0 && lane < 32 && i0 + lane < M)
+        gb[i0 + lane] = (s_b[0][lane] + s_b[1][lane]) + (s_b[2][lane] + s_b[3][lane]);
+}
+
+template <bool RELU>
+__global__ __launch_bounds__(256) void linear_bwd_kernel(const float *__restrict__ g, const float *__restrict__ y,
+                                                         const float *__restrict__ x, const float *__restrict__ w,
+                                                         int R, int IN, int OUT, float *__restrict__ gx,
+                                                         float *__restrict__ gw, float *__restrict__ gb, int n_gx,
+                                                         int gx_tj, int gw_tj) {
+    __shared__ float s_c[4][16][64];
+    __shared__ float s_b[4][32];
+    const int tile = blockIdx.x;
+    // C (M x N) = A (M x K) B (K x N):   gx: A = G' (R x OUT), B = W (OUT x IN)     gw: A = G'^T (OUT x R), B = X (R x IN)
+    if (tile < n_gx) {
+        linear_bwd_tile<true, RELU>(g, y, w, R, IN, OUT, OUT, (tile / gx_tj) * 32, (tile % gx_tj) * 32, gx, nullptr, s_c, s_b);
+    } else {
+        const int t = tile - n_gx;
+        linear_bwd_tile<false, RELU>(g, y, x, OUT, IN, R, OUT, (t / gw_tj) * 32, (t % gw_tj) * 32, gw, gb, s_c, s_b);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -1033,6 +1224,59 @@ int clipops_assign_f32(const float *cost, long stride_problem, long stride_row, 
     hipLaunchKernelGGL(assign_kernel, dim3(n_problems), dim3(64), lds, (hipStream_t)stream, cost, stride_problem,
                        stride_row, stride_col, n_rows, n_cols, row_ind, col_ind, status);
     return check_launch("assign_kernel");
+}
+
+static int shift_relu_check(const void *x, const void *shift, long planes, int C, long HW, const char *who) {
+    if (planes < 0 || C <= 0 || HW < 0) return fail(1, who);
+    if (planes && HW && (!x || !shift)) return fail(1, who);
+    return 0;
+}
+
+int clipops_shift_relu_f32(float *x, const float *shift, const float *res, long planes, int C, long HW, void *stream) {
+    if (shift_relu_check(x, shift, planes, C, HW, "clipops_shift_relu_f32: bad argument")) return 1;
+    if (planes == 0 || HW == 0) { g_err[0] = 0; return 0; }
+    const int vec = (HW % 4 == 0) && ((uintptr_t)x % 16 == 0) && (!res || (uintptr_t)res % 16 == 0);
+    const long per = vec ? HW / 4 : HW;
+    const dim3 grid((unsigned)((per + 1023) / 1024 > 64 ? 64 : (per + 1023) / 1024 < 1 ? 1 : (per + 1023) / 1024),
+                    (unsigned)(planes > 65535 ? 65535 : planes));
+    if (res) hipLaunchKernelGGL(shift_relu_f32_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, shift, res, planes, C, HW, vec);
+    else hipLaunchKernelGGL(shift_relu_f32_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, shift, res, planes, C, HW, vec);
+    return check_launch("shift_relu_f32_kernel");
+}
+
+int clipops_shift_relu_bf16(uint16_t *x, const float *shift, const uint16_t *res, long planes, int C, long HW, void *stream) {
+    if (shift_relu_check(x, shift, planes, C, HW, "clipops_shift_relu_bf16: bad argument")) return 1;
+    if (planes == 0 || HW == 0) { g_err[0] = 0; return 0; }
+    const int vec = (HW % 8 == 0) && ((uintptr_t)x % 16 == 0) && (!res || (uintptr_t)res % 16 == 0);
+    const long per = vec ? HW / 8 : HW;
+    const dim3 grid((unsigned)((per + 1023) / 1024 > 64 ? 64 : (per + 1023) / 1024 < 1 ? 1 : (per + 1023) / 1024),
+                    (unsigned)(planes > 65535 ? 65535 : planes));
+    if (res) hipLaunchKernelGGL(shift_relu_bf16_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, shift, res, planes, C, HW, vec);
+    else hipLaunchKernelGGL(shift_relu_bf16_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, shift, res, planes, C, HW, vec);
+    return check_launch("shift_relu_bf16_kernel");
+}
+
+int clipops_linear_bwd_f32(const float *grad_y, const float *y_relu, const float *x, const float *w, int rows,
+                           int in_features, int out_features, float *grad_x, float *grad_w, float *grad_b,
+                           void *stream) {
+    if (rows < 0 || in_features <= 0 || out_features <= 0) return fail(1, "clipops_linear_bwd_f32: bad dimension");
+    if (!grad_y || !x || !w) return fail(1, "clipops_linear_bwd_f32: null pointer");
+    if (grad_b && !grad_w) return fail(1, "clipops_linear_bwd_f32: grad_b is computed with grad_w");
+    const int gx_ti = (rows + 31) / 32, gx_tj = (in_features + 31) / 32;
+    const int gw_ti = (out_features + 31) / 32, gw_tj = gx_tj;
+    const int n_gx = grad_x ? gx_ti * gx_tj : 0, n_gw = grad_w ? gw_ti * gw_tj : 0;
+    if (n_gx + n_gw == 0) { g_err[0] = 0; return 0; }
+    if (rows == 0) {          // nothing to contract over: the weight and bias gradients are zero
+        if (grad_w && hipMemsetAsync(grad_w, 0, sizeof(float) * (size_t)out_features * in_features, (hipStream_t)stream) != hipSuccess)
+            return fail(3, "clipops_linear_bwd_f32: memset failed");
+        if (grad_b && hipMemsetAsync(grad_b, 0, sizeof(float) * (size_t)out_features, (hipStream_t)stream) != hipSuccess)
+            return fail(3, "clipops_linear_bwd_f32: memset failed");
+        g_err[0] = 0;
+        return 0;
+    }
+    if (y_relu) hipLaunchKernelGGL(linear_bwd_kernel<true>, dim3(n_gx + n_gw), dim3(256), 0, (hipStream_t)stream, grad_y, y_relu, x, w, rows, in_features, out_features, grad_x, grad_w, grad_b, n_gx, gx_tj, gw_tj);
+    else hipLaunchKernelGGL(linear_bwd_kernel<false>, dim3(n_gx + n_gw), dim3(256), 0, (hipStream_t)stream, grad_y, y_relu, x, w, rows, in_features, out_features, grad_x, grad_w, grad_b, n_gx, gx_tj, gw_tj);
+    return check_launch("linear_bwd_kernel");
 }
 
 }  // extern "C"

@@ -21,7 +21,8 @@ def fused(*tensors) -> bool:
 def config_key() -> tuple:
     """The environment switches that change which kernels a captured graph contains."""
     return (os.environ.get("MEMOTR_FUSED_CLIP_OPS", "1"), os.environ.get("MEMOTR_COLSUM_TALL", "1"),
-            os.environ.get("MEMOTR_ATTN_KERNELS", "1"), os.environ.get("MEMOTR_FUSED_LN", "1"))
+            os.environ.get("MEMOTR_ATTN_KERNELS", "1"), os.environ.get("MEMOTR_FUSED_LN", "1"),
+            os.environ.get("MEMOTR_FUSED_SHIFT_RELU", "1"), os.environ.get("MEMOTR_FUSED_LINEAR_BWD", "1"))
 
 
 def _lib():
@@ -350,6 +351,90 @@ def add_row_bias(x: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
     if x.is_cuda and bias.requires_grad and torch.is_grad_enabled() and bias.dim() == 1:
         return _AddRowBias.apply(x, bias)
     return x + bias
+
+
+# --------------------------------------------------------------------------------------------------------------
+# backward of a query-sized Linear in one launch (include/clip_ops_hip.h: clipops_linear_bwd_f32)
+# --------------------------------------------------------------------------------------------------------------
+LINEAR_BWD_MAX_ROWS = 1024          # beyond a few hundred rows the library GEMMs win
+LINEAR_BWD_MAX_OUT = 512            # ... and for wide outputs too: 32 x 32 tiles re-read their operands from L2 (measured
+                                    # inside a graph at 320 rows, tools/linear_bwd_probe.py: 256 -> 256: 6.5 vs 14.5 us for
+                                    # the chain, with ReLU 10.5 vs 18.4; 256 -> 768: 12.7 vs 11.5; 256 -> 1024: 18.4 vs 17.9)
+
+
+def linear_bwd_usable(g2: torch.Tensor, x2: torch.Tensor, weight: torch.Tensor) -> bool:
+    return (os.environ.get("MEMOTR_FUSED_LINEAR_BWD", "1") != "0" and fused(g2, x2, weight)
+            and g2.dtype == torch.float32 and x2.dtype == torch.float32 and weight.dtype == torch.float32
+            and 0 < g2.shape[0] <= LINEAR_BWD_MAX_ROWS and g2.shape[1] <= LINEAR_BWD_MAX_OUT
+            and x2.is_contiguous() and weight.is_contiguous())
+
+
+def linear_bwd(g2: torch.Tensor, y_relu, x2: torch.Tensor, weight: torch.Tensor, need_x=True, need_w=True, need_b=True):
+    """(grad_x, grad_w, grad_b) of y = x2 @ weight.T + b for g2 = d/dy (rows, out); ``y_relu``: the forward's output
+    when it applied a ReLU (the mask y > 0 is then part of the kernel)."""
+    g2 = g2.contiguous()
+    rows, out_f = g2.shape
+    in_f = x2.shape[1]
+    need_w = need_w or need_b
+    gx = torch.empty((rows, in_f), dtype=torch.float32, device=g2.device) if need_x else None
+    gw = torch.empty((out_f, in_f), dtype=torch.float32, device=g2.device) if need_w else None
+    gb = torch.empty((out_f,), dtype=torch.float32, device=g2.device) if need_b else None
+    L_ = _lib()
+    L_.check(L_.lib.clipops_linear_bwd_f32(g2.data_ptr(), None if y_relu is None else y_relu.data_ptr(), x2.data_ptr(),
+                                           weight.data_ptr(), rows, in_f, out_f,
+                                           None if gx is None else gx.data_ptr(), None if gw is None else gw.data_ptr(),
+                                           None if gb is None else gb.data_ptr(), _stream(g2)), "clipops_linear_bwd_f32")
+    return gx, gw, gb
+
+
+def linear_bwd_reference(g2, y_relu, x2, weight):
+    if y_relu is not None:
+        g2 = g2 * (y_relu > 0).to(g2.dtype)
+    return g2 @ weight, g2.t() @ x2, g2.sum(0)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# the backbone's element-wise tail: frozen-BN shift (+ residual) + ReLU in one pass (include/clip_ops_hip.h, ABI 9)
+# --------------------------------------------------------------------------------------------------------------
+class _ShiftRelu(torch.autograd.Function):
+    """y = relu(x + shift[None, :, None, None] (+ res)), written over ``x`` (a convolution's fresh output)."""
+
+    @staticmethod
+    def forward(ctx, x, shift, res):
+        N, C, H, W = x.shape
+        L_ = _lib()
+        fn = L_.lib.clipops_shift_relu_bf16 if x.dtype == torch.bfloat16 else L_.lib.clipops_shift_relu_f32
+        L_.check(fn(x.data_ptr(), shift.data_ptr(), None if res is None else res.data_ptr(), N * C, C, H * W,
+                    _stream(x)), "clipops_shift_relu")
+        ctx.mark_dirty(x)
+        ctx.save_for_backward(x)
+        ctx.has_res = res is not None
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        gx = torch.ops.aten.threshold_backward(g, y, 0)      # (the ReLU's own backward kernel; the shift is a constant)
+        return gx, None, (gx if ctx.has_res else None)
+
+
+def shift_relu_reference(x: torch.Tensor, shift: torch.Tensor, res: torch.Tensor = None) -> torch.Tensor:
+    y = x + shift.to(x.dtype)[None, :, None, None]
+    if res is not None:
+        y = y + res
+    return F.relu(y)
+
+
+def shift_relu_(x: torch.Tensor, shift: torch.Tensor, res: torch.Tensor = None) -> torch.Tensor:
+    """relu(x + per-channel shift (+ res)) over an NCHW tensor; in place on CUDA fp32 / bf16 (``x`` must be a tensor
+    nothing else reads: the output of the convolution in front), the element-wise torch chain elsewhere."""
+    ok = (os.environ.get("MEMOTR_FUSED_CLIP_OPS", "1") != "0" and os.environ.get("MEMOTR_FUSED_SHIFT_RELU", "1") != "0"
+          and x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16) and x.is_contiguous()
+          and not x._is_view() and shift.dtype == torch.float32 and shift.is_contiguous() and not shift.requires_grad
+          and (res is None or (res.dtype == x.dtype and res.shape == x.shape and res.is_contiguous())))
+    if not ok:
+        return shift_relu_reference(x, shift, res)
+    return _ShiftRelu.apply(x, shift, res)
 
 
 # --------------------------------------------------------------------------------------------------------------

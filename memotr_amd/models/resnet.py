@@ -29,12 +29,20 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        identity = x if self.downsample is None else _conv_norm(self.downsample[0], self.downsample[1], x)
-        out = F.relu(_conv_norm(self.conv1, self.bn1, x), inplace=True)
-        out = F.relu(_conv_norm(self.conv2, self.bn2, out), inplace=True)
-        out = _conv_norm(self.conv3, self.bn3, out)
-        out += identity
-        return F.relu(out, inplace=True)
+        extra = None
+        if self.downsample is None:
+            identity = x
+        else:
+            fold = getattr(self.downsample[1], "fold_into_conv", None)
+            if fold is not None and x.is_cuda:     # the projection's own shift rides in the block's last pass
+                ds = self.downsample[0]
+                w, extra = fold(ds.weight)
+                identity = F.conv2d(x, w, None, ds.stride, ds.padding, ds.dilation, ds.groups)
+            else:
+                identity = _conv_norm(self.downsample[0], self.downsample[1], x)
+        out = _conv_norm_relu(self.conv1, self.bn1, x)
+        out = _conv_norm_relu(self.conv2, self.bn2, out)
+        return _conv_norm_relu(self.conv3, self.bn3, out, identity, extra)   # relu(bn3(conv3) + identity)
 
 
 def _conv_norm(conv: nn.Conv2d, norm: nn.Module, x: torch.Tensor) -> torch.Tensor:
@@ -45,6 +53,29 @@ def _conv_norm(conv: nn.Conv2d, norm: nn.Module, x: torch.Tensor) -> torch.Tenso
         w, b = fold(conv.weight)
         return F.conv2d(x, w, b, conv.stride, conv.padding, conv.dilation, conv.groups)
     return norm(conv(x))
+
+
+def _conv_norm_relu(conv: nn.Conv2d, norm: nn.Module, x: torch.Tensor, res: torch.Tensor = None,
+                    extra_shift: torch.Tensor = None) -> torch.Tensor:
+    """relu(norm(conv(x)) (+ res)).  With a frozen norm folded into the convolution the shift, the residual and the
+    ReLU are ONE pass over the convolution's output (functions/clip_ops.shift_relu_) instead of three -- these
+    activations are the largest tensors of the step (344 MB for layer1's outputs of a 5-frame clip)."""
+    fold = getattr(norm, "fold_into_conv", None)
+    if fold is not None:
+        w, b = fold(conv.weight)
+        if extra_shift is not None:            # (`res` came without its own shift: Bottleneck.forward)
+            b = b + extra_shift
+        if x.is_cuda and not b.requires_grad:
+            from ..functions.clip_ops import shift_relu_
+            return shift_relu_(F.conv2d(x, w, None, conv.stride, conv.padding, conv.dilation, conv.groups), b, res)
+        out = F.conv2d(x, w, b, conv.stride, conv.padding, conv.dilation, conv.groups)
+    else:
+        out = norm(conv(x))
+        if extra_shift is not None:
+            out = out + extra_shift.view(1, -1, 1, 1)
+    if res is not None:
+        out = out + res
+    return F.relu(out, inplace=True)
 
 
 class ResNet50Body(nn.Module):
@@ -79,7 +110,7 @@ class ResNet50Body(nn.Module):
         return nn.Sequential(*layers)
 
     def forward(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
-        x = F.relu(_conv_norm(self.conv1, self.bn1, x), inplace=True)
+        x = _conv_norm_relu(self.conv1, self.bn1, x)
         x = self.maxpool(x)
         out = {}
         for name in ("layer1", "layer2", "layer3", "layer4"):

@@ -150,6 +150,12 @@ class _RowLinear(torch.autograd.Function):
     def backward(ctx, grad_out):
         from ..functions import clip_ops
         g2 = grad_out.reshape(-1, grad_out.shape[-1])
+        if clip_ops.linear_bwd_usable(g2, ctx.saved_tensors[0], ctx.saved_tensors[1]):
+            # [ReLU mask,] grad_x, grad_w and grad_b in ONE launch (include/clip_ops_hip.h: clipops_linear_bwd_f32)
+            x2, weight = ctx.saved_tensors[0], ctx.saved_tensors[1]
+            gx, gw, gb = clip_ops.linear_bwd(g2, ctx.saved_tensors[2] if ctx.relu else None, x2, weight,
+                                             ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2])
+            return (None if gx is None else gx.view(ctx.x_shape)), gw, gb, None
         if ctx.relu:
             x2, weight, y = ctx.saved_tensors
             g2 = torch.ops.aten.threshold_backward(g2, y, 0.0)                     # the ReLU mask

@@ -392,3 +392,83 @@ def test_device_assignment_batches_the_layers_of_a_frame_and_flags_infeasible_co
     wr, wc = linear_sum_assignment(wide[0].cpu().numpy())
     assert st.tolist() == [1700]
     assert np.array_equal(r[0].cpu().numpy(), wr) and np.array_equal(c[0].cpu().numpy(), wc)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 16, 20, 24), (3, 8, 25, 42), (1, 5, 7, 3)], ids=["vec", "hw1050", "tiny"])
+@pytest.mark.parametrize("with_res", [False, True], ids=["plain", "residual"])
+def test_shift_relu_is_the_three_pass_chain_in_one(dtype, shape, with_res):
+    """relu(conv_out + shift[c] (+ identity)) -- the frozen-BN bias add, the residual add and the ReLU of a ResNet
+    bottleneck (torchvision Bottleneck.forward behind models/backbone.py:70-76 of the reference) -- in one kernel, in
+    place: bit-equal to the torch chain in fp32 and bf16 (same rounding points), NaN kept, gradients those of the chain."""
+    from memotr_amd.functions import clip_ops
+    g = torch.Generator().manual_seed(sum(shape) + with_res)
+    x0 = torch.randn(*shape, generator=g).to(dtype).cuda()
+    x0[0, 0, 0, 0] = float("nan")
+    shift = torch.randn(shape[1], generator=g).cuda()
+    res0 = torch.randn(*shape, generator=g).to(dtype).cuda() if with_res else None
+
+    def chain(x, res):      # what torch runs: conv bias add (bias cast by autocast for bf16), `+= identity`, relu
+        y = x + shift.to(dtype)[None, :, None, None]
+        if res is not None:
+            y = y + res
+        return torch.relu(y)
+
+    xa = x0.clone().requires_grad_(True)
+    ra = res0.clone().requires_grad_(True) if with_res else None
+    want = chain(xa, ra)
+    xb = x0.clone().requires_grad_(True)
+    rb = res0.clone().requires_grad_(True) if with_res else None
+    got = clip_ops.shift_relu_(xb * 1, shift, rb)        # (`* 1`: a fresh non-leaf tensor, like a convolution's output)
+    assert torch.equal(torch.isnan(got), torch.isnan(want)) and bool(torch.isnan(got[0, 0, 0, 0]))
+    assert torch.equal(torch.nan_to_num(got), torch.nan_to_num(want))
+    go = torch.randn(*shape, generator=g).to(dtype).cuda()
+    want.backward(go)
+    got.backward(go)
+    assert torch.equal(torch.nan_to_num(xa.grad), torch.nan_to_num(xb.grad))
+    if with_res:
+        assert torch.equal(torch.nan_to_num(ra.grad), torch.nan_to_num(rb.grad))
+
+
+@pytest.mark.parametrize("rows,in_f,out_f", [(320, 256, 256), (310, 512, 256), (320, 256, 4), (10, 256, 512), (33, 40, 70),
+                                             (1, 256, 256), (1024, 256, 384), (320, 1024, 256)])
+@pytest.mark.parametrize("relu", [False, True], ids=["linear", "relu"])
+def test_linear_backward_in_one_launch(rows, in_f, out_f, relu):
+    """grad_x = G' W, grad_w = G'^T x, grad_b = colsum G' (G' = grad_y masked by y > 0 behind a fused ReLU): the backward
+    of torch.nn.functional.linear on the decoder's query-sized linears, against float64 products of the same fp32
+    inputs -- fp32 MFMA is an fmaf chain, so the error is fp32 round-off of a K-term sum."""
+    from memotr_amd.functions import clip_ops
+    g = torch.Generator().manual_seed(rows * 7 + in_f + out_f + relu)
+    x = torch.randn(rows, in_f, generator=g).cuda()
+    w = (torch.randn(out_f, in_f, generator=g) / in_f ** 0.5).cuda()
+    b = torch.randn(out_f, generator=g).cuda()
+    gy = torch.randn(rows, out_f, generator=g).cuda()
+    y = torch.relu(x @ w.t() + b) if relu else None
+    assert clip_ops.linear_bwd_usable(gy, x, w)
+    gx, gw, gb = clip_ops.linear_bwd(gy, y, x, w)
+    gm = gy.double() * ((y > 0).double() if relu else 1.0)
+    wx, ww, wb = gm @ w.double(), gm.t() @ x.double(), gm.sum(0)
+    for got, want, k in ((gx, wx, out_f), (gw, ww, rows), (gb, wb, rows)):
+        scale = float(want.abs().max()) + 1e-6
+        assert float((got.double() - want).abs().max()) <= 4e-7 * k ** 0.5 * scale + 1e-6, (rows, in_f, out_f)
+    # the parts a caller does not need are not computed
+    only_w = clip_ops.linear_bwd(gy, y, x, w, need_x=False, need_w=True, need_b=False)
+    assert only_w[0] is None and only_w[2] is None and torch.equal(only_w[1], gw)
+
+
+def test_row_linear_backward_uses_the_fused_kernel_and_matches_autograd(monkeypatch):
+    from memotr_amd.modules.linear import row_linear
+    g = torch.Generator().manual_seed(12)
+    x0 = torch.randn(2, 160, 256, generator=g).cuda()
+    lin = torch.nn.Linear(256, 256).cuda()
+    go = torch.randn(2, 160, 256, generator=g).cuda()
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MEMOTR_FUSED_LINEAR_BWD", flag)
+        x = x0.clone().requires_grad_(True)
+        lin.zero_grad()
+        y = row_linear(x, lin.weight, lin.bias, relu=True)
+        y.backward(go)
+        outs.append((x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone()))
+    for a, b in zip(*outs):
+        torch.testing.assert_close(a, b, rtol=2e-5, atol=2e-5)
