@@ -166,6 +166,11 @@ int clipops_linear_bwd_f32(const float *grad_y, const float *y_relu, const float
                            int in_features, int out_features, float *grad_x, float *grad_w, float *grad_b,
                            void *stream);
 
+/* ... and its forward, y (rows, out) = [relu](x W^T + b) (`bias` may be NULL; in_features a multiple of 4): the same
+ * 32 x 32 MFMA tiles with both operands read as 16-byte loads along the contraction. */
+int clipops_linear_fwd_f32(const float *x, const float *w, const float *bias, int rows, int in_features,
+                           int out_features, int relu, float *y, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -979,6 +979,51 @@ __global__ __launch_bounds__(256) void linear_bwd_kernel(const float *__restrict
     }
 }
 
+// Forward of the same linears: y = [relu](x W^T + b), one 32 x 32 tile per workgroup.  Both operands are contiguous
+// along the contraction (x rows, W rows), so a lane's four k of a chunk are ONE 16-byte load each.
+template <bool RELU>
+__global__ __launch_bounds__(256) void linear_fwd_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                         const float *__restrict__ bias, int R, int IN, int OUT,
+                                                         float *__restrict__ yout, int tj) {
+    __shared__ float s_c[4][16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i0 = (blockIdx.x / tj) * 32, j0 = (blockIdx.x % tj) * 32;
+    const int i = i0 + (lane & 31), j = j0 + (lane & 31), kq = (lane >> 5) * 4;
+    const bool iok = i < R, jok = j < OUT;
+    const int chunks = (IN + 7) / 8, per = (chunks + 3) / 4;
+    const int c_lo = wave * per, c_hi = (c_lo + per) < chunks ? (c_lo + per) : chunks;
+    lb_f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int c = c_lo; c < c_hi; c += LB_U) {
+        float4 a[LB_U], b[LB_U];
+#pragma unroll
+        for (int u = 0; u < LB_U; ++u) {
+            const int k0 = (c + u) * 8 + kq;
+            const bool kok = c + u < c_hi && k0 < IN;          // (IN is a multiple of 4: the launcher checks)
+            a[u] = (iok && kok) ? *reinterpret_cast<const float4 *>(x + (long)i * IN + k0) : float4{0.f, 0.f, 0.f, 0.f};
+            b[u] = (jok && kok) ? *reinterpret_cast<const float4 *>(w + (long)j * IN + k0) : float4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < LB_U; ++u) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, b[u].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, b[u].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].z, b[u].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].w, b[u].w, acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s_c[wave][r][lane] = acc[r];
+    __syncthreads();
+    const float bj = (bias != nullptr && jok) ? bias[j] : 0.f;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int r = wave * 4 + rr;
+        float v = ((s_c[0][r][lane] + s_c[1][r][lane]) + (s_c[2][r][lane] + s_c[3][r][lane])) + bj;
+        if (RELU) v = v < 0.f ? 0.f : v;
+        const int row = i0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < R && jok) yout[(long)row * OUT + j] = v;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -1277,6 +1322,18 @@ int clipops_linear_bwd_f32(const float *grad_y, const float *y_relu, const float
     if (y_relu) hipLaunchKernelGGL(linear_bwd_kernel<true>, dim3(n_gx + n_gw), dim3(256), 0, (hipStream_t)stream, grad_y, y_relu, x, w, rows, in_features, out_features, grad_x, grad_w, grad_b, n_gx, gx_tj, gw_tj);
     else hipLaunchKernelGGL(linear_bwd_kernel<false>, dim3(n_gx + n_gw), dim3(256), 0, (hipStream_t)stream, grad_y, y_relu, x, w, rows, in_features, out_features, grad_x, grad_w, grad_b, n_gx, gx_tj, gw_tj);
     return check_launch("linear_bwd_kernel");
+}
+
+int clipops_linear_fwd_f32(const float *x, const float *w, const float *bias, int rows, int in_features,
+                           int out_features, int relu, float *y, void *stream) {
+    if (rows < 0 || in_features <= 0 || out_features <= 0) return fail(1, "clipops_linear_fwd_f32: bad dimension");
+    if (in_features % 4) return fail(2, "clipops_linear_fwd_f32: in_features must be a multiple of 4");
+    if (rows == 0) { g_err[0] = 0; return 0; }
+    if (!x || !w || !y) return fail(1, "clipops_linear_fwd_f32: null pointer");
+    const int ti = (rows + 31) / 32, tj = (out_features + 31) / 32;
+    if (relu) hipLaunchKernelGGL(linear_fwd_kernel<true>, dim3(ti * tj), dim3(256), 0, (hipStream_t)stream, x, w, bias, rows, in_features, out_features, y, tj);
+    else hipLaunchKernelGGL(linear_fwd_kernel<false>, dim3(ti * tj), dim3(256), 0, (hipStream_t)stream, x, w, bias, rows, in_features, out_features, y, tj);
+    return check_launch("linear_fwd_kernel");
 }
 
 }  // extern "C"

@@ -135,9 +135,13 @@ class _RowLinear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, relu):
+        from ..functions import clip_ops
         x2 = x.reshape(-1, x.shape[-1])
         ctx.relu = bool(relu)
-        if ctx.relu:
+        if clip_ops.linear_fwd_usable(x2, weight, bias):
+            y = clip_ops.linear_fwd(x2, weight, bias, ctx.relu)                    # one MFMA launch (clip_ops ABI 9)
+            ctx.save_for_backward(*((x2, weight, y) if ctx.relu else (x2, weight)))
+        elif ctx.relu:
             y = torch._addmm_activation(bias, x2, weight.t(), use_gelu=False)      # relu(x W^T + b), one kernel
             ctx.save_for_backward(x2, weight, y)
         else:

@@ -472,3 +472,22 @@ def test_row_linear_backward_uses_the_fused_kernel_and_matches_autograd(monkeypa
         outs.append((x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone()))
     for a, b in zip(*outs):
         torch.testing.assert_close(a, b, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("rows,in_f,out_f", [(320, 256, 256), (310, 512, 256), (320, 256, 4), (10, 1024, 512), (33, 40, 70)])
+@pytest.mark.parametrize("relu", [False, True], ids=["linear", "relu"])
+def test_linear_forward_tile_kernel(rows, in_f, out_f, relu, monkeypatch):
+    from memotr_amd.functions import clip_ops
+    monkeypatch.setattr(clip_ops, "LINEAR_FWD_MAX_IN", 4096)       # (the kernel itself, beyond the shapes the model gives it)
+    g = torch.Generator().manual_seed(rows + in_f + out_f)
+    x = torch.randn(rows, in_f, generator=g).cuda()
+    w = (torch.randn(out_f, in_f, generator=g) / in_f ** 0.5).cuda()
+    b = torch.randn(out_f, generator=g).cuda()
+    assert clip_ops.linear_fwd_usable(x, w, b)
+    got = clip_ops.linear_fwd(x, w, b, relu)
+    want = x.double() @ w.double().t() + b.double()
+    if relu:
+        want = torch.relu(want)
+    assert float((got.double() - want).abs().max()) <= 4e-7 * in_f ** 0.5 * (float(want.abs().max()) + 1.0)
+    if relu:
+        assert float(got.min()) >= 0.0

@@ -63,12 +63,24 @@ def main():
         def one():
             return clip_ops.linear_bwd(gy, y, x, w)
 
+        bias = torch.randn(out_f, device="cuda")
+
+        def lib_fwd():
+            return torch._addmm_activation(bias, x, w.t(), use_gelu=False) if relu else torch.addmm(bias, x, w.t())
+
+        def one_fwd():
+            return clip_ops.linear_fwd(x, w, bias, relu)
+
+        gf, reps_f = graphed(lib_fwd)
+        gof, _ = graphed(one_fwd)
+        fwd_line = (f"   ||  forward: library {timed(lib_fwd):5.1f} us  tile kernel {timed(one_fwd):5.1f} us  | in a graph "
+                    f"{timed(gf, 50) / reps_f:5.1f} vs {timed(gof, 50) / reps_f:5.1f} us") if in_f % 4 == 0 else ""
         t_chain, t_one = timed(chain), timed(one)
         gc, reps = graphed(chain)
         go, _ = graphed(one)
         tg_chain, tg_one = timed(gc, 50) / reps, timed(go, 50) / reps
         lines.append(f"rows {rows:4d} in {in_f:4d} out {out_f:4d} relu {int(relu)}:  eager chain {t_chain:6.1f} us  one launch "
-                     f"{t_one:6.1f} us   |  inside a graph: chain {tg_chain:6.1f} us  one launch {tg_one:6.1f} us")
+                     f"{t_one:6.1f} us   |  inside a graph: chain {tg_chain:6.1f} us  one launch {tg_one:6.1f} us" + fwd_line)
     os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
     open(out, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
