@@ -370,16 +370,20 @@ def linear_bwd_usable(g2: torch.Tensor, x2: torch.Tensor, weight: torch.Tensor) 
             and x2.is_contiguous() and weight.is_contiguous())
 
 
-def linear_bwd(g2: torch.Tensor, y_relu, x2: torch.Tensor, weight: torch.Tensor, need_x=True, need_w=True, need_b=True):
+def linear_bwd(g2: torch.Tensor, y_relu, x2: torch.Tensor, weight: torch.Tensor, need_x=True, need_w=True, need_b=True,
+               gw_out: torch.Tensor = None, gb_out: torch.Tensor = None):
     """(grad_x, grad_w, grad_b) of y = x2 @ weight.T + b for g2 = d/dy (rows, out); ``y_relu``: the forward's output
-    when it applied a ReLU (the mask y > 0 is then part of the kernel)."""
+    when it applied a ReLU (the mask y > 0 is then part of the kernel).  ``gw_out`` / ``gb_out``: contiguous buffers
+    to write into (row slices of a packed parameter's gradient)."""
     g2 = g2.contiguous()
     rows, out_f = g2.shape
     in_f = x2.shape[1]
     need_w = need_w or need_b
     gx = torch.empty((rows, in_f), dtype=torch.float32, device=g2.device) if need_x else None
-    gw = torch.empty((out_f, in_f), dtype=torch.float32, device=g2.device) if need_w else None
-    gb = torch.empty((out_f,), dtype=torch.float32, device=g2.device) if need_b else None
+    gw = (gw_out if gw_out is not None else torch.empty((out_f, in_f), dtype=torch.float32, device=g2.device)) if need_w else None
+    gb = (gb_out if gb_out is not None else torch.empty((out_f,), dtype=torch.float32, device=g2.device)) if need_b else None
+    assert gw is None or (gw.is_contiguous() and gw.shape == (out_f, in_f)), "gw_out must be a contiguous (out, in) buffer"
+    assert gb is None or (gb.is_contiguous() and gb.shape == (out_f,)), "gb_out must be a contiguous (out,) buffer"
     L_ = _lib()
     L_.check(L_.lib.clipops_linear_bwd_f32(g2.data_ptr(), None if y_relu is None else y_relu.data_ptr(), x2.data_ptr(),
                                            weight.data_ptr(), rows, in_f, out_f,

@@ -39,9 +39,18 @@ class _PackedInProj(torch.autograd.Function):
         E = w.shape[1]
         g_qk2, g_v2 = g_qk.reshape(-1, 2 * E), g_v.reshape(-1, E)
         gw, gb = torch.empty_like(w), torch.empty((3 * E,), dtype=w.dtype, device=w.device)
+        from ..functions import clip_ops
+        if clip_ops.linear_bwd_usable(g_qk2, qk2, w[:2 * E]) and clip_ops.linear_bwd_usable(g_v2, v2, w[2 * E:]):
+            # two launches (clipops_linear_bwd_f32) straight into the packed gradient's row slices instead of four
+            # GEMMs and two column sums
+            g_in_qk = clip_ops.linear_bwd(g_qk2, None, qk2, w[:2 * E], ctx.needs_input_grad[0], True, True,
+                                          gw_out=gw[:2 * E], gb_out=gb[:2 * E])[0]
+            g_in_v = clip_ops.linear_bwd(g_v2, None, v2, w[2 * E:], ctx.needs_input_grad[1], True, True,
+                                         gw_out=gw[2 * E:], gb_out=gb[2 * E:])[0]
+            return (None if g_in_qk is None else g_in_qk.view(ctx.shapes[0]),
+                    None if g_in_v is None else g_in_v.view(ctx.shapes[1]), gw, gb)
         torch.mm(g_qk2.t(), qk2, out=gw[:2 * E])
         torch.mm(g_v2.t(), v2, out=gw[2 * E:])
-        from ..functions import clip_ops
         clip_ops.colsum(g_qk2.contiguous(), out=gb[:2 * E])          # (tiled kernel for query-sized inputs)
         clip_ops.colsum(g_v2.contiguous(), out=gb[2 * E:])
         g_in_qk = (g_qk2 @ w[:2 * E]).view(ctx.shapes[0]) if ctx.needs_input_grad[0] else None

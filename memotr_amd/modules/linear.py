@@ -154,17 +154,15 @@ class _RowLinear(torch.autograd.Function):
     def backward(ctx, grad_out):
         from ..functions import clip_ops
         g2 = grad_out.reshape(-1, grad_out.shape[-1])
-        if clip_ops.linear_bwd_usable(g2, ctx.saved_tensors[0], ctx.saved_tensors[1]):
+        saved = ctx.saved_tensors            # (read ONCE: under activation checkpointing a second unpack is an error)
+        x2, weight, y = saved[0], saved[1], (saved[2] if ctx.relu else None)
+        if clip_ops.linear_bwd_usable(g2, x2, weight):
             # [ReLU mask,] grad_x, grad_w and grad_b in ONE launch (include/clip_ops_hip.h: clipops_linear_bwd_f32)
-            x2, weight = ctx.saved_tensors[0], ctx.saved_tensors[1]
-            gx, gw, gb = clip_ops.linear_bwd(g2, ctx.saved_tensors[2] if ctx.relu else None, x2, weight,
-                                             ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2])
+            gx, gw, gb = clip_ops.linear_bwd(g2, y, x2, weight, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                             ctx.needs_input_grad[2])
             return (None if gx is None else gx.view(ctx.x_shape)), gw, gb, None
         if ctx.relu:
-            x2, weight, y = ctx.saved_tensors
             g2 = torch.ops.aten.threshold_backward(g2, y, 0.0)                     # the ReLU mask
-        else:
-            x2, weight = ctx.saved_tensors
         gx = (g2 @ weight).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
         gw = g2.t() @ x2 if ctx.needs_input_grad[1] else None
         gb = clip_ops.colsum(g2.contiguous()) if ctx.needs_input_grad[2] else None
