@@ -171,6 +171,15 @@ int clipops_linear_bwd_f32(const float *grad_y, const float *y_relu, const float
 int clipops_linear_fwd_f32(const float *x, const float *w, const float *bias, int rows, int in_features,
                            int out_features, int relu, float *y, void *stream);
 
+/* g2 = y > 0 ? g : 0 (the ReLU mask of a Linear whose forward fused the activation; torch's threshold_backward) AND
+ * the per-chunk column sums of g2 (first pass of the bias gradient, finished by clipops_colsum_f32 over `partial`
+ * (chunks, cols)) in one pass over (rows, cols) contiguous matrices: the encoder FFN's first linear
+ * (models/deformable_encoder.py:100-103 of the reference) otherwise re-reads its 914 MB gradient for the sum. */
+int clipops_relu_bwd_colsum_partial_f32(const float *g, const float *y, long rows, int cols, int chunk_rows, float *g2,
+                                        float *partial, void *stream);
+int clipops_relu_bwd_colsum_partial_bf16(const uint16_t *g, const uint16_t *y, long rows, int cols, int chunk_rows,
+                                         uint16_t *g2, float *partial, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -432,6 +432,52 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const TX *__restric
     }
 }
 
+// The ReLU mask of a fused-ReLU Linear's backward and the first pass of its bias gradient in ONE pass over the
+// gradient: g2 = y > 0 ? g : 0 is written and summed per (32-column tile, row chunk) on the way.  For the encoder
+// FFN's first linear (111,615 x 2048 floats per layer of a 5-frame clip) the separate column sum re-read 914 MB.
+__device__ __forceinline__ void colsum_st(float *x, long i, float v) { x[i] = v; }
+__device__ __forceinline__ void colsum_st(uint16_t *x, long i, float v) {        // (v is a bf16 value or 0: exact)
+    x[i] = (uint16_t)(__float_as_uint(v) >> 16);
+}
+
+template <typename TX>
+__global__ __launch_bounds__(256) void relu_bwd_colsum_partial_kernel(const TX *__restrict__ g, const TX *__restrict__ y,
+                                                                     long rows, int cols, int chunk_rows,
+                                                                     TX *__restrict__ g2, float *__restrict__ partial) {
+    __shared__ float s_part[8][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + tx;
+    const long r0 = (long)blockIdx.y * chunk_rows;
+    const long r1 = r0 + chunk_rows < rows ? r0 + chunk_rows : rows;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (c < cols) {
+        long r = r0 + ty;
+        for (; r + 24 < r1; r += 32) {
+            const long i0 = r * cols + c, i1 = (r + 8) * cols + c, i2 = (r + 16) * cols + c, i3 = (r + 24) * cols + c;
+            const float v0 = colsum_ld(y, i0) > 0.f ? colsum_ld(g, i0) : 0.f;
+            const float v1 = colsum_ld(y, i1) > 0.f ? colsum_ld(g, i1) : 0.f;
+            const float v2 = colsum_ld(y, i2) > 0.f ? colsum_ld(g, i2) : 0.f;
+            const float v3 = colsum_ld(y, i3) > 0.f ? colsum_ld(g, i3) : 0.f;
+            colsum_st(g2, i0, v0); colsum_st(g2, i1, v1); colsum_st(g2, i2, v2); colsum_st(g2, i3, v3);
+            a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+        }
+        for (; r < r1; r += 8) {
+            const long i0 = r * cols + c;
+            const float v0 = colsum_ld(y, i0) > 0.f ? colsum_ld(g, i0) : 0.f;
+            colsum_st(g2, i0, v0);
+            a0 += v0;
+        }
+    }
+    s_part[ty][tx] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (ty == 0 && c < cols) {
+        float t = s_part[0][tx];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) t += s_part[i][tx];
+        partial[(long)blockIdx.y * cols + c] = t;
+    }
+}
+
 // ----------------------------------------------------------------------------------------
 // multi-head self-attention over the decoder queries (head_dim 32, L <= 512): forward and backward
 // ----------------------------------------------------------------------------------------
@@ -1188,6 +1234,36 @@ int clipops_colsum_partial_bf16(const uint16_t *x, long rows, int cols, int chun
     hipLaunchKernelGGL(colsum_partial_kernel<uint16_t>, dim3((cols + 31) / 32, (unsigned)chunks), dim3(256), 0,
                        (hipStream_t)stream, x, rows, cols, chunk_rows, partial);
     return check_launch("colsum_partial_kernel<bf16>");
+}
+
+static int relu_bwd_colsum_check(const void *g, const void *y, const void *g2, const void *partial, long rows, int cols,
+                                 int chunk_rows, long *chunks) {
+    if (rows < 0 || cols < 0 || chunk_rows <= 0) return fail(1, "clipops_relu_bwd_colsum_partial: bad dimension");
+    *chunks = (rows + chunk_rows - 1) / chunk_rows;
+    if (cols == 0 || rows == 0) return 0;
+    if (!g || !y || !g2 || !partial) return fail(1, "clipops_relu_bwd_colsum_partial: null pointer");
+    if (*chunks > 65535) return fail(1, "clipops_relu_bwd_colsum_partial: too many chunks");
+    return 0;
+}
+
+int clipops_relu_bwd_colsum_partial_f32(const float *g, const float *y, long rows, int cols, int chunk_rows, float *g2,
+                                        float *partial, void *stream) {
+    long chunks = 0;
+    if (relu_bwd_colsum_check(g, y, g2, partial, rows, cols, chunk_rows, &chunks)) return 1;
+    if (cols == 0 || rows == 0) { g_err[0] = 0; return 0; }
+    hipLaunchKernelGGL(relu_bwd_colsum_partial_kernel<float>, dim3((cols + 31) / 32, (unsigned)chunks), dim3(256), 0,
+                       (hipStream_t)stream, g, y, rows, cols, chunk_rows, g2, partial);
+    return check_launch("relu_bwd_colsum_partial_kernel");
+}
+
+int clipops_relu_bwd_colsum_partial_bf16(const uint16_t *g, const uint16_t *y, long rows, int cols, int chunk_rows,
+                                         uint16_t *g2, float *partial, void *stream) {
+    long chunks = 0;
+    if (relu_bwd_colsum_check(g, y, g2, partial, rows, cols, chunk_rows, &chunks)) return 1;
+    if (cols == 0 || rows == 0) { g_err[0] = 0; return 0; }
+    hipLaunchKernelGGL(relu_bwd_colsum_partial_kernel<uint16_t>, dim3((cols + 31) / 32, (unsigned)chunks), dim3(256), 0,
+                       (hipStream_t)stream, g, y, rows, cols, chunk_rows, g2, partial);
+    return check_launch("relu_bwd_colsum_partial_kernel<bf16>");
 }
 
 int clipops_mha_fwd_f32(const float *q, const float *k, const float *v, long q_bs, long q_rs, long k_bs, long k_rs,

@@ -96,9 +96,15 @@ class _SplitKLinear(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
+        gb_done = None
         if ctx.relu:
             x, weight, y = ctx.saved_tensors
-            grad_out = torch.ops.aten.threshold_backward(grad_out, y, 0.0)         # the ReLU mask, one pass
+            from ..functions import clip_ops
+            g2d, y2d = grad_out.reshape(-1, weight.shape[0]), y.reshape(-1, weight.shape[0])
+            if ctx.has_bias and ctx.needs_input_grad[2] and clip_ops.relu_bwd_colsum_usable(g2d, y2d):
+                grad_out, gb_done = clip_ops.relu_bwd_colsum(g2d, y2d)             # mask + bias-gradient partials: one pass
+            else:
+                grad_out = torch.ops.aten.threshold_backward(grad_out, y, 0.0)     # the ReLU mask, one pass
         else:
             x, weight = ctx.saved_tensors
         gx = gw = gb = None
@@ -121,7 +127,9 @@ class _SplitKLinear(torch.autograd.Function):
                 if main < rows:
                     gw = gw + g2[main:].t() @ x2[main:]
             gw = gw.to(weight.dtype)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if gb_done is not None:
+            gb = gb_done.to(weight.dtype)
+        elif ctx.has_bias and ctx.needs_input_grad[2]:
             from ..functions import clip_ops
             # tiled two-pass column sum for fp32 (14 vs 33 us at 66,969 x 256); torch's reduction otherwise
             gb = (clip_ops.colsum(g2) if g2.is_contiguous() else g2.sum(0)).to(weight.dtype)

@@ -491,3 +491,20 @@ def test_linear_forward_tile_kernel(rows, in_f, out_f, relu, monkeypatch):
     assert float((got.double() - want).abs().max()) <= 4e-7 * in_f ** 0.5 * (float(want.abs().max()) + 1.0)
     if relu:
         assert float(got.min()) >= 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("rows,cols", [(5000, 300), (2049, 32), (22323, 2048)])
+def test_relu_mask_and_bias_gradient_partials_in_one_pass(dtype, rows, cols):
+    """g * (y > 0) (bit-equal to torch's threshold_backward) and its column sums (fp32, fixed order) from one pass."""
+    from memotr_amd.functions import clip_ops
+    gen = torch.Generator().manual_seed(rows + cols)
+    g = torch.randn(rows, cols, generator=gen).to(dtype).cuda()
+    y = torch.relu(torch.randn(rows, cols, generator=gen)).to(dtype).cuda()
+    assert clip_ops.relu_bwd_colsum_usable(g, y)
+    g2, gb = clip_ops.relu_bwd_colsum(g, y)
+    want = torch.ops.aten.threshold_backward(g, y, 0.0)
+    assert g2.dtype == dtype and torch.equal(g2, want)
+    ref = want.double().sum(0)
+    assert gb.dtype == torch.float32
+    assert float((gb.double() - ref).abs().max()) <= 1e-5 * rows ** 0.5 * float(want.float().abs().max())
