@@ -48,7 +48,6 @@ SYMBOLS = {
     "clipops_linear_bwd_f32": ([c_void_p] * 4 + [c_int] * 3 + [c_void_p] * 4, c_int),
     "clipops_linear_fwd_f32": ([c_void_p] * 3 + [c_int] * 4 + [c_void_p, c_void_p], c_int),
     "clipops_relu_bwd_colsum_partial_f32": ([c_void_p, c_void_p, c_long, c_int, c_int, c_void_p, c_void_p, c_void_p], c_int),
-    "clipops_relu_bwd_colsum_partial_bf16": ([c_void_p, c_void_p, c_long, c_int, c_int, c_void_p, c_void_p, c_void_p], c_int),
     "clipops_shift_relu_f32": ([c_void_p, c_void_p, c_void_p, c_long, c_int, c_long, c_void_p], c_int),
     "clipops_shift_relu_bf16": ([c_void_p, c_void_p, c_void_p, c_long, c_int, c_long, c_void_p], c_int),
     "clipops_refine_boxes_bwd_f32": ([c_void_p, c_void_p, c_void_p, c_long, c_float, c_void_p, c_void_p, c_void_p],

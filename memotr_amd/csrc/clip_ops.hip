@@ -436,9 +436,6 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const TX *__restric
 // gradient: g2 = y > 0 ? g : 0 is written and summed per (32-column tile, row chunk) on the way.  For the encoder
 // FFN's first linear (111,615 x 2048 floats per layer of a 5-frame clip) the separate column sum re-read 914 MB.
 __device__ __forceinline__ void colsum_st(float *x, long i, float v) { x[i] = v; }
-__device__ __forceinline__ void colsum_st(uint16_t *x, long i, float v) {        // (v is a bf16 value or 0: exact)
-    x[i] = (uint16_t)(__float_as_uint(v) >> 16);
-}
 
 template <typename TX>
 __global__ __launch_bounds__(256) void relu_bwd_colsum_partial_kernel(const TX *__restrict__ g, const TX *__restrict__ y,
@@ -1254,16 +1251,6 @@ int clipops_relu_bwd_colsum_partial_f32(const float *g, const float *y, long row
     hipLaunchKernelGGL(relu_bwd_colsum_partial_kernel<float>, dim3((cols + 31) / 32, (unsigned)chunks), dim3(256), 0,
                        (hipStream_t)stream, g, y, rows, cols, chunk_rows, g2, partial);
     return check_launch("relu_bwd_colsum_partial_kernel");
-}
-
-int clipops_relu_bwd_colsum_partial_bf16(const uint16_t *g, const uint16_t *y, long rows, int cols, int chunk_rows,
-                                         uint16_t *g2, float *partial, void *stream) {
-    long chunks = 0;
-    if (relu_bwd_colsum_check(g, y, g2, partial, rows, cols, chunk_rows, &chunks)) return 1;
-    if (cols == 0 || rows == 0) { g_err[0] = 0; return 0; }
-    hipLaunchKernelGGL(relu_bwd_colsum_partial_kernel<uint16_t>, dim3((cols + 31) / 32, (unsigned)chunks), dim3(256), 0,
-                       (hipStream_t)stream, g, y, rows, cols, chunk_rows, g2, partial);
-    return check_launch("relu_bwd_colsum_partial_kernel<bf16>");
 }
 
 int clipops_mha_fwd_f32(const float *q, const float *k, const float *v, long q_bs, long q_rs, long k_bs, long k_rs,

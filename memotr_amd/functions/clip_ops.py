@@ -335,7 +335,7 @@ def colsum(x: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
 def relu_bwd_colsum_usable(g: torch.Tensor, y: torch.Tensor) -> bool:
     return (os.environ.get("MEMOTR_FUSED_CLIP_OPS", "1") != "0" and os.environ.get("MEMOTR_FUSED_RELU_COLSUM", "1") != "0"
             and g.is_cuda and g.dim() == 2 and g.is_contiguous() and y.is_contiguous() and y.shape == g.shape
-            and g.dtype == y.dtype and g.dtype in (torch.float32, torch.bfloat16)
+            and g.dtype == y.dtype and g.dtype == torch.float32        # (bf16: 546 vs 358 us for the two torch passes)
             and COLSUM_MAX_ROWS < g.shape[0] <= COLSUM_MAX_ROWS * COLSUM_CHUNK_ROWS)
 
 
@@ -348,8 +348,7 @@ def relu_bwd_colsum(g: torch.Tensor, y: torch.Tensor):
     partial = torch.empty((chunks, cols), dtype=torch.float32, device=g.device)
     out = torch.empty((cols,), dtype=torch.float32, device=g.device)
     L = _lib()
-    fn = (L.lib.clipops_relu_bwd_colsum_partial_bf16 if g.dtype == torch.bfloat16
-          else L.lib.clipops_relu_bwd_colsum_partial_f32)
+    fn = L.lib.clipops_relu_bwd_colsum_partial_f32
     L.check(fn(g.data_ptr(), y.data_ptr(), rows, cols, COLSUM_CHUNK_ROWS, g2.data_ptr(), partial.data_ptr(), _stream(g)),
             "clipops_relu_bwd_colsum_partial")
     L.check(L.lib.clipops_colsum_f32(partial.data_ptr(), chunks, cols, out.data_ptr(), _stream(g)), "clipops_colsum_f32")

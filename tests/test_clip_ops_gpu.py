@@ -493,7 +493,7 @@ def test_linear_forward_tile_kernel(rows, in_f, out_f, relu, monkeypatch):
         assert float(got.min()) >= 0.0
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", [torch.float32], ids=["f32"])
 @pytest.mark.parametrize("rows,cols", [(5000, 300), (2049, 32), (22323, 2048)])
 def test_relu_mask_and_bias_gradient_partials_in_one_pass(dtype, rows, cols):
     """g * (y > 0) (bit-equal to torch's threshold_backward) and its column sums (fp32, fixed order) from one pass."""
