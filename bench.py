@@ -238,6 +238,19 @@ def read_traffic(kernel_label):
         return None
 
 
+def read_traffic_bwd(kernel_label):
+    """The same for the encoder-shape backward (profiles/traffic_bwd.json, from tools/pmc_probe.sh)."""
+    try:
+        from memotr_amd.build import source_hash
+        with open(os.path.join(ROOT, "profiles", "traffic_bwd.json")) as f:
+            t = json.load(f)
+        if not str(kernel_label).startswith(t.get("kernel_label", "?")) or t.get("source_sha16") != source_hash():
+            return None
+        return t.get("msda_bwd_encoder_bytes_per_launch")
+    except Exception:
+        return None
+
+
 def host_cpu_info():
     model = "unknown"
     try:
@@ -341,6 +354,12 @@ def kernel_lines(args, enc, dec):
         "kernels": {"enc_fwd_ms": ms_fwd, "enc_bwd_ms": ms_bwd, "dec_fwd_ms": ms_dec, "enc_bwd_kernel": kernel_bwd,
                     "enc_bwd_GBps": enc.bytes(True) / (ms_bwd * 1e-3) / 1e9},
     }
+    # the step's other large MSDA kernel, priced the same way (137,152,608 algorithmic bytes per encoder-shape call)
+    ach_b = enc.bytes(True) / (ms_bwd * 1e-3) / 1e9
+    out["roofline_backward"] = {"bound": "hbm", "achieved": ach_b, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                "frac": ach_b / HBM_PEAK_GBPS, "traffic": read_traffic_bwd(kernel_bwd),
+                                "kernel": kernel_bwd, "ms": ms_bwd, "algorithmic_bytes": enc.bytes(True),
+                                "loc_dist": args.dist}
     other = "uniform" if args.dist != "uniform" else "encoder_like"
     dev = torch.device("cuda", torch.cuda.current_device())
     alt = FusedCall(make_inputs(device=dev, dist=other, seed=3))
