@@ -15,8 +15,13 @@ Prints ONE JSON line on rank 0 (contract in the task description).  Workloads:
 
 Every rank works on its own synthetic frame (clips shard by rank; no data-path collective), so
 scaling is "weak".  The JSON carries
-  roofline      for the dominant kernel (encoder-shape forward): algorithmic bytes
-                / average launch duration, measured with HIP events on the launch stream
+  roofline      for the dominant kernel (encoder-shape fused forward, what the model launches): algorithmic bytes
+                 / average launch duration, measured with HIP events on the launch stream; `traffic` =
+                measured fabric bytes (profiles/traffic.json, only if measured on this kernel at these sources)
+  roofline_backward                 the same for the fused counting-sort backward (profiles/traffic_bwd.json)
+  roofline_uniform / _encoder_like  the forward on the OTHER location distribution (the kernel selection's other end)
+  roofline_bf16                     (--dtype bf16) the bf16-storage forward on its own bytes
+  kernels       launch times / kernel names of the encoder- and decoder-shape calls, both distributions
   cpu_baseline  the reference's pure-PyTorch fallback formulation (oracle.grid_sample_forward, a port
                 of models/ops/functions/ms_deform_attn_func.py:44-64) on the host cores, rank 0, N=1.
 """
