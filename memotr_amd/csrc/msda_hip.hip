@@ -1953,6 +1953,65 @@ __global__ __launch_bounds__(256) void msda_fused_finish16_kernel(const int64_t 
     }
 }
 
+// The two side kernels of the slim split backward with ONE lane per (query, head) row (L*P == 16, row pitches multiples
+// of 4): the sixteen logits / weights / gradients of a row are four 16-byte accesses of that lane, the softmax and its
+// Jacobian run in registers -- no cross-lane traffic, a sixteenth of the threads, one index division per row.  The sums
+// associate exactly like the 16-lane butterflies above ((t, t + 8) first, then 4, 2, 1 / 1, 2, 4), so the bits are theirs.
+__global__ __launch_bounds__(256) void msda_fused_attn16_rows_kernel(const PointSrc fs, unsigned n_rows, unsigned M,
+                                                                    float *__restrict__ attn_out) {
+    for (unsigned pm = blockIdx.x * blockDim.x + threadIdx.x; pm < n_rows; pm += gridDim.x * blockDim.x) {
+        const unsigned qrow = pm / M, m = pm - qrow * M;
+        const f32x4 *lp = reinterpret_cast<const f32x4 *>(fs.proj + ((size_t)qrow * (unsigned)fs.proj_stride +
+                                                                   (unsigned)fs.n_off + m * 16u));
+        float lg[16];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const f32x4 v = lp[k];
+            lg[4 * k] = v.x; lg[4 * k + 1] = v.y; lg[4 * k + 2] = v.z; lg[4 * k + 3] = v.w;
+        }
+        float mx = lg[0];
+#pragma unroll
+        for (int t = 1; t < 16; ++t) mx = fmaxf(mx, lg[t]);
+        float e[16], s8[8];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) e[t] = expf(lg[t] - mx);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) s8[t] = e[t] + e[t + 8];
+        const float sum = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+        const float rsum = 1.f / sum;
+        f32x4 *op = reinterpret_cast<f32x4 *>(attn_out + (size_t)pm * 16u);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) op[k] = f32x4{e[4 * k] * rsum, e[4 * k + 1] * rsum, e[4 * k + 2] * rsum, e[4 * k + 3] * rsum};
+    }
+}
+
+__global__ __launch_bounds__(256) void msda_fused_finish16_rows_kernel(const PointSrc fs, unsigned n_rows, unsigned M,
+                                                                      float *__restrict__ grad_proj) {
+    for (unsigned pm = blockIdx.x * blockDim.x + threadIdx.x; pm < n_rows; pm += gridDim.x * blockDim.x) {
+        const unsigned qrow = pm / M, m = pm - qrow * M;
+        f32x4 *gp = reinterpret_cast<f32x4 *>(grad_proj + ((size_t)qrow * (unsigned)fs.proj_stride + (unsigned)fs.n_off + m * 16u));
+        const f32x4 *ap = reinterpret_cast<const f32x4 *>(fs.attn + (size_t)pm * 16u);
+        float a[16], g[16], d[16];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const f32x4 av = ap[k], gv = gp[k];
+            a[4 * k] = av.x; a[4 * k + 1] = av.y; a[4 * k + 2] = av.z; a[4 * k + 3] = av.w;
+            g[4 * k] = gv.x; g[4 * k + 1] = gv.y; g[4 * k + 2] = gv.z; g[4 * k + 3] = gv.w;
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) d[t] = a[t] * g[t];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) d[t] += d[t + 8];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) d[t] += d[t + 4];
+        const float dot = (d[0] + d[2]) + (d[1] + d[3]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            gp[k] = f32x4{a[4 * k] * (g[4 * k] - dot), a[4 * k + 1] * (g[4 * k + 1] - dot),
+                          a[4 * k + 2] * (g[4 * k + 2] - dot), a[4 * k + 3] * (g[4 * k + 3] - dot)};
+    }
+}
+
 #include "msda_fwd_win.h"
 #include "msda_bwd_rows.h"
 #include "msda_bwd_bins.h"
@@ -1992,6 +2051,7 @@ std::atomic<int> opt_fwd_win_margins{0x3333};  // window margin per level, 4 bit
 std::atomic<int> opt_fwd_win_ablate{0};     // profiling only
 std::atomic<int> opt_fwd_win_wps{0};        // 3 / 4: force the 168- / 128-register build
 std::atomic<int> opt_fwd_win_early{2};      // 0 / 1: global points after / around the LDS phase (2: by register budget)
+std::atomic<int> opt_bwd_side_rows{1};      // slim split backward: side kernels with one lane per (query, head) row (0: one lane per point)
 std::atomic<int> opt_fwd_win_trace_lo{0}, opt_fwd_win_trace_hi{0};   // profiling: device address of the timeline buffer (31 + 31 bits)
 std::atomic<int> opt_fwd_win_dma{1};        // fill the windows with buffer_load ... lds       // profiling only: drop parts of the tiled backward (results are then wrong)
 
@@ -2561,9 +2621,17 @@ int backward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart,
                 const int offsets_done = slim && fa.ref_dim == 2 ? 1 : 0;
                 bp.fused_loc = slim ? 1 : 0;
                 bp.offsets_done = offsets_done;
+                bool rows16 = false;
                 if (split) {
                     float *loc_ws = workspace, *attn_ws = workspace + (size_t)n_rows * L * P * 2;
-                    if (L * P <= 16) {
+                    // one lane per row (16 points as four 16-byte accesses): the slim path's two side kernels
+                    rows16 = slim && L * P == 16 && (fa.proj_stride % 4) == 0 && (src.n_off % 4) == 0 &&
+                             (((uintptr_t)fa.proj | (uintptr_t)grad_proj | (uintptr_t)workspace) & 15) == 0 &&
+                             n_rows < (1L << 31) && opt_bwd_side_rows.load() != 0;
+                    if (rows16) {
+                        hipLaunchKernelGGL(msda_fused_attn16_rows_kernel, dim3(clamp_grid((n_rows + 255) / 256, 32)),
+                                           dim3(256), 0, stream, src, (unsigned)n_rows, (unsigned)M, attn_ws);
+                    } else if (L * P <= 16) {
                         hipLaunchKernelGGL(msda_fused_points16_kernel, dim3(clamp_grid((n_rows * 16 + 255) / 256, 32)),
                                            dim3(256), 0, stream, shapes, src, n_rows, M, L, P,
                                            slim ? (float *)nullptr : loc_ws, attn_ws);
@@ -2612,7 +2680,10 @@ int backward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart,
                 if (rc || !fused) return rc;
                 const int jgrid = clamp_grid((n_rows * 8 + 255) / 256, 16);
                 if (split) {
-                    if (L * P <= 16) {
+                    if (rows16 && offsets_done) {
+                        hipLaunchKernelGGL(msda_fused_finish16_rows_kernel, dim3(clamp_grid((n_rows + 255) / 256, 32)),
+                                           dim3(256), 0, stream, src, (unsigned)n_rows, (unsigned)M, grad_proj);
+                    } else if (L * P <= 16) {
                         hipLaunchKernelGGL(msda_fused_finish16_kernel, dim3(clamp_grid((n_rows * 16 + 255) / 256, 32)),
                                            dim3(256), 0, stream, shapes, src, n_rows, M, L, P, grad_proj, offsets_done);
                     } else {
@@ -2944,6 +3015,7 @@ static std::atomic<int> *find_opt(const char *key) {
     if (!strcmp(key, "fwd_win_l0")) return &opt_fwd_win_l0;
     if (!strcmp(key, "fwd_win_margins")) return &opt_fwd_win_margins;
     if (!strcmp(key, "fwd_win_dma")) return &opt_fwd_win_dma;
+    if (!strcmp(key, "bwd_side_rows")) return &opt_bwd_side_rows;
     if (!strcmp(key, "fwd_win_trace_lo")) return &opt_fwd_win_trace_lo;
     if (!strcmp(key, "fwd_win_trace_hi")) return &opt_fwd_win_trace_hi;
     if (!strcmp(key, "fwd_win_ablate")) return &opt_fwd_win_ablate;
