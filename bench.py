@@ -71,16 +71,58 @@ def parse_args():
     return ap.parse_args()
 
 
+def launcher_argv(n_gpus, script_argv, port=None):
+    """The command `python bench.py --gpus N` turns itself into when nobody launched it as N ranks: one process per
+    GPU of this node under torch.distributed.run, rendezvous on 127.0.0.1 (the reference's own launch line is
+    `python -m torch.distributed.run --nproc_per_node=8 main.py ...`, README.md:104; main.py:100-101)."""
+    if port is None:
+        import socket
+        with socket.socket() as s:          # a free port now; the launcher's store binds it a moment later
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(script_argv)
+
+
+def device_count():
+    """Visible GPUs (MEMOTR_BENCH_DEVICE_COUNT overrides: the CPU tests of the self-launch path)."""
+    fake = os.environ.get("MEMOTR_BENCH_DEVICE_COUNT")
+    return int(fake) if fake is not None else (torch.cuda.device_count() if torch.cuda.is_available() else 0)
+
+
+def self_launch_if_needed(args, script_argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): check the device count, then
+    replace this process by the N-rank launch.  Rank 0 of that launch prints the one JSON line to the same stdout.
+    MEMOTR_BENCH_DRY_LAUNCH=1 prints the launch command instead of running it."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    have = device_count()
+    if have < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible on this node "
+                         f"(device count, not a launcher problem: one rank per GPU is started automatically)")
+    argv = launcher_argv(args.gpus, script_argv)
+    if os.environ.get("MEMOTR_BENCH_DRY_LAUNCH", "0") == "1":
+        print(json.dumps({"launch": argv}), flush=True)
+        raise SystemExit(0)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on these hosts (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "1")                # the launcher would set it anyway; ranks re-size their pools
+    sys.stdout.flush()
+    os.execvpe(argv[0], argv, env)
+
+
 def init_dist(n_gpus):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != n_gpus:
+        raise SystemExit(f"--gpus {n_gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if local_rank >= device_count():
+        raise SystemExit(f"rank {rank}: local rank {local_rank} but only {device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if world != n_gpus:
-        raise SystemExit(f"--gpus {n_gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     return rank, local_rank, world
 
 
@@ -544,6 +586,7 @@ def run_msda_kernels_only(args):
 
 def main():
     args = parse_args()
+    self_launch_if_needed(args, sys.argv[1:])
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
     rank, _, world = init_dist(args.gpus)
