@@ -181,22 +181,32 @@ int msda_fused_backward_ws_bf16(const uint16_t *value, const int64_t *shapes_dev
                                 int zero_grad_value, const int64_t *shapes_host,
                                 void *workspace, size_t workspace_bytes, void *stream);
 
-/* ---- kernel selection (round 4; memotr_amd/csrc/msda_select.h) ----
+/* ---- kernel selection (round 4, records reworked in round 5 = ABI 5; memotr_amd/csrc/msda_select.h) ----
  * The cost of the reference kernels does not depend on where the sampling points land
  * (ms_deform_im2col_cuda.cuh:237-403); the windowed kernels here are fast for points near their query and slow
  * for points far away.  With "fwd_variant" / "bwd_variant" 0 the library therefore follows the data: the windowed
- * kernels report the share of corners outside their windows, and the next call of the same (call site, geometry)
- * picks the window margin -- or a kernel without windows -- accordingly.  Results never depend on the choice.
+ * kernels report the share of corners outside their windows (cumulative counters: launches replayed from a hipGraph
+ * count like eager ones), and the next call of the same call site picks the window margin -- or a kernel without
+ * windows -- accordingly.  A record belongs to (device, direction, call site, M, L, P, element size), not to a
+ * geometry; all records share one allocation per device.  Results never depend on the choice.
  *   msda_set_call_site   tags the calling thread's following calls (e.g. one tag per attention module; 0 = untagged),
  *                        so that modules with different learnt offsets on the same geometry are judged separately;
  *   msda_selector_last   level (0 = small windows ... top = no windows) and the last measured shares of corners outside
  *                        the window / outside the next smaller window, for this thread's last selected call
  *                        (shares < 0: nothing measured yet);
  *   msda_selector_next   the transition function itself (pure; for tests): next level from (kind 0 fwd / 1 bwd,
- *                        level, off-window and inner-window shares in 1/1000). */
+ *                        level, off-window and inner-window shares in 1/1000);
+ *   msda_selector_poll   for callers that replay captured launches (a hipGraph makes no library call per launch): reads
+ *                        every record of the current device, moves the levels, and stores a signature of the levels a
+ *                        call would run at now (0: every record at level 0).  A graph cache keyed on the signature
+ *                        replays the graph captured at those levels and captures another when a level has moved; a call
+ *                        made while its stream is capturing takes the level the last poll announced.  Every 32nd poll
+ *                        announces one level down for records at a level without windows (the probe that lets a record
+ *                        come back).  Returns the number of records read. */
 void msda_set_call_site(uint64_t site);
 int msda_selector_last(int *level, float *off_share, float *inner_share);
 int msda_selector_next(int kind, int level, int off_permille, int inner_permille);
+int msda_selector_poll(uint64_t *signature);
 
 /* ---- parity hooks ----
  * msda_sample_indices_f32: the integer side of the sampling arithmetic.  For every (n,q,m,l,p):

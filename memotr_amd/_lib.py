@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MEMOTR_MSDA_LIB") or os.path.join(_HERE, "lib", "libmsda_hip.so")   # (override: A/B builds)
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 c_int = ctypes.c_int
 c_void_p = ctypes.c_void_p
@@ -47,6 +47,7 @@ SYMBOLS = {
     "msda_set_call_site": ([ctypes.c_uint64], None),
     "msda_selector_last": ([ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)], c_int),
     "msda_selector_next": ([c_int] * 4, c_int),
+    "msda_selector_poll": ([ctypes.POINTER(ctypes.c_uint64)], c_int),
     "msda_set_option": ([ctypes.c_char_p, c_int], c_int),
     "msda_get_option": ([ctypes.c_char_p, ctypes.POINTER(c_int)], c_int),
 }
@@ -96,8 +97,16 @@ def get_option(key: str) -> int:
 
 
 def set_call_site(site: int) -> None:
-    """Tag this thread's following operator calls (kernel selection keeps one record per (site, geometry))."""
+    """Tag this thread's following operator calls (kernel selection keeps one record per call site)."""
     lib.msda_set_call_site(ctypes.c_uint64(site & 0xFFFFFFFFFFFFFFFF))
+
+
+def selector_poll() -> int:
+    """Read every selector record of the current device, move the levels, return the signature of the levels a call
+    would run at now (0: every record at level 0).  For code that replays captured launches: key the graph on it."""
+    sig = ctypes.c_uint64(0)
+    lib.msda_selector_poll(ctypes.byref(sig))
+    return int(sig.value)
 
 
 def selector_last():

@@ -9,11 +9,10 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(_HERE, "csrc", "msda_hip.hip")
 HDR = os.path.join(os.path.dirname(_HERE), "include", "msda_hip.h")
-COMMON = os.path.join(_HERE, "csrc", "msda_common.h")
-FWD_WIN = os.path.join(_HERE, "csrc", "msda_fwd_win.h")
-BWD_ROWS = os.path.join(_HERE, "csrc", "msda_bwd_rows.h")
-BWD_BINS = os.path.join(_HERE, "csrc", "msda_bwd_bins.h")
-SELECT = os.path.join(_HERE, "csrc", "msda_select.h")
+# the operator's kernels, one header per family, all included by msda_hip.hip
+KERNEL_HEADERS = tuple(os.path.join(_HERE, "csrc", n) for n in (
+    "msda_common.h", "msda_select.h", "msda_generic.h", "msda_fwd_gather.h", "msda_fwd_win.h", "msda_tile.h",
+    "msda_bwd_tile_lv.h", "msda_bwd_bins.h", "msda_bwd_rows.h", "msda_fused_side.h"))
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libmsda_hip.so")
 CLIP_SRC = os.path.join(_HERE, "csrc", "clip_ops.hip")
@@ -39,7 +38,7 @@ def source_hash() -> str:
     number taken on other kernels is recognised as stale."""
     import hashlib
     h = hashlib.sha256()
-    for p in (SRC, COMMON, FWD_WIN, BWD_ROWS, BWD_BINS, SELECT):
+    for p in (SRC,) + KERNEL_HEADERS:
         with open(p, "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -53,7 +52,7 @@ def _stale(lib: str, deps) -> bool:
 
 
 def needs_build() -> bool:
-    return _stale(LIB, (SRC, HDR, COMMON, FWD_WIN, BWD_ROWS, BWD_BINS, SELECT))
+    return _stale(LIB, (SRC, HDR) + KERNEL_HEADERS)
 
 
 def _compile(src: str, lib: str, verbose: bool) -> str:

@@ -451,16 +451,16 @@ __global__ __launch_bounds__(256) void relu_bwd_colsum_partial_kernel(const TX *
         long r = r0 + ty;
         for (; r + 24 < r1; r += 32) {
             const long i0 = r * cols + c, i1 = (r + 8) * cols + c, i2 = (r + 16) * cols + c, i3 = (r + 24) * cols + c;
-            const float v0 = colsum_ld(y, i0) > 0.f ? colsum_ld(g, i0) : 0.f;
-            const float v1 = colsum_ld(y, i1) > 0.f ? colsum_ld(g, i1) : 0.f;
-            const float v2 = colsum_ld(y, i2) > 0.f ? colsum_ld(g, i2) : 0.f;
-            const float v3 = colsum_ld(y, i3) > 0.f ? colsum_ld(g, i3) : 0.f;
+            const float v0 = colsum_ld(y, i0) <= 0.f ? 0.f : colsum_ld(g, i0);
+            const float v1 = colsum_ld(y, i1) <= 0.f ? 0.f : colsum_ld(g, i1);
+            const float v2 = colsum_ld(y, i2) <= 0.f ? 0.f : colsum_ld(g, i2);
+            const float v3 = colsum_ld(y, i3) <= 0.f ? 0.f : colsum_ld(g, i3);
             colsum_st(g2, i0, v0); colsum_st(g2, i1, v1); colsum_st(g2, i2, v2); colsum_st(g2, i3, v3);
             a0 += v0; a1 += v1; a2 += v2; a3 += v3;
         }
         for (; r < r1; r += 8) {
             const long i0 = r * cols + c;
-            const float v0 = colsum_ld(y, i0) > 0.f ? colsum_ld(g, i0) : 0.f;
+            const float v0 = colsum_ld(y, i0) <= 0.f ? 0.f : colsum_ld(g, i0);
             colsum_st(g2, i0, v0);
             a0 += v0;
         }
@@ -981,7 +981,7 @@ __device__ __forceinline__ void linear_bwd_tile(const float *__restrict__ g, con
         for (int u = 0; u < LB_U; ++u) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float av = RELU ? (m[u][q] > 0.f ? a[u][q] : 0.f) : a[u][q];
+                const float av = RELU ? (m[u][q] <= 0.f ? 0.f : a[u][q]) : a[u][q];      // (y <= 0 ? 0 : g -- aten's threshold_backward: a NaN activation passes g)
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[u][q], acc, 0, 0, 0);
                 bsum += av;
             }

@@ -43,8 +43,8 @@ struct BinsPlan {
     int magic_p;             // (i * magic_p) >> 16 == i / P for i < 256 * NI
     int scan_c;              // cells per lane in the prefix sum (multiple of 4); counters are padded to 64 * scan_c
     int strip;               // region rows per strip of the block -> region walk (1: raster order)
-    int shrink, level, parity;   // statistics: also count the corners outside the window shrunk by `shrink` pixels; selector level; launch parity
-    unsigned *stats, *stats_host;   // msda_select.h records (device / mapped host), null: no statistics
+    int shrink, level;           // statistics: also count the corners outside the window shrunk by `shrink` pixels; selector level
+    unsigned long long *stats, *stats_host;   // msda_select.h records (device / mapped host), null: no statistics
     // byte offsets into dynamic LDS (grad_out rows at 0).  Two unions: o_x holds the items' records (16 B each) and
     // flags (at o_fl) until the row phase is over, the sorted entries afterwards; o_st holds the ticket counters and the
     // row tables until the sort is done, the flush transpose afterwards.  o_start: u16 per cell, o_comp: u32 per
@@ -335,8 +335,8 @@ __global__ __launch_bounds__(kTileThreads, MSDA_BINS_WGS) void msda_bwd_d32_bins
     }
     __syncthreads();      // B2: tickets drawn, records written
     if (bp.stats != nullptr) {
-        if (tid == 0 && stat_wg) sel_add(bp.stats, bp.parity, (unsigned)(sw >> 3), s_cnt[0], s_cnt[1], s_cnt[2]);
-        if (sw == 0 && wave == 1) sel_publish_previous(bp.stats, bp.stats_host, bp.parity, (unsigned)bp.level, lane);
+        if (tid == 0 && stat_wg) sel_add(bp.stats, bp.level, (unsigned)(sw >> 3), s_cnt[0], s_cnt[1], s_cnt[2]);
+        if (sw == 0 && wave == 1) sel_publish(bp.stats, bp.stats_host, lane);
     }
     if (pl.ablate & 16) return;
 

@@ -31,6 +31,7 @@ constexpr int kWinMaxL = 4;
 struct WinPlan {
     int N, S, M, L, P, Lq;
     int RY, RX;                    // regions per image
+    int RYf, RXf;                  // ... of them complete on level 0 (H0 >> rlogy, W0 >> rlogx): walked first
     int rows;                      // queries per region
     int steps;                     // ceil(rows / 4)
     int lwin0;                     // first level served from an LDS window
@@ -49,8 +50,8 @@ struct WinPlan {
     unsigned value_bytes;
     int n_blocks;
     unsigned long long *trace;     // profiling only (tools/fwd_win_timeline.py): 32 s_memtime stamps per wavefront, or null
-    unsigned *stats, *stats_host;  // msda_select.h records (device / mapped host); null: no statistics
-    int sel_parity, sel_level;
+    unsigned long long *stats, *stats_host;  // msda_select.h records (device / mapped host); null: no statistics
+    int sel_level;
     int ablate;                    // profiling only (msda_set_option "fwd_win_ablate"): 1 stop after the prologue, 2 no gather,
                                    // 4 write per (row, point) 2 = left its window / 1 = served from it / 0 into `out` (use 6)
 };
@@ -60,6 +61,11 @@ struct WinTables {
     int ww[kWinMaxL], wh[kWinMaxL], wmagic[kWinMaxL], wbase[kWinMaxL + 1], lstart[kWinMaxL];
     int ox[kWinMaxL], oy[kWinMaxL];
     int lvl[16];                   // level of point t
+    // this region's queries, level by level: first pixel, pixels per row that exist, 1 / that, and (row0) the first
+    // region-row of the level counting existing pixels only -- a region on the image border has fewer rows
+    int y0[kWinMaxL], x0[kWinMaxL], wv[kWinMaxL];
+    float rcpw[kWinMaxL];
+    int rows, steps;
 };
 
 struct WinRow {
@@ -68,18 +74,21 @@ struct WinRow {
     unsigned qrow, pm;
 };
 
-__device__ __forceinline__ WinRow win_row(const WinTables &tb, int L, int rows, int r, int b, int ry, int rx, int m,
-                                          int M, int Lq) {
+// Region row r -> its query.  Rows count the pixels that EXIST (round 5): a border region of 16 x 16 pixels with 4 x 8
+// of them inside the image has 32 + 8 + 2 + 1 rows, not 340 with 297 dead ones staged and skipped.
+__device__ __forceinline__ WinRow win_row(const WinTables &tb, int L, int r, int b, int m, int M, int Lq) {
     int l = 0;
 #pragma unroll
     for (int i = 1; i < kWinMaxL; ++i)
         if (i < L && r >= tb.row0[i]) l = i;
-    const int local = r - tb.row0[l], sx = tb.shx[l], sy = tb.shy[l];
+    const int local = r - tb.row0[l], wv = tb.wv[l];
+    // local / wv for local < 1024, wv <= 32: (local + 0.5) / wv is at least 1 / 64 away from every integer
+    const int y = (int)(((float)local + 0.5f) * tb.rcpw[l]);
     WinRow o;
     o.lq = l;
-    o.py = (ry << sy) + (local >> sx);
-    o.px = (rx << sx) + (local & ((1 << sx) - 1));
-    o.ok = (r < rows) && (o.py < tb.H[l]) && (o.px < tb.W[l]);
+    o.py = tb.y0[l] + y;
+    o.px = tb.x0[l] + (local - y * wv);
+    o.ok = r < tb.rows;
     const int q = o.ok ? tb.qstart[l] + o.py * tb.W[l] + o.px : 0;
     o.qrow = (unsigned)b * (unsigned)Lq + (unsigned)q;
     o.pm = o.qrow * (unsigned)M + (unsigned)m;
@@ -126,15 +135,21 @@ __device__ __forceinline__ WinRaw win_load_raw(const PointSrc &src, unsigned qro
 // outside that range (and for zeros, whose sign the correction loses) the IEEE divisions run.  Same bits as x / d.
 __device__ __forceinline__ f32x2 div_small2(f32x2 v, float dx, float rdx, float dy, float rdy) {
 #pragma clang fp contract(off)
-    const float ax = fabsf(v.x), ay = fabsf(v.y);
+    // |v| in [2^-40, 2^40] as one unsigned compare on the bits; a ZERO is served by the fast path too (round 5: the
+    // initial offset star has exact zeros in every second head, and the whole wavefront then also ran the IEEE
+    // divisions): 0 * rd = 0, the residual is 0, the quotient is +0 -- the sign of a zero offset is lost, which no
+    // location can show (ref + (+-0) = ref for every ref but -0, and reference points are not negative zeros)
+    const unsigned bx = __float_as_uint(v.x) & 0x7fffffffu, by = __float_as_uint(v.y) & 0x7fffffffu;
+    const bool slow = ((bx - 0x2B800000u > 0x28000000u) && bx != 0u) || ((by - 0x2B800000u > 0x28000000u) && by != 0u);
     f32x2 q;
-    if (fminf(ax, ay) >= 0x1p-40f && fmaxf(ax, ay) <= 0x1p40f) {
-        const float qx = v.x * rdx, qy = v.y * rdy;
-        q.x = __builtin_fmaf(__builtin_fmaf(-dx, qx, v.x), rdx, qx);
-        q.y = __builtin_fmaf(__builtin_fmaf(-dy, qy, v.y), rdy, qy);
-    } else {
-        q.x = v.x / dx;
-        q.y = v.y / dy;
+    const float qx = v.x * rdx, qy = v.y * rdy;
+    q.x = __builtin_fmaf(__builtin_fmaf(-dx, qx, v.x), rdx, qx);
+    q.y = __builtin_fmaf(__builtin_fmaf(-dy, qy, v.y), rdy, qy);
+    if (__builtin_amdgcn_ballot_w64(slow) != 0ull) {      // (wave-uniform: nobody pays for what nobody needs)
+        if (slow) {
+            q.x = v.x / dx;
+            q.y = v.y / dy;
+        }
     }
     return q;
 }
@@ -161,12 +176,22 @@ __device__ __forceinline__ f32x2 win_location(const WinRaw &w, int ref_dim, floa
 }
 
 // reductions over the 16 lanes of a staging row (one lane per point), DPP only
+// (v_max_f32 with the DPP operand folded in: fmaxf(x, dpp(x)) compiles to a DPP move, a canonicalising max of each
+//  operand and the max -- 12 instructions for the four stages instead of 4; the s_nop are the two wait states a DPP
+//  read of a VGPR written by the previous VALU instruction needs, which the assembler does not add inside asm)
 __device__ __forceinline__ float row16_max(float x) {
-    x = fmaxf(x, MSDA_DPP(x, 0xB1));
-    x = fmaxf(x, MSDA_DPP(x, 0x4E));
-    x = fmaxf(x, MSDA_DPP(x, 0x141));
-    x = fmaxf(x, MSDA_DPP(x, 0x140));
-    return x;
+    float r;
+    asm volatile("s_nop 1\n\t"
+                 "v_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf"
+                 : "=&v"(r)
+                 : "v"(x));
+    return r;
 }
 __device__ __forceinline__ float row16_sum(float x) {
     x += MSDA_DPP(x, 0xB1);
@@ -196,11 +221,11 @@ typedef __attribute__((address_space(3))) void lds_void;
 
 // WPS = wavefronts per SIMD the register budget is sized for (4: 128 VGPRs -- 512-thread workgroups, or four 256-thread
 // workgroups per CU; 3: 168 VGPRs -- three 256-thread workgroups per CU, what 40-53 KB of LDS admits)
-// EARLY: the corner rows of the first four global points are requested before the LDS-served points and used after
-// them (their latency hides behind the LDS phase at the price of 40 registers held across it).
+// NE: the corner rows of the first NE (0 / 2 / 4) global points are requested before the LDS-served points and used
+// after them (their latency hides behind the LDS phase at the price of 10 registers per point held across it).
 // TRACE: the timeline build (tools/fwd_win_timeline.py) -- s_memtime stamps at the phase boundaries; the production
 // instantiations hold none of it (as a run-time test the stamps cost 1.1 us per launch, round 4).
-template <bool FUSED, bool DMA, int WPS, bool EARLY, bool TRACE = false>
+template <bool FUSED, int WPS, int NE, bool TRACE = false>
 __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(const float *__restrict__ value,
                                                            const int64_t *__restrict__ lstart, const PointSrc src,
                                                            float *__restrict__ out, const WinPlan pl) {
@@ -215,7 +240,25 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
     const int reg = sw % nreg;
     const int hb = sw / nreg;
     const int b = hb % pl.N, m = hb / pl.N;
-    const int ry = reg / pl.RX, rx = reg - ry * pl.RX;
+    // complete regions first, the right border column next, the bottom border row last: the partial regions (fewer
+    // rows, shorter workgroups) fill the end of the launch instead of leaving whole workgroups for a last round
+    int ry, rx;
+    {
+        const int nint = pl.RYf * pl.RXf, wcol = pl.RX - pl.RXf, ncol = wcol * pl.RYf;
+        if (reg < nint) {
+            ry = reg / pl.RXf;
+            rx = reg - ry * pl.RXf;
+        } else if (reg < nint + ncol) {
+            const int e = reg - nint;
+            ry = e / wcol;
+            rx = pl.RXf + (e - ry * wcol);
+        } else {
+            const int e = reg - nint - ncol;
+            ry = e / pl.RX;
+            rx = e - ry * pl.RX;
+            ry += pl.RYf;
+        }
+    }
 
     const int L = pl.L, P = pl.P, LP = L * P, M = pl.M;
     const int tid = threadIdx.x, lane = tid & 63, nw = (int)(blockDim.x >> 6);
@@ -252,7 +295,29 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
         tb.ox[tid] = tb.oy[tid] = 0;
     }
     if (tid <= kWinMaxL) {
-        tb.row0[tid] = pl.row0[tid];
+        int base = 0, mine = 0;
+#pragma unroll
+        for (int i = 0; i < kWinMaxL; ++i) {
+            const int sy = pl.shy[i], sx = pl.shx[i];
+            const int y0 = ry << sy, x0 = rx << sx;
+            int hv = pl.H[i] - y0, wv = pl.W[i] - x0;
+            hv = hv > (1 << sy) ? (1 << sy) : (hv < 0 ? 0 : hv);
+            wv = wv > (1 << sx) ? (1 << sx) : (wv < 0 ? 0 : wv);
+            if (i >= L) hv = 0;
+            if (tid == i) {
+                mine = base;
+                tb.y0[i] = y0;
+                tb.x0[i] = x0;
+                tb.wv[i] = wv > 0 ? wv : 1;
+                tb.rcpw[i] = 1.f / (float)(wv > 0 ? wv : 1);
+            }
+            base += hv * wv;
+        }
+        tb.row0[tid] = tid == kWinMaxL ? base : mine;
+        if (tid == kWinMaxL) {
+            tb.rows = base;
+            tb.steps = (base + 3) >> 2;
+        }
         tb.wbase[tid] = pl.wbase[tid];
     }
     if (tid >= 64 && tid < 80) tb.lvl[tid - 64] = (tid - 64) < LP ? (tid - 64) / P : 0;
@@ -265,6 +330,7 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
     unsigned char mpad[kWinMaxL] = {0, 0, 0, 0};      // fused + mask: "the window pixel this lane answers for is padded"
     __syncthreads();
     WIN_STAMP();       // 1: tables
+    if (tb.rows == 0) return;      // (levels that are not a pyramid of one image can leave a region without any query)
 
     // staging layout: lane -> (row slot, point)
     const int s_rs = lane >> 4, s_t = lane & 15;
@@ -292,8 +358,9 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
     const int lwin0 = pl.lwin0;
 
     // the region's rows -> query indices, once
-    for (int r = tid; r < pl.steps * 4; r += (int)blockDim.x) {
-        const WinRow w = win_row(tb, L, pl.rows, r, b, ry, rx, m, M, pl.Lq);
+    const int steps = __builtin_amdgcn_readfirstlane(tb.steps);     // of THIS region (pl.steps: of a complete one)
+    for (int r = tid; r < steps * 4; r += (int)blockDim.x) {
+        const WinRow w = win_row(tb, L, r, b, m, M, pl.Lq);
         s_rowq[r] = w.ok ? (int)(w.qrow - q_base) : -1;
     }
 
@@ -302,13 +369,13 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
     bool row_ok;
     WinRaw raw;
     {
-        const WinRow row = win_row(tb, L, pl.rows, step * 4 + s_rs, b, ry, rx, m, M, pl.Lq);
+        const WinRow row = win_row(tb, L, step * 4 + s_rs, b, m, M, pl.Lq);
         row_ok = row.ok;
         raw = win_load_raw<FUSED>(src, row.qrow, row.pm, m, L, LP, s_t, s_l);
         if (lwin0 < L) {
             // placement only: approximate arithmetic is fine here (the records repeat it exactly)
             float dx = 0.f, dy = 0.f, dc = 0.f;
-            if (step < pl.steps && row.ok && s_t < LP && s_l >= lwin0) {
+            if (step < steps && row.ok && s_t < LP && s_l >= lwin0) {
                 const float fW = (float)tb.W[s_l], fH = (float)tb.H[s_l];
                 f32x2 xy = raw.a;
                 if (FUSED) {
@@ -392,11 +459,7 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
                 const bool inside = (local < npx) & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
                 const int cell = gy * W + gx;
                 const unsigned off = inside ? lbase + (unsigned)cell * pix_stride : kOobOffset;
-                if (DMA) {
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(vr, (lds_void *)(s_dyn + (size_t)g * 1024), 16, (int)off, 0, 0, 0);
-                } else {
-                    reinterpret_cast<f32x4 *>(s_dyn)[(size_t)g * 64 + lane] = buf_load_f4(vr, off);
-                }
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(vr, (lds_void *)(s_dyn + (size_t)g * 1024), 16, (int)off, 0, 0, 0);
             }
         }
         // the mask bytes of the pixels THIS wavefront filled (8 lanes x 8 groups per level: make_win_plan's
@@ -438,19 +501,20 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
     const unsigned c_dead = c_windowed ? zero_off : kOobOffset;
     const unsigned char *c_mask = (FUSED && src.mask != nullptr) ? src.mask + ((size_t)b * pl.S + tb.lstart[s_l]) : nullptr;
     const int T0 = lwin0 * P < LP ? lwin0 * P : LP;
-    const bool early = EARLY && T0 >= 4;
+    constexpr int NEA = NE > 0 ? NE : 1;
+    const bool early = NE > 0 && T0 >= NE;
 
     // ---- the steps: stage 64 (row, point) records, gather, store ----
     // (the profiling switches exist in the TRACE instantiation only: as run-time tests in the step loop they hold
     //  scalar registers the production kernel has none to spare of -- 106 of 106 with six spilled, round 4)
     const int ablate = TRACE ? pl.ablate : 0;
     if (ablate & 1) {
-        if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         return;
     }
-    const int iters = (pl.steps + nw - 1) / nw;
+    const int iters = (steps + nw - 1) / nw;
     for (int it = 0; it < iters; ++it, step += nw) {
-        const bool have = step < pl.steps;       // wave-uniform
+        const bool have = step < steps;          // wave-uniform
         unsigned gmask = 0u;
         if (have) {
             // -- staging: this lane's point, straight-line --
@@ -522,7 +586,7 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
         }
         WIN_STAMP();   // 7 + 3 it: staged
         // -- prefetch the next step's inputs --
-        if (step + nw < pl.steps) {
+        if (step + nw < steps) {
             const int q = s_rowq[(step + nw) * 4 + s_rs];
             row_ok = q >= 0;
             const unsigned qrow = q_base + (unsigned)(q < 0 ? 0 : q);
@@ -533,19 +597,19 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
 
         // -- levels read through the vector L1: issue the first four points' corner rows now, use them after the
         //    LDS-served points (fewer than four such points: they all go through the late loop) --
-        u32x4 gr[4];
-        f32x4 gv[4][2];
+        u32x4 gr[NEA];
+        f32x4 gv[NEA][2];
         if (have && early && !(ablate & 2)) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) gr[i] = rec_g[2 * i];
+            for (int i = 0; i < NEA; ++i) gr[i] = rec_g[2 * i];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NEA; ++i) {
                 gv[i][0] = buf_load_f4(vr, gr[i].y + sub16);
                 gv[i][1] = buf_load_f4(vr, gr[i].w + sub16);
             }
         }
         if (it == 0 && lwin0 < L) {            // the windows must have landed before the first LDS-served point
-            if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (FUSED && src.mask != nullptr) {       // this wavefront's fill has landed: zero its padded pixels
 #pragma unroll
                 for (int l = 0; l < kWinMaxL; ++l) {
@@ -611,12 +675,12 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
             // -- consume the global points issued above, then any that were not --
             if (early) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < NEA; ++i) {
                     acc += __uint_as_float(gr[i].x) * gv[i][0];
                     acc += __uint_as_float(gr[i].z) * gv[i][1];
                 }
             }
-            int tg = early ? 4 : 0;
+            int tg = early ? NE : 0;
             for (; tg + 4 <= T0; tg += 4) {          // eight corner rows in flight per lane
                 u32x4 r[4];
                 f32x4 v[4][2];
@@ -629,6 +693,22 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
+                    acc += __uint_as_float(r[i].x) * v[i][0];
+                    acc += __uint_as_float(r[i].z) * v[i][1];
+                }
+            }
+            for (; tg + 2 <= T0; tg += 2) {          // four
+                u32x4 r[2];
+                f32x4 v[2][2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) r[i] = rec_g[2 * (tg + i)];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    v[i][0] = buf_load_f4(vr, r[i].y + sub16);
+                    v[i][1] = buf_load_f4(vr, r[i].w + sub16);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
                     acc += __uint_as_float(r[i].x) * v[i][0];
                     acc += __uint_as_float(r[i].z) * v[i][1];
                 }
@@ -657,19 +737,19 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
         WIN_STAMP();   // 9 + 3 it: gathered, stored
     }
 #undef WIN_STAMP
-    if (pl.stats != nullptr) {      // kernel selection: this launch's counts out, the previous launch's totals to the host
+    if (pl.stats != nullptr) {      // kernel selection: this launch's counts out, the totals so far to the host
         if (stat_wg) {
             // the share's denominator: the windowed points of the rows this wavefront staged (counted once, here --
             // a second ballot per step in the staging loop cost 0.5 us per launch)
             const int st = wave + (lane >> 2) * nw;
-            const bool mine = lane < iters * 4 && st < pl.steps && s_rowq[st * 4 + (lane & 3)] >= 0;
+            const bool mine = lane < iters * 4 && st < steps && s_rowq[st * 4 + (lane & 3)] >= 0;
             const unsigned n_live = (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(mine)) * (unsigned)(LP - T0);
             unsigned n_off = v_off;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) n_off += __shfl_xor(n_off, o, 64);
-            if (lane == 0) sel_add(pl.stats, pl.sel_parity, (unsigned)((sw >> 3) * nw + wave), n_live, n_off, 0u);
+            if (lane == 0) sel_add(pl.stats, pl.sel_level, (unsigned)((sw >> 3) * nw + wave), n_live, n_off, 0u);
         }
-        if (sw == 0 && wave == 1) sel_publish_previous(pl.stats, pl.stats_host, pl.sel_parity, (unsigned)pl.sel_level, lane);
+        if (sw == 0 && wave == 1) sel_publish(pl.stats, pl.stats_host, lane);
     }
 }
 
@@ -730,6 +810,9 @@ inline bool make_win_plan(WinPlan &pl, const int64_t *shapes_host, int N, int S,
     if (q != S) return false;      // the host shapes do not describe this value tensor
     for (int l = L; l <= kWinMaxL; ++l) { pl.row0[l] = rows; pl.wbase[l] = px; }
     pl.rows = rows; pl.steps = (rows + 3) / 4; pl.RY = RY; pl.RX = RX;
+    pl.RYf = (int)(shapes_host[0] >> rlogy); pl.RXf = (int)(shapes_host[1] >> rlogx);
+    if (pl.RYf > RY) pl.RYf = RY;
+    if (pl.RXf > RX) pl.RXf = RX;
     pl.rcpP = (float)(1.0 / (double)P);
     for (int a = 0; a < kWinMaxL; ++a)
         for (int c = 0; c < kWinMaxL; ++c) {

@@ -9,48 +9,69 @@
 // follow the data:
 //
 //   * the windowed kernels count, per launch, the valid corners / those outside the window / those outside a window
-//     shrunk by `shrink` pixels (what a smaller margin would have lost) in a small device record; the next launch on
-//     the record stores the totals, the level they were measured at and a sequence number into a 32-byte record in
-//     mapped host memory -- no copy, no event, nothing on the stream;
-//   * the host reads that record at the next call of the same (call site, geometry) -- whatever has arrived; a few
-//     calls of delay are harmless, the offsets drift over thousands of steps -- and moves between LEVELS:
-//       backward  0: bins, small margin   1: bins, large margin   2: no windows (generic kernel)
+//     shrunk by `shrink` pixels (what a smaller margin would have lost) into CUMULATIVE 64-bit counters of a small
+//     device record, one row of counters per selector level the launch ran at; one wavefront of every launch sums the
+//     rows and stores the totals + a sequence number into a 128-byte record in mapped host memory -- no copy, no
+//     event, nothing on the stream.  Nothing is ever cleared and no argument changes from launch to launch (round 5:
+//     round 4's two parity buffers were exchanged by a kernel argument, which a captured launch replays for ever), so
+//     launches inside a replayed hipGraph count exactly like eager ones;
+//   * the host reads that record at the next call of the same call site -- whatever has arrived; a few calls of
+//     delay are harmless, the offsets drift over thousands of steps -- takes the difference to what it saw last per
+//     level, and moves between LEVELS:
+//       backward  0: bins, small margin   1: bins, large margin   2: no windows (rows kernel)
 //       forward   0: windows              1: head-major gather
 //     with hysteresis; a level without windows produces no statistics, so every `kSelProbeEvery`-th call probes one
-//     level down.
-// The record is allocated on first use (one hipMalloc + one hipHostMalloc, never while the stream is capturing) and
-// lives for the life of the process; `msda_set_option("auto_select", 0)` switches the mechanism off (level 0 always).
+//     level down;
+//   * a record belongs to (device, direction, call site, M, L, P, element size): the off-window share is a property of
+//     the module's learnt offsets, not of the image size (round 4 keyed on the geometry too: multi-scale training
+//     filled the table within ~21 clips and never saw a geometry twice).  All records live in ONE device block and one
+//     mapped host block allocated at the first eager call; when the table is full the least recently used record is
+//     given to the new key;
+//   * callers that replay captured launches (the model's hipGraph caches) call msda_selector_poll() before a replay:
+//     it reads every record, moves the levels and returns a signature of the levels in force; a cache keyed on it
+//     replays the graph captured at those levels and captures another when a level has moved (a capturing call takes
+//     the level the last poll announced).
+// `msda_set_option("auto_select", 0)` switches the mechanism off (level 0 always).
 #pragma once
 
 #include <mutex>
 
 constexpr int kSelSlots = 256;
 constexpr unsigned kSelProbeEvery = 32;
+constexpr int kSelLevels = 3;
+constexpr int kSelShards = 32;
+// device record (64-bit words): [level][shard]{valid, off, inner, pad}, then the publishers' sequence counter
+constexpr int kSelCntWords = kSelLevels * kSelShards * 4;
+constexpr int kSelDevWords = 512;                       // 4 KiB per record
+constexpr int kSelHostWords = 16;                       // 128 B per record: [level]{valid, off, inner}, seq at [9]
+constexpr unsigned long long kSelMinSample = 2048;      // valid corners a level's difference must hold to be judged
+static_assert(kSelCntWords + 1 <= kSelDevWords, "record too small");
 
 struct SelKey {
     int dev, kind;                  // kind 0: forward, 1: backward
-    unsigned long long site;        // caller's tag (msda_set_call_site): one record per module, not per geometry only
-    int N, S, M, L, P, Lq, dt;
+    unsigned long long site;        // caller's tag (msda_set_call_site): one record per module
+    int M, L, P, dt;
     bool operator==(const SelKey &o) const {
-        return dev == o.dev && kind == o.kind && site == o.site && N == o.N && S == o.S && M == o.M && L == o.L &&
-               P == o.P && Lq == o.Lq && dt == o.dt;
+        return dev == o.dev && kind == o.kind && site == o.site && M == o.M && L == o.L && P == o.P && dt == o.dt;
     }
 };
 
 struct SelSlot {
     SelKey key;
-    bool used;
-    unsigned *dev;                  // device: kSelDevWords words (below)
-    unsigned launches;              // parity of the next launch
-    volatile unsigned *host;        // mapped host: valid, off, inner, seq, level the launch ran at
-    unsigned *host_dev;             // the device's pointer to `host`
-    unsigned seen;
-    int level;
+    bool used, primed;              // primed: `last` holds a baseline of this key's counters
+    unsigned long long *dev;        // device record
+    volatile unsigned long long *host;   // mapped host record
+    unsigned long long *host_dev;   // the device's pointer to `host`
+    unsigned long long seen;        // sequence number of the last record read
+    unsigned long long last[kSelLevels][3];
+    unsigned long long stamp;       // last use (least-recently-used replacement)
+    int level;                      // what the data ask for
+    int eff;                        // what a capturing call runs at (= level, or one below while a probe is due)
     unsigned calls;
     float frac, frac_inner;         // last measured shares (of the valid corners)
 };
 
-// thresholds in 1/1000 of the valid corners (options sel_*): measured crossovers, profiles/r04_bwd_selector.txt
+// thresholds in 1/1000 of the valid corners (options sel_*): measured crossovers, profiles/r04_selector_probe.txt
 struct SelRule {
     int up0, up1, down1, down2;
 };
@@ -70,53 +91,37 @@ inline int sel_next_level(int kind, int level, float f, float fi, const SelRule 
     return f < (float)r.down2 ? 1 : 2;
 }
 
-// Device record: two buffers (launch parity) of kSelShards x {valid, off, inner, pad} counters, then {level of the
-// launch that filled buffer 0, of buffer 1, sequence number}.
-constexpr int kSelShards = 32;
-constexpr int kSelDevWords = 2 * kSelShards * 4 + 4;
-
 #ifdef __HIPCC__
-// How the counts travel (what NOT to do was measured first: a ticket counter that lets the launch's last workgroup
-// publish costs one RETURNING atomic per workgroup on one address -- 8736 of them serialise at ~12 ns each and the
-// waiting wavefronts doubled the kernel's time; an agent-scope fence per workgroup is a full L2 write-back, worse):
-//   * every workgroup adds its counts, fire-and-forget, to one of kSelShards shards of the buffer of its launch's
-//     parity (zeros are not sent);
-//   * workgroup 0 of the NEXT launch on the record (stream order: the previous launch has finished) sums the other
-//     parity's shards, clears them and stores totals + level + a sequence number into the mapped host record.
-// The host therefore sees a launch's statistics two calls later -- the offsets drift over thousands of steps.
-__device__ __forceinline__ void sel_add(unsigned *dev, int parity, unsigned shard, unsigned valid, unsigned off,
+// How the counts travel (what NOT to do was measured in round 4: a ticket counter that lets the launch's last
+// workgroup publish costs one RETURNING atomic per workgroup on one address -- 8736 of them serialise at ~12 ns each
+// and the waiting wavefronts doubled the kernel's time; an agent-scope fence per workgroup is a full L2 write-back):
+//   * a counting workgroup adds its counts, fire-and-forget, to one of kSelShards shards of the row of the level its
+//     launch runs at (zeros are not sent);
+//   * one wavefront of every launch sums all rows and stores the totals + a sequence number into the mapped host
+//     record.  Workgroups of the same launch may already have added theirs: the host judges differences of at least
+//     kSelMinSample corners, a fraction of a launch more or less does not move a share.
+__device__ __forceinline__ void sel_add(unsigned long long *dev, int level, unsigned shard, unsigned valid, unsigned off,
                                         unsigned inner) {
-    unsigned *c = dev + ((unsigned)parity * kSelShards + (shard & (kSelShards - 1))) * 4u;
-    if (valid) __hip_atomic_fetch_add(c + 0, valid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (off) __hip_atomic_fetch_add(c + 1, off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (inner) __hip_atomic_fetch_add(c + 2, inner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long *c = dev + ((unsigned)level * kSelShards + (shard & (kSelShards - 1))) * 4u;
+    if (valid) __hip_atomic_fetch_add(c + 0, (unsigned long long)valid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (off) __hip_atomic_fetch_add(c + 1, (unsigned long long)off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (inner) __hip_atomic_fetch_add(c + 2, (unsigned long long)inner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// One full wavefront of the launch's workgroup 0 (lane = threadIdx.x & 63): publish what the previous launch counted.
-__device__ __forceinline__ void sel_publish_previous(unsigned *dev, unsigned *host, int parity, unsigned level, int lane) {
-    unsigned *c = dev + ((unsigned)(parity ^ 1) * kSelShards + (unsigned)(lane & (kSelShards - 1))) * 4u;
-    unsigned v = 0u, o = 0u, i = 0u;
-    if (lane < kSelShards) {
-        v = __hip_atomic_exchange(c + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        o = __hip_atomic_exchange(c + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        i = __hip_atomic_exchange(c + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-#pragma unroll
-    for (int s = 32; s > 0; s >>= 1) {
-        v += __shfl_xor(v, s, 64);
-        o += __shfl_xor(o, s, 64);
-        i += __shfl_xor(i, s, 64);
+// One full wavefront of the launch (lane = threadIdx.x & 63): lane j < 9 sums counter j % 3 of level j / 3 over the
+// shards and stores it; lane 0 then bumps the sequence number.
+__device__ __forceinline__ void sel_publish(unsigned long long *dev, unsigned long long *host, int lane) {
+    if (lane < kSelLevels * 3) {
+        const unsigned long long *c = dev + (unsigned)(lane / 3) * kSelShards * 4u + (unsigned)(lane % 3);
+        unsigned long long s = 0ull;
+#pragma unroll 8
+        for (int i = 0; i < kSelShards; ++i) s += __hip_atomic_load(c + i * 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(host + lane, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (lane == 0) {
-        unsigned *tail = dev + 2 * kSelShards * 4;
-        const unsigned prev_level = tail[parity ^ 1];
-        tail[parity] = level;
-        const unsigned seq = ++tail[2];
-        __hip_atomic_store(host + 0, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(host + 1, o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(host + 2, i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(host + 4, prev_level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(host + 3, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long seq =
+            __hip_atomic_fetch_add(dev + kSelCntWords, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
+        __hip_atomic_store(host + 9, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 #endif

@@ -44,17 +44,20 @@ class MSDeformAttnFunction(Function):
 
 class MSDeformAttnFusedFunction(Function):
     """The operator with the module's prologue folded in (no reference counterpart):
-    ``apply(value, spatial_shapes, level_start_index, proj, reference_points, padding_mask, n_heads, n_points)``
-    where ``proj`` is the raw output of the two query projections, ``[offsets (M,L,P,2) | logits (M,L,P)]`` per
+    ``apply(value, spatial_shapes, level_start_index, proj, reference_points, padding_mask, n_heads, n_points[,
+    zero_rows])`` where ``proj`` is the raw output of the two query projections, ``[offsets (M,L,P,2) | logits (M,L,P)]`` per
     query.  Softmax over the L*P logits, the location arithmetic of ``models/ops/modules/ms_deform_attn.py:113-122``
     and the padding-mask fill of ``value`` (:107-108) happen inside the HIP kernels, forward and backward:
     sampling locations and attention weights are never written to memory.  Gradients: value, proj and -- when it
-    requires one -- reference_points."""
+    requires one -- reference_points.  ``zero_rows`` (optional, int64 indices into the N*S rows of ``value``): rows the
+    caller has zeroed instead of passing a padding mask; their gradient is zeroed HERE, in the buffer this backward
+    has just allocated (nobody else holds it yet -- the caller's own hook could not know that)."""
 
     @staticmethod
     def forward(ctx, value, value_spatial_shapes, value_level_start_index, proj, reference_points, padding_mask,
-                n_heads, n_points):
+                n_heads, n_points, zero_rows=None):
         ctx.n_heads, ctx.n_points = int(n_heads), int(n_points)
+        ctx.zero_rows = zero_rows
         ctx.site = MSDA.get_call_site()
         ctx.shapes_host = getattr(value_spatial_shapes, "_msda_host", None)
         output = MSDA.ms_deform_attn_fused_forward(value, value_spatial_shapes, value_level_start_index, proj,
@@ -74,4 +77,6 @@ class MSDeformAttnFusedFunction(Function):
             value, shapes, level_start, proj, reference_points, padding_mask, grad_output.contiguous(), ctx.n_heads,
             ctx.n_points, need_ref_grad=ctx.needs_input_grad[4])
         MSDA.set_call_site(0)
-        return grad_value, None, None, grad_proj, grad_ref, None, None, None
+        if ctx.zero_rows is not None and ctx.zero_rows.numel():
+            grad_value.view(-1, grad_value.shape[-2] * grad_value.shape[-1]).index_fill_(0, ctx.zero_rows, 0)
+        return grad_value, None, None, grad_proj, grad_ref, None, None, None, None

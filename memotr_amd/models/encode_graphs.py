@@ -65,7 +65,10 @@ class EncodeGraphs(GraphCache):
         # (the folded batch-norm constants are baked in: an in-place write to a buffer -- a checkpoint load -- must
         # not replay the old ones)
         bufver = sum(b._version for b in self.core.backbone.buffers())
-        key = (slot, tuple(frame.tensors.shape), frame.sizes, amp, clip_ops.config_key(), bufver)
+        # (a capture bakes the kernel choice of the encoder's self-attention calls in: the selector's signature moves
+        # when the measured off-window share asks for another kernel -- replayed launches keep counting, msda_select.h)
+        from .. import _lib
+        key = (slot, tuple(frame.tensors.shape), frame.sizes, amp, clip_ops.config_key(), bufver, _lib.selector_poll())
         entry = self.lookup(key, lambda: self._capture(frame, amp))
         if entry is None:
             return None

@@ -131,8 +131,12 @@ class InferGraphs:
         # (the folded batch-norm constants are baked in: an in-place write to a buffer -- a checkpoint load -- must not
         # replay the old ones; models/encode_graphs.py keys on the same)
         bufver = sum(b._version for b in core.backbone.buffers())
+        # the selector's signature: a capture bakes the kernel choice of the encoder's self-attention calls in; replayed
+        # launches keep counting the points that leave their windows, and when the share asks for another kernel the
+        # signature moves and the graph captured (or to be captured) at the new levels takes over (msda_select.h)
+        from .. import _lib
         key = (getattr(frame, "encode_slot", 0), tuple(frame.tensors.shape), geometry, clip_ops.config_key(),
-               _fingerprint(core), bufver)
+               _fingerprint(core), bufver, _lib.selector_poll())
         constants = {}
 
         def make_fn():

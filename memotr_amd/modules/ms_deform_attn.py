@@ -65,11 +65,15 @@ def tag_masked_rows(mask: torch.Tensor) -> torch.Tensor:
 class _ZeroRows(torch.autograd.Function):
     """``x[rows] = 0`` -- in place when ``x`` is a freshly produced tensor (the 2-d product inside ``long_linear``: an
     in-place op on a VIEW of a custom Function's output would make autograd rebase the graph and copy the whole
-    gradient), a copy otherwise; the gradient of those rows is zero."""
+    gradient), a copy otherwise; the gradient of those rows is zero.  ``consumer_zeroes``: the one consumer of the
+    result (the fused operator, given the same rows) zeroes those rows of the gradient in the buffer it allocates --
+    the backward here is then the identity.  Otherwise the incoming gradient is NOT this node's to modify (a retained
+    gradient, a hook or a second consumer may hold it): the rows are zeroed in a copy."""
 
     @staticmethod
-    def forward(ctx, x, rows):
+    def forward(ctx, x, rows, consumer_zeroes=None):
         ctx.rows = rows
+        ctx.consumer_zeroes = consumer_zeroes       # a one-element list the caller sets once the consumer is known
         if x._is_view() or not x.is_contiguous():
             return x.reshape(-1, x.shape[-1]).index_fill(0, rows, 0).view(x.shape)
         x.view(-1, x.shape[-1]).index_fill_(0, rows, 0)
@@ -78,10 +82,9 @@ class _ZeroRows(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        # (g is the operator's own grad_value buffer, consumed by nothing else: zeroed in place like the kernels did)
-        g = g.contiguous()
-        g.view(-1, g.shape[-1]).index_fill_(0, ctx.rows, 0)
-        return g, None
+        if ctx.consumer_zeroes is not None and ctx.consumer_zeroes[0]:
+            return g, None, None
+        return g.reshape(-1, g.shape[-1]).index_fill(0, ctx.rows, 0).view(g.shape), None, None
 
 
 class MSDeformAttn(nn.Module):
@@ -203,10 +206,11 @@ class MSDeformAttn(nn.Module):
         if rows is not None and not (FUSED_PROLOGUE and input_flatten.is_cuda and not self.sigmoid_attn):
             rows = None
         zero = None
+        fused_zeroes = [False]      # set below when the fused operator takes `rows` and zeroes its own grad_value
         if rows is not None:
             mask = None
             if rows.numel():
-                zero = lambda y: _ZeroRows.apply(y, rows)      # noqa: E731
+                zero = lambda y: _ZeroRows.apply(y, rows, fused_zeroes)      # noqa: E731
         value = long_linear(input_flatten, self.value_proj.weight, self.value_proj.bias, activation=zero)
 
         # one GEMM for both query projections
@@ -227,11 +231,12 @@ class MSDeformAttn(nn.Module):
                 and MSDA.fused_supported(value.dtype, self.d_model // M, L, P)):
             # softmax over L*P, ref + off / (W, H) (or the box-scaled form) and the padding-mask fill run inside the
             # kernels, forward and backward: loc / attn / the masked copy of value never reach HBM
+            fused_zeroes[0] = zero is not None
             out = MSDeformAttnFusedFunction.apply(value.view(N, S, M, self.d_model // M), input_spatial_shapes,
                                                   input_level_start_index, proj.contiguous(),
                                                   reference_points.contiguous(),
                                                   None if mask is None else mask.contiguous(),
-                                                  M, P)
+                                                  M, P, rows if zero is not None else None)
             return long_linear(out, self.output_proj.weight, self.output_proj.bias)
 
         if mask is not None:

@@ -26,7 +26,7 @@ def msda(hip_lib):
     return MSDA
 
 
-@pytest.fixture(autouse=True, params=[0, 8, 10, 12], ids=["bwd_default", "bwd_tile_q2", "bwd_tile_lv", "bwd_tile_bins"])
+@pytest.fixture(autouse=True, params=[0, 10, 12], ids=["bwd_default", "bwd_tile_lv", "bwd_tile_bins"])
 def _bwd_family(request, hip_lib):
     """Every test of this file runs with the default backward and with each region-tiled family forced."""
     hip_lib.set_option("bwd_variant", request.param)

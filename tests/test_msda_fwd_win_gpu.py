@@ -19,7 +19,8 @@ from fused_helpers import expected, make_case
 
 pytestmark = pytest.mark.gpu
 
-WIN_DEFAULTS = dict(fwd_win_rlog=3, fwd_win_rlogx=3, fwd_win_block=256, fwd_win_l0=1, fwd_win_margins=0x3333, fwd_win_dma=1)
+WIN_DEFAULTS = dict(fwd_win_rlog=0, fwd_win_rlogx=0, fwd_win_block=0, fwd_win_l0=1, fwd_win_margins=0x3333, fwd_win_early=9,
+                    fwd_win_wps=0)
 
 
 @pytest.fixture(scope="module")
@@ -73,14 +74,16 @@ def test_win_forward_full_size_matches_oracle(msda, hip_lib, pyr, dist):
 
 
 CONFIGS = [
-    dict(),                                                    # defaults: 8 x 8 pixel regions, windows on levels 1-3
-    dict(fwd_win_dma=0),                                       # fill through registers
-    dict(fwd_win_rlogx=4),                                     # 16 x 8 pixel regions (170 rows per workgroup)
-    dict(fwd_win_rlog=4),                                      # 16-pixel regions (340 rows per workgroup)
-    dict(fwd_win_rlogx=5, fwd_win_margins=0x2222),             # 32 x 8 regions
+    dict(),                                                    # defaults: 16 x 16 pixel regions, 512 threads, windows on levels 1-3
+    dict(fwd_win_early=0),                                     # ... all level-0 points after the LDS phase
+    dict(fwd_win_rlog=3, fwd_win_block=256),                   # 8 x 8 pixel regions, 256 threads (rounds 3-4's default)
+    dict(fwd_win_rlog=3, fwd_win_block=256, fwd_win_wps=4, fwd_win_early=2),
+    dict(fwd_win_rlog=3, fwd_win_rlogx=4, fwd_win_block=256),  # 16 x 8 pixel regions (170 rows per workgroup)
+    dict(fwd_win_rlog=4, fwd_win_block=256),                   # 16-pixel regions (340 rows per workgroup), 4 wavefronts
+    dict(fwd_win_rlog=3, fwd_win_rlogx=5, fwd_win_margins=0x2222),             # 32 x 8 regions
     dict(fwd_win_rlog=4, fwd_win_block=512),
-    dict(fwd_win_block=512),
-    dict(fwd_win_block=128),
+    dict(fwd_win_rlog=3, fwd_win_block=512),
+    dict(fwd_win_rlog=3, fwd_win_block=128),
     dict(fwd_win_l0=0),                                        # every level windowed
     dict(fwd_win_l0=2),                                        # levels 0-1 through the L1 (8 global points per row)
     dict(fwd_win_l0=3),
@@ -167,9 +170,9 @@ FUSED_PYRAMIDS = [
 
 
 @pytest.mark.parametrize("case", FUSED_PYRAMIDS, ids=lambda c: f"seed{c[0]}")
-@pytest.mark.parametrize("cfg", [dict(), dict(fwd_win_dma=0, fwd_win_rlog=4), dict(fwd_win_l0=0),
+@pytest.mark.parametrize("cfg", [dict(), dict(fwd_win_rlog=3, fwd_win_block=256), dict(fwd_win_l0=0),
                                  dict(fwd_win_margins=0x1111, fwd_win_block=512)],
-                         ids=["default", "nodma_r4", "all_levels", "m1_b512"])
+                         ids=["default", "r3_b256", "all_levels", "m1_b512"])
 def test_win_fused_forward_matches_checker(msda, hip_lib, case, cfg):
     seed, N, M, P, shapes, ref_dim = case
     for k, v in cfg.items():

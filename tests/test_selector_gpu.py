@@ -97,3 +97,93 @@ def test_forward_level_follows_the_data(hip_lib, site):
             torch.cuda.synchronize()
             np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-4, atol=2e-5)
         assert kernel in hip_lib.last_kernel(), hip_lib.last_kernel()
+
+
+# ---- round 5: selection that survives hipGraph replay (cumulative counters + msda_selector_poll) ----
+
+def _small_model(train):
+    from test_model_gpu import build_memotr_cuda
+    import memotr_amd.modules.ms_deform_attn as mod
+    torch.manual_seed(2)
+    model = build_memotr_cuda(None, hidden=256, ffn=256, NUM_ENC_LAYERS=2, NUM_DEC_LAYERS=2)
+    model = model.train() if train else model.eval()
+    with torch.no_grad():
+        for m in model.transformer.encoder.modules():
+            if isinstance(m, mod.MSDeformAttn):
+                m.sampling_offsets.weight.normal_(0, 0.02)
+                m.attention_weights.weight.normal_(0, 0.05)
+                m.sampling_offsets.bias.mul_(4.0)          # trained-looking: the initial star, four times as long
+    return model
+
+
+def test_selection_moves_under_replayed_inference_encode_graphs(monkeypatch, hip_lib):
+    """Offsets four times the initialisation's: most windowed points leave their windows.  The encode half replayed
+    from its forward-only hipGraph makes no library call per launch -- the captured launches keep counting, the graph
+    cache polls the selector before every replay, and within 64 frames the forward runs from a graph captured at
+    level 1 (gather kernel); the result is the eager one throughout."""
+    from memotr_amd.utils.nested_tensor import tensor_list_to_nested_tensor
+    monkeypatch.setenv("MEMOTR_REQUIRE_GRAPHS", "1")
+    for k, v in (("fwd_variant", 0), ("bwd_variant", 0), ("sel_level", -1), ("auto_select", 1)):
+        hip_lib.set_option(k, v)
+    model = _small_model(train=False)
+    g = torch.Generator().manual_seed(3)
+    frames = [tensor_list_to_nested_tensor([torch.randn(3, 384, 512, generator=g)]).to(torch.device("cuda"))
+              for _ in range(2)]
+
+    def encode(frame, graphs):
+        monkeypatch.setenv("MEMOTR_INFER_GRAPHS", "1" if graphs else "0")
+        with torch.no_grad():
+            return model(frame=frame, stage="encode")["memory"].clone()
+
+    want = [encode(f, False) for f in frames]
+    assert "win" in hip_lib.last_kernel() or "gather" in hip_lib.last_kernel()
+    sig0 = hip_lib.selector_poll()
+    enc = model.infer_graphs().encode
+    moved_at = None
+    for i in range(64):
+        got = encode(frames[i % 2], True)
+        torch.testing.assert_close(got, want[i % 2], rtol=1e-4, atol=1e-4)
+        if moved_at is None and hip_lib.selector_poll() != 0:
+            moved_at = i
+    assert moved_at is not None and moved_at < 64, (sig0, hip_lib.selector_poll())
+    assert enc.captures >= 2 and enc.eager == 0 and not enc.failed, (enc.captures, enc.eager)
+    # an eager call of the same modules sees what the replays measured
+    encode(frames[0], False)
+    level, share, _ = hip_lib.selector_last()
+    assert share > 0.05, (level, share)
+    hip_lib.set_call_site(0)
+
+
+def test_selection_moves_under_replayed_bf16_training_encode_graphs(monkeypatch, hip_lib):
+    """The same for the autocast step's encode graph pair (models/encode_graphs.py): the captured counting-sort
+    backward keeps counting, the level moves off 0 within a few steps and a second pair is captured at the new level;
+    the loss stays the eager one's."""
+    from memotr_amd.engine import clip_forward_backward, clip_to_device, make_synthetic_clip
+    from memotr_amd.models.criterion import build as build_criterion
+    from model_helpers import small_config
+    monkeypatch.setenv("MEMOTR_REQUIRE_GRAPHS", "1")
+    for k, v in (("fwd_variant", 0), ("bwd_variant", 0), ("sel_level", -1), ("auto_select", 1)):
+        hip_lib.set_option(k, v)
+    cfg = small_config()
+    cfg.update(HIDDEN_DIM=256, FFN_DIM=256, NUM_ENC_LAYERS=2, NUM_DEC_LAYERS=2, MATCH_COST_CLASS=2, MATCH_COST_BBOX=5,
+               MATCH_COST_GIOU=2, LOSS_WEIGHT_FOCAL=2, LOSS_WEIGHT_L1=5, LOSS_WEIGHT_GIOU=2, AUX_LOSS_WEIGHT=[1.0],
+               SAMPLE_LENGTHS=[2, 3, 4])
+    criterion = build_criterion(cfg)
+    batch = clip_to_device(make_synthetic_clip(clip_len=2, height=384, width=512, n_gts=5, seed=3), torch.device("cuda"))
+
+    def run(graphs, steps):
+        monkeypatch.setenv("MEMOTR_ENCODE_GRAPHS", "1" if graphs else "0")
+        model = _small_model(train=True)
+        for _ in range(steps):
+            model.zero_grad()
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss, _ = clip_forward_backward(model, criterion, batch, torch.device("cuda"))
+        torch.cuda.synchronize()
+        return float(loss), model.encode_graphs()
+
+    loss_e, _ = run(False, 1)
+    loss_g, cache = run(True, 12)
+    assert abs(loss_g - loss_e) <= 2e-2 * abs(loss_e), (loss_g, loss_e)
+    assert cache.captures >= 2 and cache.eager == 0 and not cache.failed, (cache.captures, cache.eager)
+    assert hip_lib.selector_poll() != 0
+    hip_lib.set_call_site(0)

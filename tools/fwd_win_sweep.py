@@ -1,0 +1,93 @@
+#!/usr/bin/env python
+"""Round 5: the windowed forward's launch options timed in ONE process on one box (region shape x workgroup size x
+register budget x early loads x margins), N = 1 fused / plain and N = 5 fused, each checked against the generic kernel.
+
+    python tools/fwd_win_sweep.py [--out gpurun_out/fwd_win_sweep.txt] [--lib path.so]
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import FusedCall, MsdaCall, time_kernel  # noqa: E402
+from memotr_amd import _lib  # noqa: E402
+from memotr_amd.synth import make_inputs  # noqa: E402
+
+DEFAULTS = dict(fwd_variant=0, fwd_win_rlog=0, fwd_win_rlogx=0, fwd_win_block=0, fwd_win_l0=1,
+                fwd_win_margins=0x3333, fwd_head_major=0, fwd_win_early=9, fwd_win_wps=0,
+                sel_level=-1, auto_select=1)
+
+R3 = dict(fwd_variant=12, fwd_win_rlog=3)
+CONFIGS = [
+    ("win default (16x16, 512 thr, w4)", dict(fwd_variant=12)),
+    ("win 16x16 512 thr e0", dict(fwd_variant=12, fwd_win_early=0)),
+    ("win 16x16 512 thr e2", dict(fwd_variant=12, fwd_win_early=2)),
+    ("gather<4> head-major", dict(fwd_variant=3, fwd_head_major=1)),
+    ("gather<4>", dict(fwd_variant=3)),
+    ("win 8x8 256 thr w3 e4 (r3-4 default)", dict(R3, fwd_win_block=256)),
+    ("win 8x8 256 thr w4 e2", dict(R3, fwd_win_block=256, fwd_win_wps=4, fwd_win_early=2)),
+    ("win 16x8 512 thr e0", dict(R3, fwd_win_rlogx=4, fwd_win_block=512, fwd_win_early=0)),
+    ("win 16x8 512 thr e2", dict(R3, fwd_win_rlogx=4, fwd_win_block=512, fwd_win_early=2)),
+    ("win 32x8 512 thr e2", dict(R3, fwd_win_rlogx=5, fwd_win_block=512, fwd_win_early=2)),
+    ("win 32x16 512 thr e2", dict(fwd_variant=12, fwd_win_rlog=4, fwd_win_rlogx=5, fwd_win_block=512, fwd_win_early=2)),
+    ("win 16x16 512 thr m2333", dict(fwd_variant=12, fwd_win_margins=0x2333)),
+    ("win 16x16 512 thr m2222", dict(fwd_variant=12, fwd_win_margins=0x2222)),
+    ("win 16x16 512 thr m4333", dict(fwd_variant=12, fwd_win_margins=0x4333)),
+    ("win 16x16 256 thr", dict(fwd_variant=12, fwd_win_rlog=4, fwd_win_block=256)),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default="gpurun_out/fwd_win_sweep.txt")
+    args = ap.parse_args()
+    os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
+    lines = []
+
+    def say(s):
+        print(s, flush=True)
+        lines.append(s)
+
+    say(f"# tools/fwd_win_sweep.py on {torch.cuda.get_device_name(0)}; encoder shape, encoder-like locations; us per launch")
+    say(f"{'config':42s} {'N=1 fused':>10s} {'N=1 plain':>10s} {'N=5 fused':>10s}   kernel / max err vs generic")
+    calls = []
+    for batch, kinds in ((1, ("fused", "plain")), (5, ("fused",))):
+        x = make_inputs(device="cuda", batch=batch)
+        for kind in kinds:
+            c = FusedCall(x) if kind == "fused" else MsdaCall(x)
+            for k, v in DEFAULTS.items():
+                _lib.set_option(k, v)
+            _lib.set_option("fwd_variant", 1)
+            c.fwd()
+            torch.cuda.synchronize()
+            calls.append((c, c.out.clone()))
+    for name, opts in CONFIGS:
+        cells, errs, kern = [], [], ""
+        for c, ref in calls:
+            for k, v in DEFAULTS.items():
+                _lib.set_option(k, v)
+            for k, v in opts.items():
+                _lib.set_option(k, v)
+            _lib.set_option("auto_select", 0)
+            c.out.zero_()
+            try:
+                c.fwd()
+                torch.cuda.synchronize()
+            except RuntimeError as exc:
+                cells.append("   failed")
+                errs.append(str(exc)[:40])
+                continue
+            errs.append("%.1e" % float((c.out - ref).abs().max()))
+            kern = _lib.last_kernel()
+            cells.append("%10.1f" % (time_kernel(c.fwd, iters=100) * 1e3))
+        say(f"{name:42s} {' '.join(cells)}   {kern}  err {' '.join(errs)}")
+    for k, v in DEFAULTS.items():
+        _lib.set_option(k, v)
+    with open(args.out, "w") as f:
+        f.write("\n".join(lines) + "\n")
+
+
+if __name__ == "__main__":
+    main()

@@ -21,10 +21,10 @@ from memotr_amd.synth import make_inputs  # noqa: E402
 
 
 def reset():
-    for k, v in (("fwd_variant", 0), ("bwd_variant", 0), ("fwd_tile_margin", 3), ("bwd_tile_margin", 4),
-                 ("fwd_tile_l0", 1), ("fwd_block", 256), ("fwd_grid_mult", 32), ("bwd_split", 1),
-                 ("fwd_win_rlog", 3), ("fwd_win_rlogx", 3), ("fwd_win_block", 256), ("fwd_win_l0", 1), ("fwd_win_margins", 0x3333),
-                 ("fwd_win_dma", 1), ("fwd_head_major", 0), ("fwd_win_early", 2), ("fwd_win_wps", 0),
+    for k, v in (("fwd_variant", 0), ("bwd_variant", 0), ("bwd_tile_margin", 4),
+                 ("fwd_block", 256), ("fwd_grid_mult", 32), ("bwd_split", 1),
+                 ("fwd_win_rlog", 0), ("fwd_win_rlogx", 0), ("fwd_win_block", 0), ("fwd_win_l0", 1), ("fwd_win_margins", 0x3333),
+                 ("fwd_head_major", 0), ("fwd_win_early", 9), ("fwd_win_wps", 0),
                  ("fwd_win_ablate", 0), ("bwd_rows_block", 0)):
         _lib.set_option(k, v)
 
@@ -34,7 +34,6 @@ def main():
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--out", default="gpurun_out/kbench.json")
     ap.add_argument("--dists", default="encoder_like,uniform")
-    ap.add_argument("--old", action="store_true", help="also the round-2 hybrid forward / tile_q2 backward variants")
     ap.add_argument("--fwd-only", action="store_true")
     args = ap.parse_args()
     rows = []
@@ -58,28 +57,22 @@ def main():
             fcall.fwd(); fcall.bwd(); torch.cuda.synchronize()
             fref = (fcall.out.clone(), fcall.gv.clone(), fcall.gp.clone())
             enc = nq is None
-            fwd_cfgs = [("v1 generic", dict(fwd_variant=1)), ("v3 gather<4>", dict(fwd_variant=3)),
-                        ("v2 gather<2>", dict(fwd_variant=2))]
+            fwd_cfgs = [("v1 generic", dict(fwd_variant=1)), ("v3 gather<4>", dict(fwd_variant=3))]
             if enc:
                 fwd_cfgs.append(("v3 gather<4> head-major", dict(fwd_variant=3, fwd_head_major=1)))
             if enc:
                 # windowed forward (variant 12): region size x workgroup size x margins x windowed levels x fill
                 win = [dict()]
                 if not args.quick:
-                    win += [dict(fwd_win_dma=0), dict(fwd_win_block=512), dict(fwd_win_block=128),
-                            dict(fwd_win_rlog=4), dict(fwd_win_rlog=4, fwd_win_block=512),
-                            dict(fwd_win_rlog=4, fwd_win_block=512, fwd_win_margins=0x2333),
+                    win += [dict(fwd_win_rlog=3, fwd_win_block=256), dict(fwd_win_rlog=3, fwd_win_block=512),
+                            dict(fwd_win_rlog=3, fwd_win_rlogx=4, fwd_win_block=512), dict(fwd_win_early=0),
+                            dict(fwd_win_margins=0x2333),
                             dict(fwd_win_margins=0x2222), dict(fwd_win_margins=0x2233), dict(fwd_win_margins=0x4444),
                             dict(fwd_win_margins=0x2330), dict(fwd_win_l0=0), dict(fwd_win_l0=0, fwd_win_margins=0x2222),
                             dict(fwd_win_l0=2), dict(fwd_win_l0=4)]
                 for w in win:
                     tag = " ".join(f"{k[8:]}={v:x}" for k, v in w.items()) or "default"
                     fwd_cfgs.append((f"v12 win {tag}", dict(fwd_variant=12, **w)))
-                for v in ((8, 9) if args.old else ()):
-                    for l0 in (1, 2, 4):
-                        for mg in ((2, 3) if (l0 == 1 and not args.quick) else (3,)):
-                            fwd_cfgs.append((f"v{v} hybrid l0={l0} m{mg}", dict(fwd_variant=v, fwd_tile_l0=l0,
-                                                                                 fwd_tile_margin=mg)))
             for name, opts in fwd_cfgs:
                 for c, r, tag in ((call, ref[0], "fwd"), (fcall, fref[0], "fwd_fused")):
                     reset()
@@ -97,13 +90,13 @@ def main():
                 bwd_cfgs.append(("v0 rows block=128", dict(bwd_variant=0, bwd_rows_block=128)))
                 bwd_cfgs.append(("v0 rows block=256", dict(bwd_variant=0, bwd_rows_block=256)))
             if enc:
-                for v in ((8, 9, 10, 11) if args.old else (10,)):
+                for v in (10,):
                     for mg in ((3, 4, 5) if not args.quick else (4,)):
-                        bwd_cfgs.append((f"v{v} {'tile_q2' if v < 10 else 'tile_lv'} m{mg}",
-                                         dict(bwd_variant=v, bwd_tile_margin=mg)))
-                        if v >= 10:     # fused call without the three-kernel split (the plain call ignores the knob)
-                            bwd_cfgs.append((f"v{v} tile_lv m{mg} one-kernel", dict(bwd_variant=v, bwd_tile_margin=mg,
-                                                                                     bwd_split=0)))
+                        bwd_cfgs.append((f"v{v} tile_lv m{mg}", dict(bwd_variant=v, bwd_tile_margin=mg)))
+                        # fused call without the three-kernel split (the plain call ignores the knob)
+                        bwd_cfgs.append((f"v{v} tile_lv m{mg} one-kernel", dict(bwd_variant=v, bwd_tile_margin=mg,
+                                                                                 bwd_split=0)))
+                bwd_cfgs.append(("v12 bins", dict(bwd_variant=12)))
             for name, opts in ([] if args.fwd_only else bwd_cfgs):
                 for c, tag in ((call, "bwd"), (fcall, "bwd_fused")):
                     reset()
