@@ -298,6 +298,21 @@ def read_traffic_bwd(kernel_label):
         return None
 
 
+def read_gemm_table(dtype):
+    """MFMA utilisation of the step's library GEMMs (projections, FFN, attention in-projections): not measurable from
+    inside an un-profiled run, so the committed torch.profiler pass of this configuration is quoted (tools/gemm_util.py
+    -> profiles/gemm_mfma.json: FLOPs of every mm / addmm / bmm over its kernels' time, each priced against the dense MFMA
+    peak of its input type -- 157.3 TFLOP/s fp32, 2500 TFLOP/s bf16; tables: profiles/r05_gemm_mfma_utilisation_*.md)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "gemm_mfma.json")) as f:
+            t = json.load(f)[dtype]
+        return {"gemm_ms_per_step": t["gemm_ms_per_step"], "gemm_tflop_per_step": t["gemm_tflop_per_step"],
+                "gemm_frac_of_mfma_peak": t["gemm_frac_of_mfma_peak"],
+                "gemm_source": f"profiles/gemm_mfma.json ({t.get('tag', '?')}: torch.profiler pass of this step, graphs off)"}
+    except Exception:
+        return {}
+
+
 def host_cpu_info():
     model = "unknown"
     try:
@@ -396,7 +411,8 @@ def kernel_lines(args, enc, dec):
     ach = enc.bytes() / (ms_fwd * 1e-3) / 1e9
     out = {
         "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": ach / HBM_PEAK_GBPS, "traffic": read_traffic(kernel), "kernel": kernel, "ms": ms_fwd,
+                     "frac": ach / HBM_PEAK_GBPS, "traffic": read_traffic(kernel) if enc.S == 22323 else None,
+                     "kernel": kernel, "ms": ms_fwd,
                      "algorithmic_bytes": enc.bytes(), "loc_dist": args.dist},
         "kernels": {"enc_fwd_ms": ms_fwd, "enc_bwd_ms": ms_bwd, "dec_fwd_ms": ms_dec, "enc_bwd_kernel": kernel_bwd,
                     "enc_bwd_GBps": enc.bytes(True) / (ms_bwd * 1e-3) / 1e9},
@@ -404,12 +420,14 @@ def kernel_lines(args, enc, dec):
     # the step's other large MSDA kernel, priced the same way (137,152,608 algorithmic bytes per encoder-shape call)
     ach_b = enc.bytes(True) / (ms_bwd * 1e-3) / 1e9
     out["roofline_backward"] = {"bound": "hbm", "achieved": ach_b, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                "frac": ach_b / HBM_PEAK_GBPS, "traffic": read_traffic_bwd(kernel_bwd),
+                                "frac": ach_b / HBM_PEAK_GBPS,
+                                "traffic": read_traffic_bwd(kernel_bwd) if enc.S == 22323 else None,
                                 "kernel": kernel_bwd, "ms": ms_bwd, "algorithmic_bytes": enc.bytes(True),
                                 "loc_dist": args.dist}
     other = "uniform" if args.dist != "uniform" else "encoder_like"
     dev = torch.device("cuda", torch.cuda.current_device())
-    alt = FusedCall(make_inputs(device=dev, dist=other, seed=3))
+    h, w = frame_size(args)
+    alt = FusedCall(make_inputs(device=dev, dist=other, seed=3, height=h, width=w))
     lib.set_call_site(2)
     for i in range(40):                    # the selector reads a launch's statistics two calls later
         alt.fwd()
@@ -511,7 +529,7 @@ def run_infer(args, rank, world):
     from memotr_amd.utils.utils import set_seed
     dev = torch.device("cuda", torch.cuda.current_device())
     cfg = {"dancetrack": C.dancetrack_config, "mot17": C.mot17_config, "bdd100k": C.bdd100k_config}[args.config]()
-    hw = (720, 1280) if args.config == "bdd100k" else (800, 1333)
+    hw = frame_size(args)
     torch.backends.cuda.matmul.allow_tf32 = False
     torch.backends.cudnn.allow_tf32 = False
     set_seed(cfg["SEED"] + rank)
@@ -570,17 +588,29 @@ def _infer_graph_stats(core) -> dict:
             "decoder": {"captures": d.captures, "replays": d.replays, "eager": d.eager, "failed": d.failed}}
 
 
+def frame_size(args):
+    """Frame size of the configuration: its pyramid is what the kernel lines are measured on (round 5: a
+    `--config bdd100k` line used to carry the 800x1333 kernel numbers)."""
+    return (720, 1280) if args.config == "bdd100k" else (800, 1333)
+
+
 def run_msda_kernels_only(args):
-    """Roofline numbers for the dominant kernel + a thunk for the CPU baseline (used by the train workload)."""
+    """Roofline numbers for the dominant kernel on the configuration's own pyramid + a thunk for the CPU baseline
+    (used by the train and infer workloads)."""
     from memotr_amd.synth import make_inputs
     dev = torch.device("cuda", torch.cuda.current_device())
-    enc = FusedCall(make_inputs(device=dev, dist=args.dist, seed=3))
-    dec = FusedCall(make_inputs(device=dev, dist=args.dist, seed=103, n_queries=300 + args.n_track))
+    h, w = frame_size(args)
+    enc = FusedCall(make_inputs(device=dev, dist=args.dist, seed=3, height=h, width=w))
+    dec = FusedCall(make_inputs(device=dev, dist=args.dist, seed=103, n_queries=300 + args.n_track, height=h, width=w))
     out = kernel_lines(args, enc, dec)
+    for k in out:
+        if k.startswith("roofline") and isinstance(out[k], dict):
+            out[k]["pyramid"] = f"{h}x{w}: S = {enc.S}"
     return {
         **out,
-        "cpu_baseline_fn": lambda: cpu_baseline_msda(args, dict(dist=args.dist, seed=3),
-                                                     dict(dist=args.dist, seed=103, n_queries=300 + args.n_track)),
+        "cpu_baseline_fn": lambda: cpu_baseline_msda(args, dict(dist=args.dist, seed=3, height=h, width=w),
+                                                     dict(dist=args.dist, seed=103, n_queries=300 + args.n_track,
+                                                          height=h, width=w)),
     }
 
 
@@ -608,7 +638,7 @@ def main():
         from memotr_amd.train_bench import run_train
         cfg = {"dancetrack": C.dancetrack_config, "mot17": C.mot17_config, "bdd100k": C.bdd100k_config}[args.config](
             USE_CHECKPOINT=args.use_checkpoint)
-        hw = (720, 1280) if args.config == "bdd100k" else (800, 1333)
+        hw = frame_size(args)
         if hw != (800, 1333):
             # MIOpen's immediate-mode heuristic picks slow solvers for the 736x1280 pyramid (8.9 vs 19.4 frames/s
             # measured); the exhaustive find costs minutes once per process but is worth it there.  At 800x1344 both
@@ -625,6 +655,8 @@ def main():
         if rank == 0:   # the kernel roofline and the CPU fallback baseline ride along on rank 0
             k = run_msda_kernels_only(args)
             result.update({n: v for n, v in k.items() if n.startswith(("roofline", "kernels"))})
+            if args.config == "dancetrack" and not args.use_checkpoint and isinstance(result.get("kernels"), dict):
+                result["kernels"].update(read_gemm_table(args.dtype))
             if world == 1 and not args.no_cpu_baseline:
                 result["cpu_baseline"] = k["cpu_baseline_fn"]()
                 result["cpu_baseline"]["sample"] += ("; covers the MSDeformAttn calls of a frame only -- the "

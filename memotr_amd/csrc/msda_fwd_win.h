@@ -52,6 +52,8 @@ struct WinPlan {
     unsigned long long *trace;     // profiling only (tools/fwd_win_timeline.py): 32 s_memtime stamps per wavefront, or null
     unsigned long long *stats, *stats_host;  // msda_select.h records (device / mapped host); null: no statistics
     int sel_level;
+    int measure;                   // 1: every workgroup measures its own mean offsets before it places its windows (rounds 3-4);
+                                   // 0: windows go where the record's running means say (msda_select.h), counting workgroups measure
     int ablate;                    // profiling only (msda_set_option "fwd_win_ablate"): 1 stop after the prologue, 2 no gather,
                                    // 4 write per (row, point) 2 = left its window / 1 = served from it / 0 into `out` (use 6)
 };
@@ -219,6 +221,21 @@ __device__ __forceinline__ f32x4 win_mixed_point(const u32x4 r, const unsigned c
 
 typedef __attribute__((address_space(3))) void lds_void;
 
+// Window origin of level l: centred on the region's centre in level-l sampling coordinates plus the mean sampling
+// offset (dx, dy), kept on the level and its one-pixel zero border.
+__device__ __forceinline__ void win_place(WinTables &tb, const WinPlan &pl, int l, int ry, int rx, float dx, float dy) {
+    const float cx = ((float)(rx << pl.rlogx) + 0.5f * (float)(1 << pl.rlogx)) * pl.ratw[0][l] - 0.5f + dx;
+    const float cy = ((float)(ry << pl.rlogy) + 0.5f * (float)(1 << pl.rlogy)) * pl.rath[0][l] - 0.5f + dy;
+    const int ww = pl.ww[l], wh = pl.wh[l];
+    int ox = (int)floorf(cx - 0.5f * (float)(ww - 1) + 0.5f);
+    int oy = (int)floorf(cy - 0.5f * (float)(wh - 1) + 0.5f);
+    const int max_x = pl.W[l] + 1 - ww, max_y = pl.H[l] + 1 - wh;
+    ox = ox > max_x ? max_x : ox;
+    oy = oy > max_y ? max_y : oy;
+    tb.ox[l] = ox < -1 ? -1 : ox;
+    tb.oy[l] = oy < -1 ? -1 : oy;
+}
+
 // WPS = wavefronts per SIMD the register budget is sized for (4: 128 VGPRs -- 512-thread workgroups, or four 256-thread
 // workgroups per CU; 3: 168 VGPRs -- three 256-thread workgroups per CU, what 40-53 KB of LDS admits)
 // NE: the corner rows of the first NE (0 / 2 / 4) global points are requested before the LDS-served points and used
@@ -283,15 +300,9 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
         tb.ww[tid] = pl.ww[tid];
         tb.wh[tid] = pl.wh[tid];
         tb.wmagic[tid] = pl.wmagic[tid];
-        // (uniform indices: scalar loads through the constant cache, not a vector load every wave waits a
-        //  memory round trip for before the first barrier)
-        int ls = 0;
-#pragma unroll
-        for (int i = 0; i < kWinMaxL; ++i) {
-            const int v = i < L ? (int)lstart[i] : 0;
-            ls = tid == i ? v : ls;
-        }
-        tb.lstart[tid] = ls;
+        // (one query per pixel: level l of `value` starts where its queries do -- the device copy of level_start_index,
+        //  a cold global load in front of the first barrier, is not read)
+        tb.lstart[tid] = pl.qstart[tid];
         tb.ox[tid] = tb.oy[tid] = 0;
     }
     if (tid <= kWinMaxL) {
@@ -326,6 +337,20 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
 #define MSDA_WIN_STATS 1      // (0: A/B builds without the selector's counting)
 #endif
     const bool stat_wg = MSDA_WIN_STATS && pl.stats != nullptr && (sw & 7) == 0;
+    const bool measure = pl.measure != 0;          // block-uniform
+    // windows of the windowed levels: centred on the region + this head's mean sampling offset on that level, as the
+    // launches before this one measured it (round 5; no dependent round trip in front of the fill any more)
+    if (!measure) {
+        const float *hp = reinterpret_cast<const float *>(pl.stats + kSelHintWord) + m * (kSelHintLevels * 2);
+        // (agent-scope loads: the means were written by the previous launch's publishing wavefront; a scalar load
+        //  could be served by a constant cache that launch boundary did not invalidate)
+        float hx = 0.f, hy = 0.f;
+        if (tid >= pl.lwin0 && tid < L && m < kSelHintHeads) {
+            hx = __hip_atomic_load(hp + 2 * tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            hy = __hip_atomic_load(hp + 2 * tid + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (tid >= pl.lwin0 && tid < L) win_place(tb, pl, tid, ry, rx, hx, hy);
+    }
     unsigned v_off = 0u;                // statistics: windowed points of this lane that left their window
     unsigned char mpad[kWinMaxL] = {0, 0, 0, 0};      // fused + mask: "the window pixel this lane answers for is padded"
     __syncthreads();
@@ -368,10 +393,15 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
     int step = wave;
     bool row_ok;
     WinRaw raw;
-    {
-        const WinRow row = win_row(tb, L, step * 4 + s_rs, b, m, M, pl.Lq);
-        row_ok = row.ok;
-        raw = win_load_raw<FUSED>(src, row.qrow, row.pm, m, L, LP, s_t, s_l);
+    const WinRow row = win_row(tb, L, step * 4 + s_rs, b, m, M, pl.Lq);
+    row_ok = row.ok;
+    // (placement from the record: the rows' own inputs are requested AFTER the fill.  Vector-memory results return in
+    //  order; these loads stream from HBM while the fill mostly hits the L2, and queued in front of it they held the
+    //  fill's data back -- the prologue alone took 23.7 instead of 12 us)
+    if (measure) raw = win_load_raw<FUSED>(src, row.qrow, row.pm, m, L, LP, s_t, s_l);
+    // mean sampling offset per windowed level on this wavefront's first rows: for the placement (measuring mode, before
+    // the fill) or for the record's running means (counting workgroups, after the fill has been issued)
+    auto measure_offsets = [&]() {
         if (lwin0 < L) {
             // placement only: approximate arithmetic is fine here (the records repeat it exactly)
             float dx = 0.f, dy = 0.f, dc = 0.f;
@@ -397,46 +427,51 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
             }
             for (int l = lwin0; l < L; ++l) {
                 const bool mine = s_l == l;
-                const float sx = row16_sum(mine ? dx : 0.f), sy = row16_sum(mine ? dy : 0.f);
-                const float sc = row16_sum(mine ? dc : 0.f);
-                if (s_t == 0) {
-                    float *pp = s_part + ((wave * 4 + s_rs) * kWinMaxL + l) * 3;
-                    pp[0] = sx;
-                    pp[1] = sy;
-                    pp[2] = sc;
+                float sx = row16_sum(mine ? dx : 0.f), sy = row16_sum(mine ? dy : 0.f);
+                float sc = row16_sum(mine ? dc : 0.f);
+                if (measure) {
+                    if (s_t == 0) {
+                        float *pp = s_part + ((wave * 4 + s_rs) * kWinMaxL + l) * 3;
+                        pp[0] = sx;
+                        pp[1] = sy;
+                        pp[2] = sc;
+                    }
+                } else {       // counting workgroup: this wavefront's four rows to the record's running sums
+                    sx += __shfl_xor(sx, 16, 64); sy += __shfl_xor(sy, 16, 64); sc += __shfl_xor(sc, 16, 64);
+                    sx += __shfl_xor(sx, 32, 64); sy += __shfl_xor(sy, 32, 64); sc += __shfl_xor(sc, 32, 64);
+                    // (ONE wavefront of one workgroup in sixteen: 72 addresses take ~340 float atomics per launch.  With
+                    //  every wavefront of one workgroup in eight -- 5.5 k same-address atomics -- the L2's atomic
+                    //  units serialised them and the FILL behind them took twice as long: 54 instead of 46 us)
+                    if (lane == 0 && sc > 0.f && m < kSelHintHeads) sel_hint_add(pl.stats, m, l, sx, sy, sc);
                 }
             }
         }
-    }
-    WIN_STAMP();       // 2: first rows requested, offsets measured (the loads have returned: the DPP sums used them)
-    __syncthreads();
-    WIN_STAMP();       // 3
+    };
+    if (measure) measure_offsets();
+    WIN_STAMP();       // 2: first rows requested, (measuring) offsets measured
     if (lwin0 < L) {
-        if (tid >= lwin0 && tid < L) {
-            const int l = tid;
-            float sx = 0.f, sy = 0.f, cnt = 0.f;
-            for (int i = 0; i < nw * 4; ++i) {
-                sx += s_part[(i * kWinMaxL + l) * 3];
-                sy += s_part[(i * kWinMaxL + l) * 3 + 1];
-                cnt += s_part[(i * kWinMaxL + l) * 3 + 2];
+        if (measure) {
+            __syncthreads();
+            WIN_STAMP();   // 3
+            if (tid >= lwin0 && tid < L) {
+                const int l = tid;
+                float sx = 0.f, sy = 0.f, cnt = 0.f;
+                for (int i = 0; i < nw * 4; ++i) {
+                    sx += s_part[(i * kWinMaxL + l) * 3];
+                    sy += s_part[(i * kWinMaxL + l) * 3 + 1];
+                    cnt += s_part[(i * kWinMaxL + l) * 3 + 2];
+                }
+                const float rc = cnt > 0.f ? __builtin_amdgcn_rcpf(cnt) : 0.f;
+                win_place(tb, pl, l, ry, rx, sx * rc, sy * rc);
             }
-            const float rc = cnt > 0.f ? __builtin_amdgcn_rcpf(cnt) : 0.f;
-            // centre of the region in level-l sampling coordinates + the measured mean offset
-            const float cx = ((float)(rx << pl.rlogx) + 0.5f * (float)(1 << pl.rlogx)) * pl.ratw[0][l] - 0.5f + sx * rc;
-            const float cy = ((float)(ry << pl.rlogy) + 0.5f * (float)(1 << pl.rlogy)) * pl.rath[0][l] - 0.5f + sy * rc;
-            const int ww = tb.ww[l], wh = tb.wh[l];
-            int ox = (int)floorf(cx - 0.5f * (float)(ww - 1) + 0.5f);
-            int oy = (int)floorf(cy - 0.5f * (float)(wh - 1) + 0.5f);
-            // keep the window on the level plus its one-pixel zero border
-            const int max_x = tb.W[l] + 1 - ww, max_y = tb.H[l] + 1 - wh;
-            ox = ox > max_x ? max_x : ox;
-            oy = oy > max_y ? max_y : oy;
-            tb.ox[l] = ox < -1 ? -1 : ox;
-            tb.oy[l] = oy < -1 ? -1 : oy;
+            WIN_STAMP();   // 4: (threads 1..3 of wavefront 0: placement done; everyone else: nothing)
+            __syncthreads();
+            WIN_STAMP();   // 5: placement visible
+        } else {
+            WIN_STAMP();   // (3-5: the same stamp numbers in both modes)
+            WIN_STAMP();
+            WIN_STAMP();
         }
-        WIN_STAMP();   // 4: (threads 1..3 of wavefront 0: placement done; everyone else: nothing)
-        __syncthreads();
-        WIN_STAMP();   // 5: placement visible
 
         // ---- fill the windows: 8 pixels (1 KiB) per wave instruction; cells outside the level / padded read 0.
         //      Every level's window starts on a group boundary, so the level is uniform per instruction.  (One
@@ -481,6 +516,10 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
                 }
             }
         }
+    }
+    if (!measure) {
+        raw = win_load_raw<FUSED>(src, row.qrow, row.pm, m, L, LP, s_t, s_l);
+        if (stat_wg && wave == 0 && (sw & 15) == 0) measure_offsets();
     }
 
     WIN_STAMP();       // 6: fill issued
@@ -747,9 +786,14 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
             unsigned n_off = v_off;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) n_off += __shfl_xor(n_off, o, 64);
-            if (lane == 0) sel_add(pl.stats, pl.sel_level, (unsigned)((sw >> 3) * nw + wave), n_live, n_off, 0u);
+            // (a launch whose windows were placed without measured means says nothing about the offsets)
+            const bool hint_valid = measure || __hip_atomic_load(pl.stats + kSelHintValidWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull;
+            if (lane == 0 && hint_valid) sel_add(pl.stats, pl.sel_level, (unsigned)((sw >> 3) * nw + wave), n_live, n_off, 0u);
         }
-        if (sw == 0 && wave == 1) sel_publish(pl.stats, pl.stats_host, lane);
+        if (sw == 0 && wave == 1) {
+            sel_publish(pl.stats, pl.stats_host, lane);
+            if (!measure) sel_hint_publish(pl.stats, lane, M, L);
+        }
     }
 }
 

@@ -106,6 +106,7 @@ std::atomic<int> opt_fwd_win_block{0};      // threads per workgroup (128 / 256 
 std::atomic<int> opt_fwd_win_l0{1};         // first level served from an LDS window
 std::atomic<int> opt_fwd_win_margins{0x3333};  // window margin per level, 4 bits each (level 0 in the low nibble)
 std::atomic<int> opt_fwd_win_ablate{0};     // profiling only
+std::atomic<int> opt_fwd_win_place{0};      // 1: measured window placement in every workgroup (rounds 3-4)
 std::atomic<int> opt_fwd_win_wps{0};        // 3 / 4: force the 168- / 128-register build
 std::atomic<int> opt_fwd_win_early{9};      // 0 / 2 / 4: level-0 points requested before the LDS phase (else: by register budget)
 constexpr int kWinEarlyW4 = 2;              // ... of the 128-register build
@@ -529,12 +530,12 @@ int forward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart, 
         hipLaunchKernelGGL((msda_fwd_d32_win<FU, WPS, NE>), dim3(grid), dim3(threads), lds, stream,                  \
                            (const float *)value, lstart, src, (float *)out, wp);                                     \
     } while (0)
-#define MSDA_LAUNCH_WIN_T(FU, NAME)                                                                                  \
+#define MSDA_LAUNCH_WIN_T(FU, WPS, NE, NAME)                                                                         \
     do {                                                                                                             \
-        rc = allow_big_lds(msda_fwd_d32_win<FU, 3, 4, true>, lds);                                                   \
+        rc = allow_big_lds(msda_fwd_d32_win<FU, WPS, NE, true>, lds);                                                \
         if (rc) return rc;                                                                                           \
         g_kernel = NAME;                                                                                             \
-        hipLaunchKernelGGL((msda_fwd_d32_win<FU, 3, 4, true>), dim3(grid), dim3(threads), lds, stream,               \
+        hipLaunchKernelGGL((msda_fwd_d32_win<FU, WPS, NE, true>), dim3(grid), dim3(threads), lds, stream,            \
                            (const float *)value, lstart, src, (float *)out, wp);                                     \
     } while (0)
                     wp.ablate = opt_fwd_win_ablate.load();
@@ -545,6 +546,9 @@ int forward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart, 
                         wp.stats_host = slot->host_dev;
                         wp.sel_level = sel;
                     }
+                    // windows placed from the record's running mean offsets (no round trip in front of the fill); without
+                    // a record, or on request, every workgroup measures its own first ("fwd_win_place" 1)
+                    wp.measure = (slot == nullptr || M > kSelHintHeads || L > kSelHintLevels || opt_fwd_win_place.load() != 0) ? 1 : 0;
                     // register budget by what the workgroup shape admits: three 256-thread workgroups per CU (40-53 KB
                     // of LDS each) -> 168 registers, all four level-0 points requested before the LDS phase; 512-thread
                     // workgroups (two per CU) or four small ones -> 128 registers, two of them
@@ -559,15 +563,20 @@ int forward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart, 
                     if (early == 4) wps = 3;
                     if (wps == 3) {
                         if (fused) {
-                            if (wp.trace || wp.ablate) MSDA_LAUNCH_WIN_T(true, "msda_fwd_d32_win<fused,w3,e4>");
+                            if (wp.trace || wp.ablate) MSDA_LAUNCH_WIN_T(true, 3, 4, "msda_fwd_d32_win<fused,w3,e4>");
                             else MSDA_LAUNCH_WIN(true, 3, 4, "msda_fwd_d32_win<fused,w3,e4>");
                         } else {
-                            if (wp.trace || wp.ablate) MSDA_LAUNCH_WIN_T(false, "msda_fwd_d32_win<w3,e4>");
+                            if (wp.trace || wp.ablate) MSDA_LAUNCH_WIN_T(false, 3, 4, "msda_fwd_d32_win<w3,e4>");
                             else MSDA_LAUNCH_WIN(false, 3, 4, "msda_fwd_d32_win<w3,e4>");
                         }
                     } else if (early == 2) {
-                        if (fused) MSDA_LAUNCH_WIN(true, 4, 2, "msda_fwd_d32_win<fused,w4,e2>");
-                        else MSDA_LAUNCH_WIN(false, 4, 2, "msda_fwd_d32_win<w4,e2>");
+                        if (fused) {
+                            if (wp.trace || wp.ablate) MSDA_LAUNCH_WIN_T(true, 4, 2, "msda_fwd_d32_win<fused,w4,e2>");
+                            else MSDA_LAUNCH_WIN(true, 4, 2, "msda_fwd_d32_win<fused,w4,e2>");
+                        } else {
+                            if (wp.trace || wp.ablate) MSDA_LAUNCH_WIN_T(false, 4, 2, "msda_fwd_d32_win<w4,e2>");
+                            else MSDA_LAUNCH_WIN(false, 4, 2, "msda_fwd_d32_win<w4,e2>");
+                        }
                     } else {
                         if (fused) MSDA_LAUNCH_WIN(true, 4, 0, "msda_fwd_d32_win<fused,w4>");
                         else MSDA_LAUNCH_WIN(false, 4, 0, "msda_fwd_d32_win<w4>");
@@ -1100,6 +1109,7 @@ static std::atomic<int> *find_opt(const char *key) {
     if (!strcmp(key, "fwd_win_trace_lo")) return &opt_fwd_win_trace_lo;
     if (!strcmp(key, "fwd_win_trace_hi")) return &opt_fwd_win_trace_hi;
     if (!strcmp(key, "fwd_win_ablate")) return &opt_fwd_win_ablate;
+    if (!strcmp(key, "fwd_win_place")) return &opt_fwd_win_place;
     if (!strcmp(key, "fwd_win_wps")) return &opt_fwd_win_wps;
     if (!strcmp(key, "fwd_win_early")) return &opt_fwd_win_early;
     return nullptr;

@@ -42,10 +42,18 @@ constexpr int kSelLevels = 3;
 constexpr int kSelShards = 32;
 // device record (64-bit words): [level][shard]{valid, off, inner, pad}, then the publishers' sequence counter
 constexpr int kSelCntWords = kSelLevels * kSelShards * 4;
-constexpr int kSelDevWords = 512;                       // 4 KiB per record
+constexpr int kSelDevWords = 1024;                      // 8 KiB per record
+// ... and, for the windowed forward, where its windows go (device-only, never read by the host): per (head, level) the
+// running sums {dx, dy, n} of the sampling offsets relative to the query's own pixel (floats, added by the counting
+// workgroups, consumed by the publishing wavefront), the mean offsets the NEXT launches centre their windows on, and a
+// flag "means have been measured"
+constexpr int kSelHintHeads = 16, kSelHintLevels = 4;
+constexpr int kSelHintAccWord = 392;                    // 16 x 4 x {dx, dy, n, -} floats
+constexpr int kSelHintWord = kSelHintAccWord + kSelHintHeads * kSelHintLevels * 2;      // 16 x 4 x {dx, dy} floats
+constexpr int kSelHintValidWord = kSelHintWord + kSelHintHeads * kSelHintLevels;
 constexpr int kSelHostWords = 16;                       // 128 B per record: [level]{valid, off, inner}, seq at [9]
 constexpr unsigned long long kSelMinSample = 2048;      // valid corners a level's difference must hold to be judged
-static_assert(kSelCntWords + 1 <= kSelDevWords, "record too small");
+static_assert(kSelCntWords + 1 <= kSelHintAccWord && kSelHintValidWord < kSelDevWords, "record too small");
 
 struct SelKey {
     int dev, kind;                  // kind 0: forward, 1: backward
@@ -123,5 +131,38 @@ __device__ __forceinline__ void sel_publish(unsigned long long *dev, unsigned lo
             __hip_atomic_fetch_add(dev + kSelCntWords, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
         __hip_atomic_store(host + 9, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+}
+
+// Window placement of the windowed forward, device side only.  A counting workgroup adds the offsets it measured on its
+// first rows; the publishing wavefront (lane = (head, level)) turns a batch of at least 64 samples into the mean the next
+// launches use and takes the batch out (an exchange: what later workgroups of the same launch add stays for the next
+// publisher).  No argument changes from launch to launch, so replayed captures keep adapting.
+__device__ __forceinline__ void sel_hint_add(unsigned long long *dev, int head, int level, float sx, float sy, float n) {
+    float *a = reinterpret_cast<float *>(dev + kSelHintAccWord) + (head * kSelHintLevels + level) * 4;
+    unsafeAtomicAdd(a + 0, sx);
+    unsafeAtomicAdd(a + 1, sy);
+    unsafeAtomicAdd(a + 2, n);
+}
+
+__device__ __forceinline__ void sel_hint_publish(unsigned long long *dev, int lane, int M, int L) {
+    const int head = lane / kSelHintLevels, level = lane % kSelHintLevels;
+    bool any = false;
+    if (head < M && head < kSelHintHeads && level < L) {
+        float *a = reinterpret_cast<float *>(dev + kSelHintAccWord) + (head * kSelHintLevels + level) * 4;
+        const float n0 = __hip_atomic_load(a + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (n0 >= 64.f) {
+            const float n = __hip_atomic_exchange(a + 2, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float sx = __hip_atomic_exchange(a + 0, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float sy = __hip_atomic_exchange(a + 1, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (n > 0.f) {
+                float *h = reinterpret_cast<float *>(dev + kSelHintWord) + (head * kSelHintLevels + level) * 2;
+                __hip_atomic_store(h + 0, sx / n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(h + 1, sy / n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                any = true;
+            }
+        }
+    }
+    if (__builtin_amdgcn_ballot_w64(any) != 0ull && lane == 0)
+        __hip_atomic_store(dev + kSelHintValidWord, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 #endif

@@ -65,6 +65,9 @@ def _fp32_island(fn):
     return wrapped
 
 
+_MAX_CLIP_FRAMES = 63      # frames per clip the distributed count all-reduce has room for (64 floats)
+
+
 class ClipCriterion:
     def __init__(self, num_classes, matcher: HungarianMatcher, n_det_queries, aux_loss: bool, weight: dict,
                  max_frame_length: int, n_aux: int, merge_det_track_layer: int = 0, aux_weights: List = None,
@@ -133,12 +136,17 @@ class ClipCriterion:
         host = [float(sum(self.n_gts))] + [float(n) for n in self.n_gts]
         per_frame = None
         if is_distributed():
-            counts = torch.as_tensor(host, dtype=torch.float, device=self.device)
+            # a fixed-length vector: ranks whose clips differ in length (a sampler that mixes sample lengths) still issue
+            # the SAME collective -- the reference's per-frame all-reduces (criterion.py:208-214) would deadlock there
+            if len(host) > _MAX_CLIP_FRAMES + 1:
+                raise ValueError(f"clip of {len(host) - 1} frames: the count all-reduce carries at most {_MAX_CLIP_FRAMES}")
+            padded = host + [0.0] * (_MAX_CLIP_FRAMES + 1 - len(host))
+            counts = torch.as_tensor(padded, dtype=torch.float, device=self.device)
             torch.distributed.all_reduce(counts)
             counts = torch.clamp(counts / distributed_world_size(), min=1)
             total = counts[0]
             if with_log:
-                per_frame = counts[1:].tolist()
+                per_frame = counts[1:len(host)].tolist()
         else:
             total = max(host[0], 1.0)
             per_frame = [max(c, 1.0) for c in host[1:]]

@@ -112,7 +112,11 @@ def _worker_shared_device(rank, world, port, out_path):
                                                     gradient_as_bucket_view=True, broadcast_buffers=False)
     criterion = build_criterion(cfg)
     opt = build_optimizer(cfg, ddp)
-    batch = clip_to_device(make_synthetic_clip(clip_len=3, height=192, width=256, n_gts=3 + 2 * rank, seed=7 + rank), dev)
+    # the ranks differ in ground-truth count (query buckets) AND in clip length (T partial forwards per backward, the
+    # length of the count vector): every collective of the step -- the count all-reduce, DDP's gradient buckets --
+    # must still be met by both
+    clip_len = 3 - rank
+    batch = clip_to_device(make_synthetic_clip(clip_len=clip_len, height=192, width=256, n_gts=3 + 2 * rank, seed=7 + rank), dev)
     losses, counts, step_ms = [], None, []
     import time
     for _ in range(2):                               # a second step raises if a bucket was left unreduced
@@ -127,9 +131,11 @@ def _worker_shared_device(rank, world, port, out_path):
     torch.cuda.synchronize()
     g = model.transformer.decoder.graphs()
     flat = torch.cat([p.detach().reshape(-1) for p in ddp.parameters()]).cpu()
+    from memotr_amd.utils.host import cpu_quota, respect_cpu_quota
+    threads = respect_cpu_quota(processes=world)       # what bench.py's self-launched ranks do (LOCAL_WORLD_SIZE)
     torch.save({"flat": flat, "losses": losses, "captures": g.captures, "replays": g.replays, "eager": g.eager,
-                "n_gts": counts, "backend": dist.get_backend(), "world": dist.get_world_size(),
-                "step_ms": step_ms}, f"{out_path}.{rank}")
+                "n_gts": counts, "backend": dist.get_backend(), "world": dist.get_world_size(), "clip_len": clip_len,
+                "step_ms": step_ms, "threads": threads, "quota": cpu_quota()}, f"{out_path}.{rank}")
     dist.barrier()
     dist.destroy_process_group()
 
@@ -148,8 +154,13 @@ def test_two_ranks_on_one_device_over_gloo_stay_in_sync(tmp_path):
     # ranks with different ground-truth counts (3 and 5 tracks -> different query buckets) still meet at every
     # all-reduce: the second (steady-state) step of the two ranks ends within a few milliseconds of each other.  The
     # spread is printed for the record (both ranks share ONE device here, so it is an upper bound on rank skew)
+    # -- and different clip lengths (3 and 2 frames): the step ends at DDP's last bucket on both, so the shorter clip's
+    # rank waits for the longer one; rank_skew_ms is what bench.py reports for a real multi-GPU run
     spread = abs(r0["step_ms"][1] - r1["step_ms"][1])
-    print(f"per-rank step time (ms): rank0 {r0['step_ms'][1]:.1f} rank1 {r1['step_ms'][1]:.1f} spread {spread:.1f}")
+    print(f"per-rank step time (ms): rank0 {r0['step_ms'][1]:.1f} rank1 {r1['step_ms'][1]:.1f} rank_skew_ms {spread:.1f}")
     assert spread < 0.5 * max(r0["step_ms"][1], r1["step_ms"][1])
-    for r in (r0, r1):                                     # decoder graphs active under DDP: 3 frames x 2 steps
-        assert r["captures"] == 3 and r["replays"] == 6 and r["eager"] == 0, r
+    assert (r0["clip_len"], r1["clip_len"]) == (3, 2) and len(r0["n_gts"]) == 3 and len(r1["n_gts"]) == 2
+    for r in (r0, r1):                                     # decoder graphs active under DDP: T frames x 2 steps
+        assert r["captures"] == r["clip_len"] and r["replays"] == 2 * r["clip_len"] and r["eager"] == 0, r
+        # the thread pools are sized to this rank's share of the container's CPU quota (utils/host.py)
+        assert 1 <= r["threads"] <= max(1, int(r["quota"] * 0.5 / 2) + 1), (r["threads"], r["quota"])

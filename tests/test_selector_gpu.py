@@ -127,7 +127,8 @@ def test_selection_moves_under_replayed_inference_encode_graphs(monkeypatch, hip
         hip_lib.set_option(k, v)
     model = _small_model(train=False)
     g = torch.Generator().manual_seed(3)
-    frames = [tensor_list_to_nested_tensor([torch.randn(3, 384, 512, generator=g)]).to(torch.device("cuda"))
+    # (large enough that four times the initial offsets leave the 16 x 16-pixel regions' windows, not the levels)
+    frames = [tensor_list_to_nested_tensor([torch.randn(3, 640, 832, generator=g)]).to(torch.device("cuda"))
               for _ in range(2)]
 
     def encode(frame, graphs):
@@ -169,7 +170,7 @@ def test_selection_moves_under_replayed_bf16_training_encode_graphs(monkeypatch,
                MATCH_COST_GIOU=2, LOSS_WEIGHT_FOCAL=2, LOSS_WEIGHT_L1=5, LOSS_WEIGHT_GIOU=2, AUX_LOSS_WEIGHT=[1.0],
                SAMPLE_LENGTHS=[2, 3, 4])
     criterion = build_criterion(cfg)
-    batch = clip_to_device(make_synthetic_clip(clip_len=2, height=384, width=512, n_gts=5, seed=3), torch.device("cuda"))
+    batch = clip_to_device(make_synthetic_clip(clip_len=2, height=640, width=832, n_gts=5, seed=3), torch.device("cuda"))
 
     def run(graphs, steps):
         monkeypatch.setenv("MEMOTR_ENCODE_GRAPHS", "1" if graphs else "0")

@@ -16,12 +16,13 @@ from memotr_amd import _lib  # noqa: E402
 from memotr_amd.synth import make_inputs  # noqa: E402
 
 DEFAULTS = dict(fwd_variant=0, fwd_win_rlog=0, fwd_win_rlogx=0, fwd_win_block=0, fwd_win_l0=1,
-                fwd_win_margins=0x3333, fwd_head_major=0, fwd_win_early=9, fwd_win_wps=0,
+                fwd_win_margins=0x3333, fwd_head_major=0, fwd_win_early=9, fwd_win_wps=0, fwd_win_place=0,
                 sel_level=-1, auto_select=1)
 
 R3 = dict(fwd_variant=12, fwd_win_rlog=3)
 CONFIGS = [
     ("win default (16x16, 512 thr, w4)", dict(fwd_variant=12)),
+    ("win 16x16 512 thr measured placement", dict(fwd_variant=12, fwd_win_place=1)),
     ("win 16x16 512 thr e0", dict(fwd_variant=12, fwd_win_early=0)),
     ("win 16x16 512 thr e2", dict(fwd_variant=12, fwd_win_early=2)),
     ("gather<4> head-major", dict(fwd_variant=3, fwd_head_major=1)),
@@ -63,6 +64,8 @@ def main():
             c.fwd()
             torch.cuda.synchronize()
             calls.append((c, c.out.clone()))
+    _lib.set_option("sel_level", 0)       # (every configuration at the selector's level 0; the records keep counting)
+    DEFAULTS["sel_level"] = 0
     for name, opts in CONFIGS:
         cells, errs, kern = [], [], ""
         for c, ref in calls:
@@ -70,7 +73,6 @@ def main():
                 _lib.set_option(k, v)
             for k, v in opts.items():
                 _lib.set_option(k, v)
-            _lib.set_option("auto_select", 0)
             c.out.zero_()
             try:
                 c.fwd()
@@ -79,10 +81,15 @@ def main():
                 cells.append("   failed")
                 errs.append(str(exc)[:40])
                 continue
+            for _ in range(4):      # (the window means of this call site settle within two launches)
+                c.fwd()
+            torch.cuda.synchronize()
             errs.append("%.1e" % float((c.out - ref).abs().max()))
             kern = _lib.last_kernel()
             cells.append("%10.1f" % (time_kernel(c.fwd, iters=100) * 1e3))
-        say(f"{name:42s} {' '.join(cells)}   {kern}  err {' '.join(errs)}")
+            share = _lib.selector_last()[1]
+        say(f"{name:42s} {' '.join(cells)}   {kern}  err {' '.join(errs)}  off-window share {share:.4f}")
+    DEFAULTS["sel_level"] = -1
     for k, v in DEFAULTS.items():
         _lib.set_option(k, v)
     with open(args.out, "w") as f:

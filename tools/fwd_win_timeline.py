@@ -24,9 +24,21 @@ def main():
     x = make_inputs(device="cuda")
     call = MsdaCall(x) if plain else FusedCall(x)
     _lib.set_option("fwd_variant", 12)
-    _lib.set_option("auto_select", 0)
+    _lib.set_option("sel_level", 0)
+    for w in sys.argv[1:]:
+        if "=" in w:
+            k, v = w.split("=")
+            _lib.set_option(k, int(v, 0))
     ms = time_kernel(call.fwd, iters=50)
-    n_wg, nw = 13 * 21 * 8, 4
+    rl = _lib.get_option("fwd_win_rlog") or 4
+    rlx = _lib.get_option("fwd_win_rlogx") or rl
+    thr = _lib.get_option("fwd_win_block") or (512 if _lib.get_option("fwd_win_rlog") == 0 else 256)
+    h0, w0 = x["shapes_list"][0]
+    n_wg, nw = -(-h0 // (1 << rl)) * -(-w0 // (1 << rlx)) * 8, thr // 64
+    for ab, what in ((1, "prologue only (tables, first loads, placement, fill)"), (2, "no gather (prologue + staging + records)")):
+        _lib.set_option("fwd_win_ablate", ab)
+        print(f"ablate {ab}: {time_kernel(call.fwd, iters=50)*1e3:.1f} us  -- {what}")
+    _lib.set_option("fwd_win_ablate", 0)
     buf = torch.zeros(n_wg * nw * 32, dtype=torch.int64, device="cuda")
     p = buf.data_ptr()
     _lib.set_option("fwd_win_trace_lo", p & 0x7FFFFFFF)
@@ -47,7 +59,7 @@ def main():
     d = np.diff(t, axis=2)
     for k in range(len(NAMES)):
         lines.append(f"  {NAMES[k]:28s} {d[:, :, k].mean():8.0f}")
-    for it in range(6):
+    for it in range(8):
         base = len(NAMES) + 3 * it
         valid = t[:, :, base + 3] > 0
         if not valid.any():
