@@ -48,13 +48,17 @@
  *     DESIGN.md.
  *   - Integer/index arithmetic (floor of loc*size-0.5, corner indices, the
  *     (-1,H)x(-1,W) gate, zero padding per corner) is bit-identical to the
- *     reference kernels' SOURCE read as two operations -- the product loc*size
- *     rounded, then 0.5 subtracted (.cuh:33-84,285-288; oracle built with
- *     -ffp-contract=off).  An nvcc build of the reference with its default
- *     -fmad=true fuses the two into one FMA; the readings agree on every point of
- *     both benchmark distributions at the BASELINE shape and differ (neighbouring
- *     pixel, complementary weight, same interpolated value to an ulp) on ~0.6 % of
- *     points placed exactly on pixel centres (tests/test_oracle_golden.py).
+ *     reference kernels: the product loc*size rounded to float, then 0.5
+ *     subtracted (.cuh:33-84,285-288; oracle built with -ffp-contract=off).
+ *     For scalar_t = float this IS the reference binary's arithmetic, not one
+ *     reading of it: `.cuh:285` subtracts the DOUBLE literal 0.5, so the float
+ *     product is promoted to double before the subtraction -- a float multiply
+ *     feeding a double add, which nvcc's -fmad (same-type mul + add only) cannot
+ *     contract; the exact double subtraction rounded once to float equals the
+ *     float subtraction.  Only the f64 instantiation could be fused by nvcc; the
+ *     f64 entry points here follow the uncontracted source (tests/
+ *     test_oracle_golden.py keeps the fused reading as a probe: 0 of 2.86 M
+ *     indices differ on both benchmark distributions).
  *     msda_sample_indices_f32 exposes the arithmetic for parity tests.
  */
 #ifndef MSDA_HIP_H_

@@ -138,11 +138,12 @@ __global__ __launch_bounds__(kTileThreads, MSDA_BINS_WGS) void msda_bwd_d32_bins
     const int rem = reg - strip * sh_rows * pl.RX;
     const int hgt = pl.RY - sh_rows * strip < sh_rows ? pl.RY - sh_rows * strip : sh_rows;
     const int rx = rem / hgt, ry = sh_rows * strip + (rem - rx * hgt);
-    int H = pl.H[0], W = pl.W[0], win = pl.win[0], magic = pl.win_magic[0], shl = pl.shift[0];
+    int H = pl.H[0], W = pl.W[0], win = pl.win[0], magic = pl.win_magic[0], shl = pl.shift[0], lstart_l = pl.qstart[0];
 #pragma unroll
     for (int i = 1; i < kTileMaxL; ++i)
-        if (l == i) { H = pl.H[i]; W = pl.W[i]; win = pl.win[i]; magic = pl.win_magic[i]; shl = pl.shift[i]; }
-    const int lstart_l = (int)lstart[l];
+        if (l == i) { H = pl.H[i]; W = pl.W[i]; win = pl.win[i]; magic = pl.win_magic[i]; shl = pl.shift[i]; lstart_l = pl.qstart[i]; }
+    // (one query per pixel: the level starts where its queries do; the device copy of level_start_index -- a cold
+    //  scalar load in front of everything else -- is not read)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rows = pl.rows, n_items = bp.n_items;
 

@@ -1,4 +1,4 @@
-// msda_fwd_win.h -- forward for self-attention over the pyramid (one query per pixel, Lq == S), round 3.
+// msda_fwd_win.h -- forward for self-attention over the pyramid (one query per pixel, Lq == S), rounds 3-5.
 // Included by msda_hip.hip inside its anonymous namespace (shares msda_common.h and the host-side option state).
 //
 // Semantics: models/ops/src/cuda/ms_deform_im2col_cuda.cuh:237-299 (+ bilinear :33-84); fused prologue
@@ -9,13 +9,19 @@
 // This kernel moves the three coarse levels (75 % of the requests, 25 % of `value`) to LDS:
 //
 //   * a workgroup owns (batch, head, region); a region is the set of queries whose pixels fall in one cell of a
-//     2^rlog-pixel grid on the finest level (8 x 8 + 4 x 4 + 2 x 2 + 1 queries for rlog = 3) -- all of them sample the
-//     same neighbourhood of every level;
+//     2^rlog-pixel grid on the finest level -- all of them sample the same neighbourhood of every level.  Round 5:
+//     16 x 16-pixel regions (256 + 64 + 16 + 4 = 340 rows) and 512 threads -- four times the rows per set of windows and
+//     per prologue of rounds 3-4's 8 x 8 regions; a border region holds only the rows that exist, and border regions are
+//     walked last so that the launch's workgroups end together (55.1 -> 45.9 us fused at 800 x 1333);
 //   * blocks are numbered head-major and block i runs on XCD i % 8, so each XCD's 4 MiB L2 holds ONE head's slab of
 //     `value` (2.9 MB at 800 x 1333): the slab is fetched from the fabric once instead of ~3.6 times;
 //   * per windowed level one window of this head's rows (128 B per pixel, zero outside the level / on padded
-//     pixels) is filled with `buffer_load ... lds` (no VGPR round trip) around the mean sampling position measured
-//     on the workgroup's first rows; the finest level keeps going through the vector L1, so both pipes work;
+//     pixels) is filled with `buffer_load ... lds` (no VGPR round trip) around the region's centre + this head's mean
+//     sampling offset on that level.  Rounds 3-4 measured that offset in every workgroup (rows -> reduce -> barrier ->
+//     place -> barrier -> fill: two dependent round trips in front of the fill); round 5 keeps running means per (head,
+//     level) in the call site's selector record (msda_select.h), fed by one wavefront of one workgroup in sixteen and
+//     read at the start -- the fill is issued right after the table barrier.  The finest level keeps going through the
+//     vector L1, so both pipes work;
 //   * 16 lanes own a (query, head) row: lanes of one half read pixel w0, the other half pixel w0 + 1 -- one
 //     ds_read_b128 covers 256 contiguous bytes per row, and the lane -> (row, chunk) map follows the four 16-lane
 //     groups the LDS services a b128 read in, so the read is bank-conflict free (256 B/clk/CU instead of ~110 for
@@ -552,11 +558,10 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
         return;
     }
     const int iters = (steps + nw - 1) / nw;
-    for (int it = 0; it < iters; ++it, step += nw) {
-        const bool have = step < steps;          // wave-uniform
-        unsigned gmask = 0u;
-        if (have) {
-            // -- staging: this lane's point, straight-line --
+    // One step's staging: this lane's (row, point) -> its record pair in the wavefront's record block (`raw`, `row_ok`:
+    // the inputs of step st_).  Returns the 16-bit mask of points some row of the wavefront could not serve from a window.
+    auto stage_step = [&](int st_) -> unsigned {
+        // -- staging: this lane's point, straight-line --
             float a_in;
             if (FUSED) {
                 // exp2 / rcp approximations (<= 2 ulp on a weight): the forward's tolerance is 1e-3, the backward
@@ -604,7 +609,7 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
                 ok11 = ok11 && !c_mask[ok11 ? cell + cW + 1 : 0];
             }
             if (ablate & 4) {      // profiling only (tools/fwd_offset_sweep.py): which points left their window
-                const int qq = s_rowq[step * 4 + s_rs];
+                const int qq = s_rowq[st_ * 4 + s_rs];
                 if (c_pt && qq >= 0)
                     out[(size_t)((q_base + (unsigned)qq) * (unsigned)M + (unsigned)m) * 32u + (unsigned)s_t] =
                         (need && c_windowed) ? 2.f : ((live && c_windowed) ? 1.f : 0.f);
@@ -621,33 +626,20 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
             const unsigned long long bal = __builtin_amdgcn_ballot_w64(need && c_windowed);
             v_off += (need && c_windowed) ? 1u : 0u;      // (statistics: per lane, summed once at the end)
             const unsigned fold = (unsigned)(bal | (bal >> 32));
-            gmask = (fold | (fold >> 16)) & 0xffffu;
-        }
-        WIN_STAMP();   // 7 + 3 it: staged
-        // -- prefetch the next step's inputs --
-        if (step + nw < steps) {
-            const int q = s_rowq[(step + nw) * 4 + s_rs];
-            row_ok = q >= 0;
-            const unsigned qrow = q_base + (unsigned)(q < 0 ? 0 : q);
-            raw = win_load_raw<FUSED>(src, qrow, qrow * (unsigned)M + (unsigned)m, m, L, LP, s_t, s_l);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-
-        // -- levels read through the vector L1: issue the first four points' corner rows now, use them after the
-        //    LDS-served points (fewer than four such points: they all go through the late loop) --
-        u32x4 gr[NEA];
-        f32x4 gv[NEA][2];
-        if (have && early && !(ablate & 2)) {
-#pragma unroll
-            for (int i = 0; i < NEA; ++i) gr[i] = rec_g[2 * i];
-#pragma unroll
-            for (int i = 0; i < NEA; ++i) {
-                gv[i][0] = buf_load_f4(vr, gr[i].y + sub16);
-                gv[i][1] = buf_load_f4(vr, gr[i].w + sub16);
-            }
-        }
-        if (it == 0 && lwin0 < L) {            // the windows must have landed before the first LDS-served point
+            return (fold | (fold >> 16)) & 0xffffu;
+        
+    };
+    // the inputs of step st_ (its rows' projection rows / locations): requested a step ahead
+    auto prefetch_step = [&](int st_) {
+        const int q = s_rowq[st_ * 4 + s_rs];
+        row_ok = q >= 0;
+        const unsigned qrow = q_base + (unsigned)(q < 0 ? 0 : q);
+        raw = win_load_raw<FUSED>(src, qrow, qrow * (unsigned)M + (unsigned)m, m, L, LP, s_t, s_l);
+    };
+    // the windows must have landed before the first LDS-served point (first iteration, every wavefront)
+    auto windows_landed = [&]() {
+        const int it = 0;
+        if (it == 0 && lwin0 < L) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (FUSED && src.mask != nullptr) {       // this wavefront's fill has landed: zero its padded pixels
 #pragma unroll
@@ -662,12 +654,9 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
             }
             __syncthreads();
         }
-        WIN_STAMP();   // 8 + 3 it: records visible, early loads issued, (first step) windows landed
-        if (have && !(ablate & 2)) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            // -- levels read from the LDS windows, four points per batch.  A point some row of the wave could not
-            //    serve from its window (bit in gmask) is handled on the spot, loads and FMAs, so that the common path
-            //    holds no register a vector-memory instruction writes --
+    };
+    // the LDS-served points of the step whose records are in place
+    auto lds_points = [&](unsigned gmask, f32x4 acc) -> f32x4 {
             int t0 = T0;
             for (; t0 + 4 <= LP; t0 += 4) {
                 const u32x4 *rp = rec_g + 2 * t0;
@@ -711,6 +700,54 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
                 }
             }
             for (; t0 < LP; ++t0) acc = win_mixed_point(rec_g[2 * t0], s_dyn, zero_off, vr, sub16, acc);
+            return acc;
+    };
+    // the two pixel halves of a row meet, the row leaves
+    auto finish_row = [&](f32x4 acc) {
+            // -- the two pixel halves of a row sit on row_mirror partners --
+            // (scalars: __builtin_bit_cast of a vector ELEMENT reads element 0 with this compiler)
+            const float a0 = acc.x, a1 = acc.y, a2 = acc.z, a3 = acc.w;
+            acc.x = a0 + MSDA_DPP(a0, 0x140);
+            acc.y = a1 + MSDA_DPP(a1, 0x140);
+            acc.z = a2 + MSDA_DPP(a2, 0x140);
+            acc.w = a3 + MSDA_DPP(a3, 0x140);
+            const int q = s_rowq[step * 4 + g_row];
+            if (g_half == 0 && q >= 0) {
+                const unsigned pm = (q_base + (unsigned)q) * (unsigned)M + (unsigned)m;
+                *reinterpret_cast<f32x4 *>(out + ((size_t)pm * 32u + (unsigned)g_chunk * 4u)) = acc;
+            }
+    };
+    {
+    for (int it = 0; it < iters; ++it, step += nw) {
+        const bool have = step < steps;          // wave-uniform
+        unsigned gmask = 0u;
+        if (have) gmask = stage_step(step);
+        WIN_STAMP();   // 7 + 3 it: staged
+        if (step + nw < steps) prefetch_step(step + nw);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        // -- levels read through the vector L1: issue the first four points' corner rows now, use them after the
+        //    LDS-served points (fewer than four such points: they all go through the late loop) --
+        u32x4 gr[NEA];
+        f32x4 gv[NEA][2];
+        if (have && early && !(ablate & 2)) {
+#pragma unroll
+            for (int i = 0; i < NEA; ++i) gr[i] = rec_g[2 * i];
+#pragma unroll
+            for (int i = 0; i < NEA; ++i) {
+                gv[i][0] = buf_load_f4(vr, gr[i].y + sub16);
+                gv[i][1] = buf_load_f4(vr, gr[i].w + sub16);
+            }
+        }
+        if (it == 0) windows_landed();
+        WIN_STAMP();   // 8 + 3 it: records visible, early loads issued, (first step) windows landed
+        if (have && !(ablate & 2)) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            // -- levels read from the LDS windows, four points per batch.  A point some row of the wave could not
+            //    serve from its window (bit in gmask) is handled on the spot, loads and FMAs, so that the common path
+            //    holds no register a vector-memory instruction writes --
+            acc = lds_points(gmask, acc);
             // -- consume the global points issued above, then any that were not --
             if (early) {
 #pragma unroll
@@ -719,7 +756,7 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
                     acc += __uint_as_float(gr[i].z) * gv[i][1];
                 }
             }
-            int tg = early ? NE : 0;
+            int tg = early ? NEA : 0;
             for (; tg + 4 <= T0; tg += 4) {          // eight corner rows in flight per lane
                 u32x4 r[4];
                 f32x4 v[4][2];
@@ -758,22 +795,12 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
                 acc += __uint_as_float(r.x) * v0;
                 acc += __uint_as_float(r.z) * v1;
             }
-            // -- the two pixel halves of a row sit on row_mirror partners --
-            // (scalars: __builtin_bit_cast of a vector ELEMENT reads element 0 with this compiler)
-            const float a0 = acc.x, a1 = acc.y, a2 = acc.z, a3 = acc.w;
-            acc.x = a0 + MSDA_DPP(a0, 0x140);
-            acc.y = a1 + MSDA_DPP(a1, 0x140);
-            acc.z = a2 + MSDA_DPP(a2, 0x140);
-            acc.w = a3 + MSDA_DPP(a3, 0x140);
-            const int q = s_rowq[step * 4 + g_row];
-            if (g_half == 0 && q >= 0) {
-                const unsigned pm = (q_base + (unsigned)q) * (unsigned)M + (unsigned)m;
-                *reinterpret_cast<f32x4 *>(out + ((size_t)pm * 32u + (unsigned)g_chunk * 4u)) = acc;
-            }
+            finish_row(acc);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         WIN_STAMP();   // 9 + 3 it: gathered, stored
+    }
     }
 #undef WIN_STAMP
     if (pl.stats != nullptr) {      // kernel selection: this launch's counts out, the totals so far to the host

@@ -76,6 +76,7 @@ def test_win_forward_full_size_matches_oracle(msda, hip_lib, pyr, dist):
 CONFIGS = [
     dict(),                                                    # defaults: 16 x 16 pixel regions, 512 threads, windows on levels 1-3
     dict(fwd_win_early=0),                                     # ... all level-0 points after the LDS phase
+    dict(fwd_win_early=2),                                     # ... two of them requested before it
     dict(fwd_win_rlog=3, fwd_win_block=256),                   # 8 x 8 pixel regions, 256 threads (rounds 3-4's default)
     dict(fwd_win_rlog=3, fwd_win_block=256, fwd_win_wps=4, fwd_win_early=2),
     dict(fwd_win_rlog=3, fwd_win_rlogx=4, fwd_win_block=256),  # 16 x 8 pixel regions (170 rows per workgroup)
@@ -171,8 +172,8 @@ FUSED_PYRAMIDS = [
 
 @pytest.mark.parametrize("case", FUSED_PYRAMIDS, ids=lambda c: f"seed{c[0]}")
 @pytest.mark.parametrize("cfg", [dict(), dict(fwd_win_rlog=3, fwd_win_block=256), dict(fwd_win_l0=0),
-                                 dict(fwd_win_margins=0x1111, fwd_win_block=512)],
-                         ids=["default", "r3_b256", "all_levels", "m1_b512"])
+                                 dict(fwd_win_margins=0x1111, fwd_win_block=512), dict(fwd_win_early=0)],
+                         ids=["default", "r3_b256", "all_levels", "m1_b512", "e0"])
 def test_win_fused_forward_matches_checker(msda, hip_lib, case, cfg):
     seed, N, M, P, shapes, ref_dim = case
     for k, v in cfg.items():
