@@ -388,6 +388,55 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
     const unsigned q_base = (unsigned)b * (unsigned)pl.Lq;
     const int lwin0 = pl.lwin0;
 
+    // ---- the windows' fill (LDS-DMA) and, with a padding mask, the mask bytes of the pixels this wavefront fills ----
+    auto fill_windows = [&]() {
+        // ---- fill the windows: 8 pixels (1 KiB) per wave instruction; cells outside the level / padded read 0.
+        //      Every level's window starts on a group boundary, so the level is uniform per instruction.  (One
+        //      instruction per window ROW needs a third of the address arithmetic but 40 % more, partly filled,
+        //      DMA instructions: measured slower, 16.6 vs 14.7 us for the start-up phase alone) ----
+        //      The padding mask is NOT consulted here: a mask byte ahead of every DMA address makes each fill
+        //      instruction wait a memory round trip (and, vmcnt being in-order, for every DMA before it).  The bytes
+        //      are requested below, next to the fill, and padded pixels are zeroed in LDS once both have landed.
+        for (int l = lwin0; l <= L; ++l) {        // l == L: the group that holds the zero row
+            const int g0 = tb.wbase[l < L ? l : kWinMaxL] >> 3;
+            const int g1 = l < L ? (tb.wbase[l + 1 < L ? l + 1 : kWinMaxL] >> 3) : pl.groups;
+            const int lc = l < L ? l : L - 1;
+            const int ww = tb.ww[lc], npx = l < L ? ww * tb.wh[lc] : 0, magic = tb.wmagic[lc];
+            const int oy = tb.oy[lc], ox = tb.ox[lc], H = tb.H[lc], W = tb.W[lc];
+            const unsigned lbase = row_base + (unsigned)tb.lstart[lc] * pix_stride + (unsigned)(lane & 7) * 16u;
+            for (int g = g0 + wave; g < g1; g += nw) {
+                const int local = (g - g0) * 8 + (lane >> 3);
+                const int wy = (local * magic) >> 16, wx = local - wy * ww;
+                const int gy = oy + wy, gx = ox + wx;
+                const bool inside = (local < npx) & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
+                const int cell = gy * W + gx;
+                const unsigned off = inside ? lbase + (unsigned)cell * pix_stride : kOobOffset;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(vr, (lds_void *)(s_dyn + (size_t)g * 1024), 16, (int)off, 0, 0, 0);
+            }
+        }
+        // the mask bytes of the pixels THIS wavefront filled (8 lanes x 8 groups per level: make_win_plan's
+        // wgroups_max keeps a level's window within 64 * nw pixels when there is a mask), in flight with the fill
+        if (FUSED && src.mask != nullptr) {
+            const unsigned char *mk = src.mask + (size_t)b * pl.S;
+#pragma unroll
+            for (int l = 0; l < kWinMaxL; ++l) {
+                mpad[l] = 0;
+                if (l >= lwin0 && l < L) {
+                    const int g0 = tb.wbase[l] >> 3, g1 = tb.wbase[l + 1 < L ? l + 1 : kWinMaxL] >> 3;
+                    const int g = g0 + wave + (lane >> 3) * nw;
+                    const int local = (g - g0) * 8 + (lane & 7);
+                    const int ww = tb.ww[l], wy = (local * tb.wmagic[l]) >> 16, wx = local - wy * ww;
+                    const int gy = tb.oy[l] + wy, gx = tb.ox[l] + wx;
+                    const bool inside = (g < g1) & (local < ww * tb.wh[l]) & ((unsigned)gy < (unsigned)tb.H[l]) &
+                                        ((unsigned)gx < (unsigned)tb.W[l]);
+                    if (inside) mpad[l] = mk[tb.lstart[l] + gy * tb.W[l] + gx];
+                }
+            }
+        }
+    };
+    // placement from the record's means: the fill -- the long pole of the prologue -- goes out before anything else
+    if (!measure && lwin0 < L) fill_windows();
+
     // the region's rows -> query indices, once
     const int steps = __builtin_amdgcn_readfirstlane(tb.steps);     // of THIS region (pl.steps: of a complete one)
     for (int r = tid; r < steps * 4; r += (int)blockDim.x) {
@@ -401,9 +450,7 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
     WinRaw raw;
     const WinRow row = win_row(tb, L, step * 4 + s_rs, b, m, M, pl.Lq);
     row_ok = row.ok;
-    // (placement from the record: the rows' own inputs are requested AFTER the fill.  Vector-memory results return in
-    //  order; these loads stream from HBM while the fill mostly hits the L2, and queued in front of it they held the
-    //  fill's data back -- the prologue alone took 23.7 instead of 12 us)
+    // (placement from the record: the fill is already out; the rows' own inputs follow it below)
     if (measure) raw = win_load_raw<FUSED>(src, row.qrow, row.pm, m, L, LP, s_t, s_l);
     // mean sampling offset per windowed level on this wavefront's first rows: for the placement (measuring mode, before
     // the fill) or for the record's running means (counting workgroups, after the fill has been issued)
@@ -479,49 +526,7 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
             WIN_STAMP();
         }
 
-        // ---- fill the windows: 8 pixels (1 KiB) per wave instruction; cells outside the level / padded read 0.
-        //      Every level's window starts on a group boundary, so the level is uniform per instruction.  (One
-        //      instruction per window ROW needs a third of the address arithmetic but 40 % more, partly filled,
-        //      DMA instructions: measured slower, 16.6 vs 14.7 us for the start-up phase alone) ----
-        //      The padding mask is NOT consulted here: a mask byte ahead of every DMA address makes each fill
-        //      instruction wait a memory round trip (and, vmcnt being in-order, for every DMA before it).  The bytes
-        //      are requested below, next to the fill, and padded pixels are zeroed in LDS once both have landed.
-        for (int l = lwin0; l <= L; ++l) {        // l == L: the group that holds the zero row
-            const int g0 = tb.wbase[l < L ? l : kWinMaxL] >> 3;
-            const int g1 = l < L ? (tb.wbase[l + 1 < L ? l + 1 : kWinMaxL] >> 3) : pl.groups;
-            const int lc = l < L ? l : L - 1;
-            const int ww = tb.ww[lc], npx = l < L ? ww * tb.wh[lc] : 0, magic = tb.wmagic[lc];
-            const int oy = tb.oy[lc], ox = tb.ox[lc], H = tb.H[lc], W = tb.W[lc];
-            const unsigned lbase = row_base + (unsigned)tb.lstart[lc] * pix_stride + (unsigned)(lane & 7) * 16u;
-            for (int g = g0 + wave; g < g1; g += nw) {
-                const int local = (g - g0) * 8 + (lane >> 3);
-                const int wy = (local * magic) >> 16, wx = local - wy * ww;
-                const int gy = oy + wy, gx = ox + wx;
-                const bool inside = (local < npx) & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
-                const int cell = gy * W + gx;
-                const unsigned off = inside ? lbase + (unsigned)cell * pix_stride : kOobOffset;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(vr, (lds_void *)(s_dyn + (size_t)g * 1024), 16, (int)off, 0, 0, 0);
-            }
-        }
-        // the mask bytes of the pixels THIS wavefront filled (8 lanes x 8 groups per level: make_win_plan's
-        // wgroups_max keeps a level's window within 64 * nw pixels when there is a mask), in flight with the fill
-        if (FUSED && src.mask != nullptr) {
-            const unsigned char *mk = src.mask + (size_t)b * pl.S;
-#pragma unroll
-            for (int l = 0; l < kWinMaxL; ++l) {
-                mpad[l] = 0;
-                if (l >= lwin0 && l < L) {
-                    const int g0 = tb.wbase[l] >> 3, g1 = tb.wbase[l + 1 < L ? l + 1 : kWinMaxL] >> 3;
-                    const int g = g0 + wave + (lane >> 3) * nw;
-                    const int local = (g - g0) * 8 + (lane & 7);
-                    const int ww = tb.ww[l], wy = (local * tb.wmagic[l]) >> 16, wx = local - wy * ww;
-                    const int gy = tb.oy[l] + wy, gx = tb.ox[l] + wx;
-                    const bool inside = (g < g1) & (local < ww * tb.wh[l]) & ((unsigned)gy < (unsigned)tb.H[l]) &
-                                        ((unsigned)gx < (unsigned)tb.W[l]);
-                    if (inside) mpad[l] = mk[tb.lstart[l] + gy * tb.W[l] + gx];
-                }
-            }
-        }
+        if (measure) fill_windows();
     }
     if (!measure) {
         raw = win_load_raw<FUSED>(src, row.qrow, row.pm, m, L, LP, s_t, s_l);
@@ -609,7 +614,8 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
                 ok11 = ok11 && !c_mask[ok11 ? cell + cW + 1 : 0];
             }
             if (ablate & 4) {      // profiling only (tools/fwd_offset_sweep.py): which points left their window
-                const int qq = s_rowq[st_ * 4 + s_rs];
+                const WinRow wq_ = win_row(tb, L, st_ * 4 + s_rs, b, m, M, pl.Lq);      // (not the table: first step, no barrier yet)
+                const int qq = wq_.ok ? (int)(wq_.qrow - q_base) : -1;
                 if (c_pt && qq >= 0)
                     out[(size_t)((q_base + (unsigned)qq) * (unsigned)M + (unsigned)m) * 32u + (unsigned)s_t] =
                         (need && c_windowed) ? 2.f : ((live && c_windowed) ? 1.f : 0.f);
@@ -630,16 +636,25 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
         
     };
     // the inputs of step st_ (its rows' projection rows / locations): requested a step ahead
-    auto prefetch_step = [&](int st_) {
-        const int q = s_rowq[st_ * 4 + s_rs];
+    // (`table`: the row -> query table may be read -- it is written by all wavefronts before the first step and the
+    //  first workgroup barrier after that is the one that waits for the windows: the prefetch of the first iteration
+    //  computes its row instead.  Round 5's placement without barriers exposed this; with the measuring placement the two
+    //  placement barriers happened to cover it)
+    auto prefetch_step = [&](int st_, bool table) {
+        int q;
+        if (table) {
+            q = s_rowq[st_ * 4 + s_rs];
+        } else {
+            const WinRow w = win_row(tb, L, st_ * 4 + s_rs, b, m, M, pl.Lq);
+            q = w.ok ? (int)(w.qrow - q_base) : -1;
+        }
         row_ok = q >= 0;
         const unsigned qrow = q_base + (unsigned)(q < 0 ? 0 : q);
         raw = win_load_raw<FUSED>(src, qrow, qrow * (unsigned)M + (unsigned)m, m, L, LP, s_t, s_l);
     };
     // the windows must have landed before the first LDS-served point (first iteration, every wavefront)
     auto windows_landed = [&]() {
-        const int it = 0;
-        if (it == 0 && lwin0 < L) {
+        if (lwin0 < L) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (FUSED && src.mask != nullptr) {       // this wavefront's fill has landed: zero its padded pixels
 #pragma unroll
@@ -652,8 +667,8 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
                     }
                 }
             }
-            __syncthreads();
         }
+        __syncthreads();      // (also: the row -> query table is complete from here on, windows or not)
     };
     // the LDS-served points of the step whose records are in place
     auto lds_points = [&](unsigned gmask, f32x4 acc) -> f32x4 {
@@ -723,7 +738,7 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
         unsigned gmask = 0u;
         if (have) gmask = stage_step(step);
         WIN_STAMP();   // 7 + 3 it: staged
-        if (step + nw < steps) prefetch_step(step + nw);
+        if (step + nw < steps) prefetch_step(step + nw, it > 0);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 

@@ -109,7 +109,7 @@ std::atomic<int> opt_fwd_win_ablate{0};     // profiling only
 std::atomic<int> opt_fwd_win_place{0};      // 1: measured window placement in every workgroup (rounds 3-4)
 std::atomic<int> opt_fwd_win_wps{0};        // 3 / 4: force the 168- / 128-register build
 std::atomic<int> opt_fwd_win_early{9};      // 0 / 2 / 4: level-0 points requested before the LDS phase (else: by register budget)
-constexpr int kWinEarlyW4 = 2;              // ... of the 128-register build
+constexpr int kWinEarlyW4 = 0;              // ... of the 128-register build (0 and 2 time the same; 0 needs 107 registers, no spill)
 std::atomic<int> opt_bwd_side_rows{1};      // slim split backward: side kernels with one lane per (query, head) row (0: one lane per point)
 std::atomic<int> opt_fwd_win_trace_lo{0}, opt_fwd_win_trace_hi{0};   // profiling: device address of the timeline buffer (31 + 31 bits)
        // profiling only: drop parts of the tiled backward (results are then wrong)
@@ -570,16 +570,16 @@ int forward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart, 
                             else MSDA_LAUNCH_WIN(false, 3, 4, "msda_fwd_d32_win<w3,e4>");
                         }
                     } else if (early == 2) {
-                        if (fused) {
-                            if (wp.trace || wp.ablate) MSDA_LAUNCH_WIN_T(true, 4, 2, "msda_fwd_d32_win<fused,w4,e2>");
-                            else MSDA_LAUNCH_WIN(true, 4, 2, "msda_fwd_d32_win<fused,w4,e2>");
-                        } else {
-                            if (wp.trace || wp.ablate) MSDA_LAUNCH_WIN_T(false, 4, 2, "msda_fwd_d32_win<w4,e2>");
-                            else MSDA_LAUNCH_WIN(false, 4, 2, "msda_fwd_d32_win<w4,e2>");
-                        }
+                        if (fused) MSDA_LAUNCH_WIN(true, 4, 2, "msda_fwd_d32_win<fused,w4,e2>");
+                        else MSDA_LAUNCH_WIN(false, 4, 2, "msda_fwd_d32_win<w4,e2>");
                     } else {
-                        if (fused) MSDA_LAUNCH_WIN(true, 4, 0, "msda_fwd_d32_win<fused,w4>");
-                        else MSDA_LAUNCH_WIN(false, 4, 0, "msda_fwd_d32_win<w4>");
+                        if (fused) {
+                            if (wp.trace || wp.ablate) MSDA_LAUNCH_WIN_T(true, 4, 0, "msda_fwd_d32_win<fused,w4>");
+                            else MSDA_LAUNCH_WIN(true, 4, 0, "msda_fwd_d32_win<fused,w4>");
+                        } else {
+                            if (wp.trace || wp.ablate) MSDA_LAUNCH_WIN_T(false, 4, 0, "msda_fwd_d32_win<w4>");
+                            else MSDA_LAUNCH_WIN(false, 4, 0, "msda_fwd_d32_win<w4>");
+                        }
                     }
 #undef MSDA_LAUNCH_WIN
 #undef MSDA_LAUNCH_WIN_T
