@@ -26,9 +26,11 @@ def msda(hip_lib):
     return MSDA
 
 
-@pytest.fixture(autouse=True, params=[0, 10, 12], ids=["bwd_default", "bwd_tile_lv", "bwd_tile_bins"])
+@pytest.fixture(autouse=True, params=[0, 10], ids=["bwd_default", "bwd_tile_lv"])
 def _bwd_family(request, hip_lib):
-    """Every test of this file runs with the default backward and with each region-tiled family forced."""
+    """Every test of this file runs with the default backward (the counting-sort kernel at the selector's level for
+    pyramids, the row kernel for decoder shapes) and with the fixed-point window family forced.  (Round 4 also forced
+    variant 12 -- the kernel the default already runs at these inputs.)"""
     hip_lib.set_option("bwd_variant", request.param)
     yield
     for k in ("fwd_variant", "bwd_variant"):
@@ -39,11 +41,28 @@ def _cpu(x):
     return {k: v.detach().cpu().numpy() for k, v in x.items() if isinstance(v, torch.Tensor)}
 
 
+_ORACLE_CACHE = {}
+
+
 def _oracle(c):
+    """The C oracle on the host copy of the inputs; the same seeded inputs come back once per backward family, so the
+    result is kept (keyed on a digest of the inputs: 0.2 + 0.9 s per full-size call otherwise)."""
+    import hashlib
     from oracle import msda_oracle as oracle
-    out = oracle.forward(c["value"], c["shapes"], c["level_start"], c["loc"], c["attn"])
-    gv, gl, ga = oracle.backward(c["value"], c["shapes"], c["level_start"], c["loc"], c["attn"], c["grad_out"])
-    return out, gv, gl, ga
+    h = hashlib.sha1()
+    for k in ("value", "loc", "attn", "grad_out", "shapes"):
+        a = np.ascontiguousarray(c[k])
+        h.update(str(a.shape).encode())
+        h.update(a.tobytes()[:1 << 22])
+        h.update(a.tobytes()[-(1 << 16):])
+    key = h.hexdigest()
+    if key not in _ORACLE_CACHE:
+        if len(_ORACLE_CACHE) > 6:
+            _ORACLE_CACHE.clear()
+        out = oracle.forward(c["value"], c["shapes"], c["level_start"], c["loc"], c["attn"])
+        gv, gl, ga = oracle.backward(c["value"], c["shapes"], c["level_start"], c["loc"], c["attn"], c["grad_out"])
+        _ORACLE_CACHE[key] = (out, gv, gl, ga)
+    return _ORACLE_CACHE[key]
 
 
 def _hip(msda, x):
