@@ -344,12 +344,21 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
 #endif
     const bool stat_wg = MSDA_WIN_STATS && pl.stats != nullptr && (sw & 7) == 0;
     const bool measure = pl.measure != 0;          // block-uniform
+    bool hint_valid = true;
     // windows of the windowed levels: centred on the region + this head's mean sampling offset on that level, as the
     // launches before this one measured it (round 5; no dependent round trip in front of the fill any more)
     if (!measure) {
         const float *hp = reinterpret_cast<const float *>(pl.stats + kSelHintWord) + m * (kSelHintLevels * 2);
         // (agent-scope loads: the means were written by the previous launch's publishing wavefront; a scalar load
         //  could be served by a constant cache that launch boundary did not invalidate)
+        // (a counting workgroup notes NOW whether the means it is about to use were measured: by the time it reports, this
+        //  launch's own publishing wavefront may have set the flag -- the first launch of a call site, windows centred
+        //  on nothing, would then report its misplaced points and send the selector to the gather kernel for 32 calls)
+        if (stat_wg) {       // (bit head * 4 + level: every windowed level of THIS head must have a measured mean)
+            const unsigned long long have = __hip_atomic_load(pl.stats + kSelHintValidWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned want = ((1u << L) - 1u) & ~((1u << pl.lwin0) - 1u);
+            hint_valid = m < kSelHintHeads && (((unsigned)(have >> (m * kSelHintLevels)) & want) == want);
+        }
         float hx = 0.f, hy = 0.f;
         if (tid >= pl.lwin0 && tid < L && m < kSelHintHeads) {
             hx = __hip_atomic_load(hp + 2 * tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -833,7 +842,6 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) n_off += __shfl_xor(n_off, o, 64);
             // (a launch whose windows were placed without measured means says nothing about the offsets)
-            const bool hint_valid = measure || __hip_atomic_load(pl.stats + kSelHintValidWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull;
             if (lane == 0 && hint_valid) sel_add(pl.stats, pl.sel_level, (unsigned)((sw >> 3) * nw + wave), n_live, n_off, 0u);
         }
         if (sw == 0 && wave == 1) {

@@ -45,8 +45,8 @@ constexpr int kSelCntWords = kSelLevels * kSelShards * 4;
 constexpr int kSelDevWords = 1024;                      // 8 KiB per record
 // ... and, for the windowed forward, where its windows go (device-only, never read by the host): per (head, level) the
 // running sums {dx, dy, n} of the sampling offsets relative to the query's own pixel (floats, added by the counting
-// workgroups, consumed by the publishing wavefront), the mean offsets the NEXT launches centre their windows on, and a
-// flag "means have been measured"
+// workgroups, consumed by the publishing wavefront), the mean offsets the NEXT launches centre their windows on, and
+// one bit per (head, level) "this mean has been measured"
 constexpr int kSelHintHeads = 16, kSelHintLevels = 4;
 constexpr int kSelHintAccWord = 392;                    // 16 x 4 x {dx, dy, n, -} floats
 constexpr int kSelHintWord = kSelHintAccWord + kSelHintHeads * kSelHintLevels * 2;      // 16 x 4 x {dx, dy} floats
@@ -134,7 +134,7 @@ __device__ __forceinline__ void sel_publish(unsigned long long *dev, unsigned lo
 }
 
 // Window placement of the windowed forward, device side only.  A counting workgroup adds the offsets it measured on its
-// first rows; the publishing wavefront (lane = (head, level)) turns a batch of at least 64 samples into the mean the next
+// first rows; the publishing wavefront (lane = (head, level)) turns a batch of at least 32 samples into the mean the next
 // launches use and takes the batch out (an exchange: what later workgroups of the same launch add stays for the next
 // publisher).  No argument changes from launch to launch, so replayed captures keep adapting.
 __device__ __forceinline__ void sel_hint_add(unsigned long long *dev, int head, int level, float sx, float sy, float n) {
@@ -150,7 +150,7 @@ __device__ __forceinline__ void sel_hint_publish(unsigned long long *dev, int la
     if (head < M && head < kSelHintHeads && level < L) {
         float *a = reinterpret_cast<float *>(dev + kSelHintAccWord) + (head * kSelHintLevels + level) * 4;
         const float n0 = __hip_atomic_load(a + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (n0 >= 64.f) {
+        if (n0 >= 32.f) {
             const float n = __hip_atomic_exchange(a + 2, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const float sx = __hip_atomic_exchange(a + 0, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const float sy = __hip_atomic_exchange(a + 1, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -162,7 +162,9 @@ __device__ __forceinline__ void sel_hint_publish(unsigned long long *dev, int la
             }
         }
     }
-    if (__builtin_amdgcn_ballot_w64(any) != 0ull && lane == 0)
-        __hip_atomic_store(dev + kSelHintValidWord, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // one "measured" bit per (head, level): lane = head * 4 + level is the bit's number
+    const unsigned long long bits = __builtin_amdgcn_ballot_w64(any);
+    if (bits != 0ull && lane == 0)
+        __hip_atomic_fetch_or(dev + kSelHintValidWord, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 #endif

@@ -188,3 +188,24 @@ def test_selection_moves_under_replayed_bf16_training_encode_graphs(monkeypatch,
     assert cache.captures >= 2 and cache.eager == 0 and not cache.failed, (cache.captures, cache.eager)
     assert hip_lib.selector_poll() != 0
     hip_lib.set_call_site(0)
+
+
+def test_a_fresh_call_site_keeps_the_windowed_forward_from_its_first_call(hip_lib, site):
+    """The first launch of a call site places its windows without measured mean offsets (centred on the regions); what
+    leaves them then says nothing about the data, and must not reach the selector: at the initialisation's offsets every
+    one of the first calls runs the windowed kernel (round 5: the launch's own publishing wavefront used to validate
+    the means while later workgroups of the same launch were still reporting -- the site went to the gather kernel for 32
+    calls)."""
+    from memotr_amd import MultiScaleDeformableAttention as MSDA
+    from memotr_amd.MultiScaleDeformableAttention import tag_host_shapes
+    from memotr_amd.synth import make_inputs, to_fused_inputs
+    x = make_inputs(dist="encoder_like", device="cuda", seed=12)          # 800 x 1333
+    tag_host_shapes(x["shapes"], x["shapes_list"])
+    f = to_fused_inputs(x)
+    kernels = []
+    for _ in range(12):
+        MSDA.ms_deform_attn_fused_forward(x["value"], x["shapes"], x["level_start"], f["proj"], f["ref"], None, 8, 4)
+        torch.cuda.synchronize()
+        kernels.append(hip_lib.last_kernel())
+    assert all("msda_fwd_d32_win" in k for k in kernels), kernels
+    assert 0.0 <= hip_lib.selector_last()[1] < 0.05
