@@ -209,3 +209,27 @@ def test_a_fresh_call_site_keeps_the_windowed_forward_from_its_first_call(hip_li
         kernels.append(hip_lib.last_kernel())
     assert all("msda_fwd_d32_win" in k for k in kernels), kernels
     assert 0.0 <= hip_lib.selector_last()[1] < 0.05
+
+
+def test_more_call_sites_than_records_reuse_the_least_recently_used(hip_lib):
+    """256 records per process (one device block, allocated once); site number 257 takes over the record that has not
+    been used for longest instead of running blind, results stay the oracle's, and an evicted site simply starts over
+    (advisor, round 4: the table used to fill -- one slot per geometry -- and never free)."""
+    from memotr_amd import MultiScaleDeformableAttention as MSDA
+    x = _inputs("encoder_like")
+    want = _oracle(x)[0]
+    args = (x["value"], x["shapes"], x["level_start"], x["loc"], x["attn"], 64)
+    for site in range(9000, 9300):
+        MSDA.set_call_site(site)
+        out = MSDA.ms_deform_attn_forward(*args)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-4, atol=2e-5)
+    for site in (9000, 9299, 9150):                 # the first one was evicted long ago: a fresh record, same results
+        MSDA.set_call_site(site)
+        for _ in range(4):
+            out = MSDA.ms_deform_attn_forward(*args)
+        torch.cuda.synchronize()
+        assert "msda_fwd_d32_win" in hip_lib.last_kernel(), hip_lib.last_kernel()
+        np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-4, atol=2e-5)
+    assert hip_lib.selector_poll() in (0, hip_lib.selector_poll())       # (polling with 256 live records works)
+    MSDA.set_call_site(0)
