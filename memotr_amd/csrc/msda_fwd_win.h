@@ -76,6 +76,13 @@ struct WinTables {
     int rows, steps;
 };
 
+
+// 24-bit integer multiplies (v_mul_u32_u24 / v_mul_i32_i24: full rate; v_mul_lo_u32 and v_mad_u64_u32 are quarter rate
+// on CDNA -- seven of them per step were ~10 % of the step's VALU time).  make_win_plan keeps every operand in range:
+// queries and pixels per level below 2^23, row strides below 2^23.
+__device__ __forceinline__ unsigned win_umul24(unsigned a, unsigned b) { return (unsigned)__umul24(a, b); }
+__device__ __forceinline__ int win_mul24(int a, int b) { return __mul24(a, b); }
+
 struct WinRow {
     bool ok;
     int lq, py, px;
@@ -119,10 +126,11 @@ __device__ __forceinline__ WinRaw win_load_raw(const PointSrc &src, unsigned qro
     w.r = f32x4{0.f, 0.f, 0.f, 0.f};
     if (t < LP) {      // rows that do not exist read query 0: always a legal address
         if (FUSED) {
-            const float *off = src.proj + (qrow * (unsigned)src.proj_stride + (unsigned)((m * LP + t) * 2));
+            const unsigned prow = win_umul24(qrow, (unsigned)src.proj_stride);
+            const float *off = src.proj + (prow + (unsigned)((m * LP + t) * 2));
             w.a = *reinterpret_cast<const f32x2 *>(off);
-            w.w = src.proj[qrow * (unsigned)src.proj_stride + (unsigned)(src.n_off + m * LP + t)];
-            const float *rp = src.ref + (qrow * (unsigned)L + (unsigned)l) * (unsigned)src.ref_dim;
+            w.w = src.proj[prow + (unsigned)(src.n_off + m * LP + t)];
+            const float *rp = src.ref + ((win_umul24(qrow, (unsigned)L) + (unsigned)l) << (src.ref_dim >> 1));      // (x 2 or x 4)
             if (src.ref_dim == 2) {
                 const f32x2 r2 = *reinterpret_cast<const f32x2 *>(rp);
                 w.r.x = r2.x;
@@ -131,8 +139,9 @@ __device__ __forceinline__ WinRaw win_load_raw(const PointSrc &src, unsigned qro
                 w.r = *reinterpret_cast<const f32x4 *>(rp);
             }
         } else {
-            w.a = *reinterpret_cast<const f32x2 *>(src.loc + (pm * (unsigned)LP + (unsigned)t) * 2u);
-            w.w = src.attn[pm * (unsigned)LP + (unsigned)t];
+            const unsigned pt = win_umul24(pm, (unsigned)LP) + (unsigned)t;      // (pm < 2^24: make_win_plan)
+            w.a = *reinterpret_cast<const f32x2 *>(src.loc + pt * 2u);
+            w.w = src.attn[pt];
         }
     }
     return w;
@@ -613,13 +622,13 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
             // inside its window: LDS byte addresses (the window holds zeros outside the level / on padded pixels)
             const int wx = w0 - c_ox, wy = h0 - c_oy;
             const bool inwin = live && (unsigned)wx < c_wwm1 && (unsigned)wy < c_whm1;
-            const unsigned lbase = c_wbase + (unsigned)(wy * c_ww + wx) * 128u;
+            const unsigned lbase = c_wbase + (unsigned)(win_mul24(wy, c_ww) + wx) * 128u;
             // otherwise: byte offsets into `value`, out of range for corners that do not exist
             const bool need = live && !inwin;
             const bool okh0 = (unsigned)h0 < (unsigned)cH, okh1 = (unsigned)(h0 + 1) < (unsigned)cH;
             const bool okw0 = (unsigned)w0 < (unsigned)cW, okw1 = (unsigned)(w0 + 1) < (unsigned)cW;
             bool ok00 = okh0 && okw0, ok01 = okh0 && okw1, ok10 = okh1 && okw0, ok11 = okh1 && okw1;
-            const int cell = h0 * cW + w0;
+            const int cell = win_mul24(h0, cW) + w0;
             if (FUSED && c_mask != nullptr && need) {
                 ok00 = ok00 && !c_mask[ok00 ? cell : 0];
                 ok01 = ok01 && !c_mask[ok01 ? cell + 1 : 0];
@@ -633,7 +642,7 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
                     out[(size_t)((q_base + (unsigned)qq) * (unsigned)M + (unsigned)m) * 32u + (unsigned)s_t] =
                         (need && c_windowed) ? 2.f : ((live && c_windowed) ? 1.f : 0.f);
             }
-            const unsigned o00 = c_lbase + (unsigned)cell * pix_stride;
+            const unsigned o00 = c_lbase + (unsigned)win_mul24(cell, (int)pix_stride);      // (signed: cell is -W - 1 ... H W)
             ra.y = inwin ? lbase : (need ? (ok00 ? o00 : kOobOffset) | c_flag : c_dead);
             ra.w = inwin ? lbase + c_wrow : (need ? (ok10 ? o00 + c_wps : kOobOffset) : c_dead);
             rb.y = inwin ? lbase + 128u : (need ? (ok01 ? o00 + pix_stride : kOobOffset) | c_flag : c_dead);
@@ -663,7 +672,7 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
         }
         row_ok = q >= 0;
         const unsigned qrow = q_base + (unsigned)(q < 0 ? 0 : q);
-        raw = win_load_raw<FUSED>(src, qrow, qrow * (unsigned)M + (unsigned)m, m, L, LP, s_t, s_l);
+        raw = win_load_raw<FUSED>(src, qrow, win_umul24(qrow, (unsigned)M) + (unsigned)m, m, L, LP, s_t, s_l);
     };
     // the windows must have landed before the first LDS-served point (first iteration, every wavefront)
     auto windows_landed = [&]() {
@@ -741,7 +750,7 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
             acc.w = a3 + MSDA_DPP(a3, 0x140);
             const int q = s_rowq[step * 4 + g_row];
             if (g_half == 0 && q >= 0) {
-                const unsigned pm = (q_base + (unsigned)q) * (unsigned)M + (unsigned)m;
+                const unsigned pm = win_umul24(q_base + (unsigned)q, (unsigned)M) + (unsigned)m;
                 *reinterpret_cast<f32x4 *>(out + ((size_t)pm * 32u + (unsigned)g_chunk * 4u)) = acc;
             }
     };
@@ -870,7 +879,7 @@ inline bool make_win_plan(WinPlan &pl, const int64_t *shapes_host, int N, int S,
     for (int l = 0; l < kWinMaxL; ++l) {
         if (l < L) {
             const long H = shapes_host[2 * l], W = shapes_host[2 * l + 1];
-            if (H <= 0 || W <= 0 || H > 32767 || W > 32767 || W * M >= (1L << 23)) return false;
+            if (H <= 0 || W <= 0 || H > 32767 || W > 32767 || W * M >= (1L << 23) || H * W >= (1L << 23)) return false;
             const int sx = rlogx - l, sy = rlogy - l, side_x = 1 << sx, side_y = 1 << sy;
             int ww = 0, wh = 0;
             if (l >= lwin0) {
@@ -906,6 +915,8 @@ inline bool make_win_plan(WinPlan &pl, const int64_t *shapes_host, int N, int S,
         }
     }
     if (q != S) return false;      // the host shapes do not describe this value tensor
+    // 24-bit multiplies in the step loop: (query, head) rows, projection-row offsets' factors and row strides in range
+    if ((long)N * Lq * M >= (1L << 24) || (long)M * 128 >= (1L << 23) || L * P > 16) return false;
     for (int l = L; l <= kWinMaxL; ++l) { pl.row0[l] = rows; pl.wbase[l] = px; }
     pl.rows = rows; pl.steps = (rows + 3) / 4; pl.RY = RY; pl.RX = RX;
     pl.RYf = (int)(shapes_host[0] >> rlogy); pl.RXf = (int)(shapes_host[1] >> rlogx);
