@@ -227,15 +227,18 @@ int msda_fused_points_f32(const int64_t *shapes_dev, const float *proj, int proj
                           float *loc_out, float *attn_out, void *stream);
 
 /* ---- tuning knobs (benchmarks / tests only; defaults pick the fastest correct path) ----
- * key: "fwd_variant" | "bwd_variant" (0 = auto, 1 = generic one-thread-per-output
- *       kernels, >=2 = specialised kernels), "fwd_block" | "bwd_block"
- *       (threads per block, multiple of 64), "fwd_grid_mult" | "bwd_grid_mult" (blocks per CU),
- *       "fwd_tile_margin" | "bwd_tile_margin" (LDS window margin in pixels), "fwd_tile_l0" (first pyramid level the
- *       hybrid forward serves from LDS), "bwd_split" (1 = the three-kernel fused backward when a workspace is given),
+ * key: "fwd_variant" (0 = auto, 1 = generic one-thread-per-output kernel, 3 = D = 32 gather, 12 = windowed forward) |
+ *       "bwd_variant" (0 = auto, 1 = generic, 10 = fixed-point windows, 12 = counting sort), see DESIGN.md;
+ *       "fwd_block" | "bwd_block" (threads per block, multiple of 64), "fwd_grid_mult" | "bwd_grid_mult" (blocks per
+ *       CU), "bwd_tile_margin" (LDS window margin in pixels, variant 10), "bwd_split" (1 = the three-kernel fused
+ *       backward when a workspace is given),
  *       "fwd_win_auto" (1 = fp32 self-attention over the pyramid takes the windowed forward, variant 12; 0 = the
- *       gather kernel, the better choice once trained sampling offsets exceed the windows' 3-pixel margins),
- *       "fwd_win_*" (region size, block size, margins per level as 0xL3L2L1L0, first windowed level, LDS-DMA fill,
- *       profiling switches; tools/kbench.py lists them), "fwd_head_major" (head-major block numbering of the gather
+ *       gather kernel), "fwd_win_rlog" / "fwd_win_rlogx" / "fwd_win_block" (log2 of the region height / width on the
+ *       finest level and threads per workgroup; 0 = auto: 16 x 16 pixels, 512 threads), "fwd_win_margins" (per level as
+ *       0xL3L2L1L0), "fwd_win_l0" (first windowed level), "fwd_win_early" / "fwd_win_wps" (level-0 rows requested
+ *       ahead, register budget), "fwd_win_place" (1 = every workgroup measures its window placement, rounds 3-4;
+ *       0 = from the call site's running means), profiling switches; tools/fwd_win_sweep.py lists them;
+ *       "fwd_head_major" (head-major block numbering of the gather
  *       kernel), "bwd_rows" / "bwd_rows_block" (the 32-lanes-per-row backward of decoder-shaped calls),
  *       "bwd_wide_log2", "bwd_ablate" / "fwd_win_ablate" (profiling only: results are wrong by construction),
  *       "bwd_bins_margin" / "bwd_bins_margin_hi" / "bwd_bins_strip" (counting-sort backward, variant 12: window margins
