@@ -180,20 +180,30 @@ __global__ __launch_bounds__(kTileThreads, MSDA_BINS_WGS) void msda_bwd_d32_bins
     }
     __syncthreads();      // B0
 
-    // ---- phase 0: grad_out rows -> LDS, this thread's items ----
-    for (int idx = tid; idx < (rows + 1) * 8; idx += kTileThreads) {
-        const int r = idx >> 3, c = idx & 7;
+    // ---- phase 0: grad_out rows -> LDS, this thread's items.  Every global input of the phase is requested before
+    //      the first one is used (round 5; the staging loop and the items used to be a chain of seven dependent round
+    //      trips per workgroup: three staging iterations, then location -> attention weight per item).  Rows that do
+    //      not exist read row 0 and are zeroed afterwards: no branch stands between the requests ----
+    constexpr int kStageIters = ((kTileMaxRows + 1) * 8 + kTileThreads - 1) / kTileThreads;
+    const int n_stage = (rows + 1) * 8;
+    f32x4 st_g[kStageIters];
+    bool st_ok[kStageIters];
+#pragma unroll
+    for (int i = 0; i < kStageIters; ++i) {
+        const int idx = tid + i * kTileThreads;
+        const int r = (idx >> 3) < rows ? (idx >> 3) : rows;        // (row `rows` is the zero row)
         const unsigned pm = ROWP[r];
-        f32x4 g = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (pm != 0xffffffffu) g = bins_load_g4<TV>(grad_out + (pm * (unsigned)D + (unsigned)(c * 4)));
-        *reinterpret_cast<f32x4 *>(G + (unsigned)r * kBinsGRow + (unsigned)c * 16u) = g;
+        st_ok[i] = pm != 0xffffffffu;
+        st_g[i] = bins_load_g4<TV>(grad_out + ((st_ok[i] ? pm : 0u) * (unsigned)D + (unsigned)((idx & 7) * 4)));
     }
     int it_r[NI];
     bool it_live[NI], it_gate[NI];
     int it_h0[NI], it_w0[NI];
     float it_lh[NI], it_lw[NI], it_a[NI];
     {
-        float sx = 0.f, sy = 0.f, cn = 0.f;
+        f32x2 raw[NI], r01[NI], r23[NI];
+        float araw[NI];
+        bool okk[NI];
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
             const int it = tid + k * kTileThreads;
@@ -202,16 +212,35 @@ __global__ __launch_bounds__(kTileThreads, MSDA_BINS_WGS) void msda_bwd_d32_bins
             const int r = bins_mul24(itc, bp.magic_p) >> 16, p = itc - bins_mul24(r, P);
             it_r[k] = r;
             const unsigned pm = ROWP[r];
-            const bool ok = live && pm != 0xffffffffu;
+            okk[k] = live && pm != 0xffffffffu;
+            const unsigned pmc = okk[k] ? pm : 0u;
             const unsigned t = (unsigned)(l * P + p);
-            f32x2 xy = f32x2{0.f, 0.f};
-            float a = 0.f;
-            if (ok) {
-                // (fused_loc: the module's own arithmetic, ms_deform_attn.py:114-120, the bits msda_fused_points_f32 exposes)
-                xy = bp.fused_loc ? fused_location<unsigned>(src, ROWQ[r], m, L, P, (int)t, l, H, W)
-                                  : *reinterpret_cast<const f32x2 *>(src.loc + (pm * (unsigned)LP + t) * 2u);
-                a = src.attn[pm * (unsigned)LP + t];
-            }
+            const unsigned qrow = ROWQ[r];           // (a real query row even when the row does not exist)
+            // (fused_loc: the module's own arithmetic, ms_deform_attn.py:114-120, the bits msda_fused_points_f32
+            //  exposes.  The source is chosen by address, not by branch -- a branch between two requests makes the
+            //  second wait for the first; operands a mode does not have re-read the first address)
+            const float *const p_raw = bp.fused_loc ? src.proj + (qrow * (unsigned)src.proj_stride + (unsigned)((m * LP) * 2) + t * 2u)
+                                                    : src.loc + (pmc * (unsigned)LP + t) * 2u;
+            const float *const rp = src.ref + (qrow * (unsigned)L + (unsigned)l) * (unsigned)src.ref_dim;
+            raw[k] = *reinterpret_cast<const f32x2 *>(p_raw);
+            r01[k] = *reinterpret_cast<const f32x2 *>(bp.fused_loc ? rp : p_raw);
+            r23[k] = *reinterpret_cast<const f32x2 *>(bp.fused_loc && src.ref_dim != 2 ? rp + 2 : p_raw);
+            araw[k] = src.attn[pmc * (unsigned)LP + t];
+        }
+#pragma unroll
+        for (int i = 0; i < kStageIters; ++i) {
+            const int idx = tid + i * kTileThreads;
+            if (idx < n_stage)
+                *reinterpret_cast<f32x4 *>(G + (unsigned)(idx >> 3) * kBinsGRow + (unsigned)(idx & 7) * 16u) =
+                    st_ok[i] ? st_g[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        float sx = 0.f, sy = 0.f, cn = 0.f;
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const bool ok = okk[k];
+            f32x2 xy = bp.fused_loc ? fused_location_from(raw[k], r01[k], r23[k], src.ref_dim, P, H, W) : raw[k];
+            xy = ok ? xy : f32x2{0.f, 0.f};
+            const float a = ok ? araw[k] : 0.f;
             const Sample<float> s = sample_setup<float>(xy.x, xy.y, H, W);
             const bool gate = s.gate && ok;
             it_live[k] = ok;                       // the row exists
@@ -477,6 +506,10 @@ __global__ __launch_bounds__(kTileThreads, MSDA_BINS_WGS) void msda_bwd_d32_bins
     const int half = lane >> 5, c32 = lane & 31;
     const unsigned sent = bp.o_x + total * 8u;                      // LDS offset of the terminator
     const unsigned g_a = ch_a * 16u, g_b = ch_b * 16u;
+    // (tried in round 5, measured, dropped -- profiles/r05_lib_ab_bwd_*.txt: several quads per cell for workgroups with
+    //  few non-empty cells, +3 us; the compacted list sorted by list length so that a wavefront's 16 cells have like trip
+    //  counts -- 35 % fewer inner iterations (tools/gather_sim.py), -2 us fused / 0 plain, not worth its 10-bit counters;
+    //  the four ticket atomics of an item issued without branches and the empty second item slot skipped per wavefront: 0)
     for (int round = 0; round * 64 + wave * 16 < (int)nz_total; ++round) {
         const int idx = round * 64 + wave * 16 + grp;
         const bool live = idx < (int)nz_total;

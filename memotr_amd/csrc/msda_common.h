@@ -129,6 +129,25 @@ __device__ __forceinline__ f32x2 fused_location(const PointSrc &s, IDX qrow, int
     return xy;
 }
 
+// The same arithmetic on operands that are already in registers (`off`: the raw offsets, `r01` / `r23`: the reference
+// point's xy / wh), for kernels that request every input of a phase before they use the first one.
+__device__ __forceinline__ f32x2 fused_location_from(f32x2 off, f32x2 r01, f32x2 r23, int ref_dim, int P, int H, int W) {
+#pragma clang fp contract(off)
+    f32x2 xy;
+    if (ref_dim == 2) {
+        const float dx = off.x / (float)W, dy = off.y / (float)H;
+        xy.x = r01.x + dx;
+        xy.y = r01.y + dy;
+    } else {
+        const float px = off.x / (float)P, py = off.y / (float)P;
+        const float qx = px * r23.x, qy = py * r23.y;
+        const float hx = qx * 0.5f, hy = qy * 0.5f;
+        xy.x = r01.x + hx;
+        xy.y = r01.y + hy;
+    }
+    return xy;
+}
+
 template <typename IDX>
 __device__ __forceinline__ const float *fused_logits(const PointSrc &s, IDX qrow, int m, int LP) {
     return s.proj + (qrow * (IDX)s.proj_stride + (IDX)(s.n_off + m * LP));

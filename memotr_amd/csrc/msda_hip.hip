@@ -303,7 +303,8 @@ bool sel_pool(int dev, hipStream_t stream) {
 
 // The record of a call site; null when the mechanism is off or the device's block does not exist yet (first call of
 // the process inside a capture): the call then runs at level 0 without statistics.  A full table hands the least
-// recently used record to the new key (its counters keep counting: the first record read is only a baseline).
+// recently used record to the new key (its counters keep counting: the first record read is only a baseline; the
+// forward's window placement words are cleared).
 SelSlot *sel_acquire(int kind, int M, int L, int P, int dt, hipStream_t stream) {
     if (!opt_auto_select.load()) return nullptr;
     SelKey k;
@@ -326,6 +327,18 @@ SelSlot *sel_acquire(int kind, int M, int L, int P, int dt, hipStream_t stream) 
     if (!pick || !sel_pool(k.dev, stream)) return nullptr;
     const int d = k.dev & 63, i = (int)(pick - g_sel);
     SelSlot &s = *pick;
+    if (s.used) {
+        // A record that changes hands keeps counting (the first read is a baseline), but the window placement the
+        // old call site measured -- mean offsets and their "measured" bits -- would centre the new site's windows on
+        // another module's offsets and report what leaves them: those words start over.  A memset cannot be recorded
+        // into a capture (it would replay); a capturing call with no record of its own runs without one.
+        if (stream_capturing(stream)) return nullptr;
+        unsigned long long *const rec = g_sel_pool_dev[d] + (size_t)i * kSelDevWords;
+        if (hipMemsetAsync(rec + kSelHintAccWord, 0, (size_t)(kSelHintValidWord + 1 - kSelHintAccWord) * 8, stream) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+    }
     s.key = k;
     s.dev = g_sel_pool_dev[d] + (size_t)i * kSelDevWords;
     s.host = g_sel_pool_host[d] + (size_t)i * kSelHostWords;
