@@ -574,14 +574,12 @@ int forward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart, 
                     }
                     if (early != 0 && early != 2 && early != 4) early = wps == 3 ? 4 : kWinEarlyW4;
                     if (early == 4) wps = 3;
+                    // (the profiling instantiation -- timeline stamps, ablation bits -- exists for the default shape only)
+                    if ((wp.trace || wp.ablate) && (wps == 3 || early == 2))
+                        return fail(MSDA_EINVAL, "fwd_win_trace / fwd_win_ablate: profiling build of the default launch shape only");
                     if (wps == 3) {
-                        if (fused) {
-                            if (wp.trace || wp.ablate) MSDA_LAUNCH_WIN_T(true, 3, 4, "msda_fwd_d32_win<fused,w3,e4>");
-                            else MSDA_LAUNCH_WIN(true, 3, 4, "msda_fwd_d32_win<fused,w3,e4>");
-                        } else {
-                            if (wp.trace || wp.ablate) MSDA_LAUNCH_WIN_T(false, 3, 4, "msda_fwd_d32_win<w3,e4>");
-                            else MSDA_LAUNCH_WIN(false, 3, 4, "msda_fwd_d32_win<w3,e4>");
-                        }
+                        if (fused) MSDA_LAUNCH_WIN(true, 3, 4, "msda_fwd_d32_win<fused,w3,e4>");
+                        else MSDA_LAUNCH_WIN(false, 3, 4, "msda_fwd_d32_win<w3,e4>");
                     } else if (early == 2) {
                         if (fused) MSDA_LAUNCH_WIN(true, 4, 2, "msda_fwd_d32_win<fused,w4,e2>");
                         else MSDA_LAUNCH_WIN(false, 4, 2, "msda_fwd_d32_win<w4,e2>");
