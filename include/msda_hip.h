@@ -206,11 +206,15 @@ int msda_fused_backward_ws_bf16(const uint16_t *value, const int64_t *shapes_dev
  *                        replays the graph captured at those levels and captures another when a level has moved; a call
  *                        made while its stream is capturing takes the level the last poll announced.  Every 32nd poll
  *                        announces one level down for records at a level without windows (the probe that lets a record
- *                        come back).  Returns the number of records read. */
+ *                        come back).  Returns the number of records read;
+ *   msda_selector_reset  forgets every record of every device (waits for the device, clears the blocks; captured graphs
+ *                        stay valid -- the blocks are not freed).  For processes that retire a model and build another,
+ *                        and for test suites: records of modules that no longer run still take part in the signature. */
 void msda_set_call_site(uint64_t site);
 int msda_selector_last(int *level, float *off_share, float *inner_share);
 int msda_selector_next(int kind, int level, int off_permille, int inner_permille);
 int msda_selector_poll(uint64_t *signature);
+int msda_selector_reset(void);
 
 /* ---- parity hooks ----
  * msda_sample_indices_f32: the integer side of the sampling arithmetic.  For every (n,q,m,l,p):

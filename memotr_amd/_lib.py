@@ -48,6 +48,7 @@ SYMBOLS = {
     "msda_selector_last": ([ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)], c_int),
     "msda_selector_next": ([c_int] * 4, c_int),
     "msda_selector_poll": ([ctypes.POINTER(ctypes.c_uint64)], c_int),
+    "msda_selector_reset": ([], c_int),
     "msda_set_option": ([ctypes.c_char_p, c_int], c_int),
     "msda_get_option": ([ctypes.c_char_p, ctypes.POINTER(c_int)], c_int),
 }
@@ -107,6 +108,13 @@ def selector_poll() -> int:
     sig = ctypes.c_uint64(0)
     lib.msda_selector_poll(ctypes.byref(sig))
     return int(sig.value)
+
+
+def selector_reset() -> None:
+    """Forget every selector record (waits for the device).  Captured graphs stay valid."""
+    rc = lib.msda_selector_reset()
+    if rc != 0:
+        raise RuntimeError(f"msda_selector_reset: {last_error()}")
 
 
 def selector_last():

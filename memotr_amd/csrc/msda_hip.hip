@@ -333,11 +333,13 @@ SelSlot *sel_acquire(int kind, int M, int L, int P, int dt, hipStream_t stream) 
         // another module's offsets and report what leaves them: those words start over.  A memset cannot be recorded
         // into a capture (it would replay); a capturing call with no record of its own runs without one.
         if (stream_capturing(stream)) return nullptr;
+#ifndef MSDA_SEL_KEEP_PLACEMENT      // (test builds only: the bug the reuse test pins)
         unsigned long long *const rec = g_sel_pool_dev[d] + (size_t)i * kSelDevWords;
         if (hipMemsetAsync(rec + kSelHintAccWord, 0, (size_t)(kSelHintValidWord + 1 - kSelHintAccWord) * 8, stream) != hipSuccess) {
             (void)hipGetLastError();
             return nullptr;
         }
+#endif
     }
     s.key = k;
     s.dev = g_sel_pool_dev[d] + (size_t)i * kSelDevWords;
@@ -911,6 +913,29 @@ int msda_selector_poll(uint64_t *signature) {
     }
     if (signature) *signature = h == 0xcbf29ce484222325ull ? 0ull : h;
     return n;
+}
+int msda_selector_reset(void) {
+    std::lock_guard<std::mutex> lock(g_sel_mu);
+    const size_t dbytes = (size_t)kSelSlots * kSelDevWords * 8, hbytes = (size_t)kSelSlots * kSelHostWords * 8;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    int rc = MSDA_OK;
+    for (int d = 0; d < 64; ++d) {
+        if (!g_sel_pool_dev[d]) continue;
+        // (launches in flight still count into the block: wait for them, then clear it)
+        if (hipSetDevice(d) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+            hipMemset(g_sel_pool_dev[d], 0, dbytes) != hipSuccess) {
+            const hipError_t e = hipGetLastError();
+            rc = fail((int)(e != hipSuccess ? e : hipErrorUnknown), "msda_selector_reset: device block not cleared");
+            continue;
+        }
+        memset(g_sel_pool_host[d], 0, hbytes);
+    }
+    (void)hipSetDevice(cur);
+    for (int i = 0; i < kSelSlots; ++i) g_sel[i].used = false;
+    g_sel_level = 0;
+    g_sel_frac = g_sel_inner = -1.f;
+    return rc;
 }
 const char *msda_last_error(void) { return g_err; }
 const char *msda_last_kernel(void) { return g_kernel; }

@@ -77,6 +77,11 @@ def _fresh_call_site(request):
         yield
         return
     from memotr_amd import MultiScaleDeformableAttention as MSDA
+    from memotr_amd import _lib
+    # ... and starts without records: msda_selector_poll()'s signature covers every record of the device, those of
+    # earlier tests' modules included (a record left at the top level announces a probe every 32nd poll, and a graph
+    # cache of the next test captures once more than that test counts on)
+    _lib.selector_reset()
     _TEST_SITE[0] += 1
     MSDA.set_call_site(_TEST_SITE[0])
     yield

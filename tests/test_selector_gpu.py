@@ -219,12 +219,21 @@ def test_more_call_sites_than_records_reuse_the_least_recently_used(hip_lib):
     x = _inputs("encoder_like")
     want = _oracle(x)[0]
     args = (x["value"], x["shapes"], x["level_start"], x["loc"], x["attn"], 64)
-    for site in range(9000, 9300):
+    # eight records first belong to modules with four times the sampling offsets: their window placement (mean offsets,
+    # "measured" bits) must not reach the call sites that inherit the records -- windows centred on another module's
+    # offsets lose most points, and the inheriting site would report that and leave for the gather kernel
+    far = _inputs("encoder_like", off_scale=4.0)
+    far_args = (far["value"], far["shapes"], far["level_start"], far["loc"], far["attn"], 64)
+    for site in range(8000, 8008):
+        MSDA.set_call_site(site)
+        for _ in range(12):
+            MSDA.ms_deform_attn_forward(*far_args)
+    for site in range(9000, 9300):                  # 9248 .. 9255 take over the eight records above
         MSDA.set_call_site(site)
         out = MSDA.ms_deform_attn_forward(*args)
     torch.cuda.synchronize()
     np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-4, atol=2e-5)
-    for site in (9000, 9299, 9150):                 # the first one was evicted long ago: a fresh record, same results
+    for site in (9000, 9299, 9150, 9248, 9255):     # the first one was evicted long ago: a fresh record, same results
         MSDA.set_call_site(site)
         for _ in range(4):
             out = MSDA.ms_deform_attn_forward(*args)
