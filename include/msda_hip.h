@@ -29,10 +29,12 @@
  *     without a device->host read.  Results never depend on it.
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls are
  *     asynchronous, never synchronise and are thread-safe.  Global state: the tuning
- *     options below and, for self-attention over the pyramid, one 32-byte device +
- *     32-byte mapped-host record per (call site, geometry) through which the kernels
- *     report how many sampling points left their windows (see "kernel selection";
- *     allocated on the first such call, never while `stream` is capturing).
+ *     options below and, for self-attention over the pyramid, one 8-KiB device +
+ *     128-byte mapped-host record per (device, direction, call site, M, L, P,
+ *     element size) -- NOT per geometry -- through which the kernels report how many
+ *     sampling points left their windows (see "kernel selection"; all records of a
+ *     device live in one block allocated on the first such call, never while
+ *     `stream` is capturing).
  *   - Buffers are borrowed for the duration of the enqueued work.  `out`,
  *     `grad_loc`, `grad_attn` are fully overwritten.  `grad_value` is accumulated
  *     into with hardware float atomics: it must be zero on entry (the reference
@@ -50,15 +52,14 @@
  *     (-1,H)x(-1,W) gate, zero padding per corner) is bit-identical to the
  *     reference kernels: the product loc*size rounded to float, then 0.5
  *     subtracted (.cuh:33-84,285-288; oracle built with -ffp-contract=off).
- *     For scalar_t = float this IS the reference binary's arithmetic, not one
- *     reading of it: `.cuh:285` subtracts the DOUBLE literal 0.5, so the float
- *     product is promoted to double before the subtraction -- a float multiply
- *     feeding a double add, which nvcc's -fmad (same-type mul + add only) cannot
- *     contract; the exact double subtraction rounded once to float equals the
- *     float subtraction.  Only the f64 instantiation could be fused by nvcc; the
- *     f64 entry points here follow the uncontracted source (tests/
- *     test_oracle_golden.py keeps the fused reading as a probe: 0 of 2.86 M
- *     indices differ on both benchmark distributions).
+ *     Whether the reference BINARY contracts `.cuh:285` (`loc * size - 0.5`) into
+ *     one fused multiply-add is UNDECIDED without nvcc: the literal 0.5 is a
+ *     double, so for scalar_t = float the source reads fpext(mul) - 0.5 -> fptrunc,
+ *     which a compiler may or may not narrow back to a float fma.  The library and
+ *     the oracle follow the uncontracted source; tests/test_oracle_golden.py keeps
+ *     the fused reading as a probe: zero of 2.86 M corner indices flip on either
+ *     benchmark distribution (17,063 of them do, by one pixel with a bilinear
+ *     weight <= 2^-23, for locations placed exactly on pixel centres).
  *     msda_sample_indices_f32 exposes the arithmetic for parity tests.
  */
 #ifndef MSDA_HIP_H_
@@ -185,7 +186,7 @@ int msda_fused_backward_ws_bf16(const uint16_t *value, const int64_t *shapes_dev
                                 int zero_grad_value, const int64_t *shapes_host,
                                 void *workspace, size_t workspace_bytes, void *stream);
 
-/* ---- kernel selection (round 4, records reworked in round 5 = ABI 5; memotr_amd/csrc/msda_select.h) ----
+/* ---- kernel selection (round 4, records reworked in round 5 = ABI 5, per-site poll = ABI 6; memotr_amd/csrc/msda_select.h) ----
  * The cost of the reference kernels does not depend on where the sampling points land
  * (ms_deform_im2col_cuda.cuh:237-403); the windowed kernels here are fast for points near their query and slow
  * for points far away.  With "fwd_variant" / "bwd_variant" 0 the library therefore follows the data: the windowed
@@ -207,6 +208,12 @@ int msda_fused_backward_ws_bf16(const uint16_t *value, const int64_t *shapes_dev
  *                        made while its stream is capturing takes the level the last poll announced.  Every 32nd poll
  *                        announces one level down for records at a level without windows (the probe that lets a record
  *                        come back).  Returns the number of records read;
+ *   msda_selector_poll_sites   (ABI 6) the same for the records of the `n_sites` call sites in `sites` only: a graph
+ *                        cache hashes the levels of the modules ITS graphs hold, so a move or a probe of another
+ *                        module's record does not change its key, and the signature does not depend on which slot of
+ *                        the table a site occupies.  `probe` != 0: records at a level without windows announce one level
+ *                        down (the caller counts its own polls).  Once a record has been polled, eager calls no longer
+ *                        overwrite what the poll announced (a cache's eager warm-up calls ahead of a capture used to);
  *   msda_selector_reset  forgets every record of every device (waits for the device, clears the blocks; captured graphs
  *                        stay valid -- the blocks are not freed).  For processes that retire a model and build another,
  *                        and for test suites: records of modules that no longer run still take part in the signature. */
@@ -214,6 +221,7 @@ void msda_set_call_site(uint64_t site);
 int msda_selector_last(int *level, float *off_share, float *inner_share);
 int msda_selector_next(int kind, int level, int off_permille, int inner_permille);
 int msda_selector_poll(uint64_t *signature);
+int msda_selector_poll_sites(const uint64_t *sites, int n_sites, int probe, uint64_t *signature);
 int msda_selector_reset(void);
 
 /* ---- parity hooks ----

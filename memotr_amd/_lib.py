@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MEMOTR_MSDA_LIB") or os.path.join(_HERE, "lib", "libmsda_hip.so")   # (override: A/B builds)
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 c_int = ctypes.c_int
 c_void_p = ctypes.c_void_p
@@ -48,6 +48,7 @@ SYMBOLS = {
     "msda_selector_last": ([ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)], c_int),
     "msda_selector_next": ([c_int] * 4, c_int),
     "msda_selector_poll": ([ctypes.POINTER(ctypes.c_uint64)], c_int),
+    "msda_selector_poll_sites": ([ctypes.POINTER(ctypes.c_uint64), c_int, c_int, ctypes.POINTER(ctypes.c_uint64)], c_int),
     "msda_selector_reset": ([], c_int),
     "msda_set_option": ([ctypes.c_char_p, c_int], c_int),
     "msda_get_option": ([ctypes.c_char_p, ctypes.POINTER(c_int)], c_int),
@@ -107,6 +108,17 @@ def selector_poll() -> int:
     would run at now (0: every record at level 0).  For code that replays captured launches: key the graph on it."""
     sig = ctypes.c_uint64(0)
     lib.msda_selector_poll(ctypes.byref(sig))
+    return int(sig.value)
+
+
+def selector_poll_sites(sites, probe: bool = False) -> int:
+    """`selector_poll` for the records of the call sites in `sites` only (a graph cache hashes the modules its graphs
+    hold); `probe`: records at a level without windows announce one level down -- the caller counts its own polls."""
+    sites = [int(s) & 0xFFFFFFFFFFFFFFFF for s in sites]
+    arr = (ctypes.c_uint64 * max(len(sites), 1))(*sites)
+    sig = ctypes.c_uint64(0)
+    if lib.msda_selector_poll_sites(arr, len(sites), 1 if probe else 0, ctypes.byref(sig)) < 0:
+        raise ValueError(f"msda_selector_poll_sites: {last_error()}")
     return int(sig.value)
 
 

@@ -349,6 +349,7 @@ SelSlot *sel_acquire(int kind, int M, int L, int P, int dt, hipStream_t stream) 
     s.seen = s.host[9];
     memset(s.last, 0, sizeof(s.last));
     s.level = s.eff = 0; s.calls = 0u; s.frac = s.frac_inner = -1.f;      // (-1: nothing measured yet)
+    s.polled = false; s.pub_seen = s.seen;
     s.stamp = ++g_sel_clock;
     s.used = true;
     return &s;
@@ -414,7 +415,11 @@ int sel_level(SelSlot *s, int kind, bool &probe, bool capturing = false) {
     } else {
         ++s->calls;
         level = pinned >= 0 ? pinned : s->level;
-        s->eff = s->level;
+        // (`eff` belongs to msda_selector_poll() once a caller polls: the eager warm-up calls a graph cache makes in
+        //  front of a capture used to reset it here, and the capture keyed on "probe one level down" then held the
+        //  top level's kernel -- advisor, round 5.  Without a polling caller a capture takes the level of the last
+        //  eager call, as before)
+        if (!s->polled) s->eff = s->level;
         if (pinned < 0 && level == top && (s->calls % kSelProbeEvery) == 0u) {
             level = top - 1;
             probe = true;
@@ -556,14 +561,20 @@ int forward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart, 
                     wp.ablate = opt_fwd_win_ablate.load();
                     wp.trace = reinterpret_cast<unsigned long long *>(((unsigned long long)opt_fwd_win_trace_hi.load() << 31) |
                                                                       (unsigned long long)opt_fwd_win_trace_lo.load());
-                    if (slot) {     // (cumulative counters, fixed addresses: a captured launch counts like an eager one)
+                    // The kernel's share denominator covers 16 staged steps per wavefront (one ballot) and its publisher is
+                    // wavefront 1: workgroup shapes reachable through the options only ("fwd_win_block" 128 / 256 with
+                    // 16 x 16 regions: 22-43 steps; 64 threads) run without statistics instead of reporting an inflated
+                    // off-window share (advisor, round 5)
+                    const int win_nw = threads / 64;
+                    const bool stats_ok = slot != nullptr && win_nw >= 2 && (wp.steps + win_nw - 1) / win_nw <= 16;
+                    if (stats_ok) {     // (cumulative counters, fixed addresses: a captured launch counts like an eager one)
                         wp.stats = slot->dev;
                         wp.stats_host = slot->host_dev;
                         wp.sel_level = sel;
                     }
                     // windows placed from the record's running mean offsets (no round trip in front of the fill); without
                     // a record, or on request, every workgroup measures its own first ("fwd_win_place" 1)
-                    wp.measure = (slot == nullptr || M > kSelHintHeads || L > kSelHintLevels || opt_fwd_win_place.load() != 0) ? 1 : 0;
+                    wp.measure = (!stats_ok || M > kSelHintHeads || L > kSelHintLevels || opt_fwd_win_place.load() != 0) ? 1 : 0;
                     // register budget by what the workgroup shape admits: three 256-thread workgroups per CU (40-53 KB
                     // of LDS each) -> 168 registers, all four level-0 points requested before the LDS phase; 512-thread
                     // workgroups (two per CU) or four small ones -> 128 registers, two of them
@@ -868,7 +879,7 @@ int backward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart,
 
 extern "C" {
 
-int msda_abi_version(void) { return 5; }
+int msda_abi_version(void) { return 6; }
 
 void msda_set_call_site(uint64_t site) { g_site = site; }
 
@@ -883,36 +894,61 @@ int msda_selector_next(int kind, int level, int off_permille, int inner_permille
     return sel_next_level(kind, level, (float)off_permille, (float)inner_permille, sel_rule(kind));
 }
 
-// For callers that REPLAY captured launches (no library call per launch): read every record of the current device,
-// move the levels, and return a signature of the levels a call would run at now (0 when nothing is selected).  Every
-// kSelProbeEvery-th poll announces one level down for the records that sit at a level without windows -- the graph
-// captured under that signature is the probe.
-int msda_selector_poll(uint64_t *signature) {
+static int selector_poll_impl(const uint64_t *sites, int n_sites, int probe, uint64_t *signature) {
     int dev = 0, n = 0;
     (void)hipGetDevice(&dev);
-    unsigned long long h = 0xcbf29ce484222325ull;
+    unsigned long long h = 0ull;
     const int pinned = opt_sel_level.load();
     if (opt_auto_select.load()) {
         std::lock_guard<std::mutex> lock(g_sel_mu);
-        const bool probe_tick = (++g_sel_tick % kSelProbeEvery) == 0ull;
+        // (unfiltered: every kSelProbeEvery-th poll of the process is a probe tick; filtered: the caller counts its own)
+        const bool probe_tick = sites ? probe != 0 : (++g_sel_tick % kSelProbeEvery) == 0ull;
         for (int i = 0; i < kSelSlots; ++i) {
             SelSlot &s = g_sel[i];
             if (!s.used || s.key.dev != dev) continue;
+            if (sites) {
+                bool mine = false;
+                for (int k = 0; k < n_sites && !mine; ++k) mine = sites[k] == s.key.site;
+                if (!mine) continue;
+            }
+            // launches are arriving (replayed graphs make no library call): the record is in use, whatever its stamp says
+            if (s.host[9] != s.pub_seen) { s.pub_seen = s.host[9]; s.stamp = ++g_sel_clock; }
             sel_refresh(&s);
             const int top = s.key.kind == 0 ? 1 : 2;
             s.eff = (s.level == top && probe_tick) ? top - 1 : s.level;
+            s.polled = true;
             const int level = pinned >= 0 ? pinned : s.eff;
             if (level != 0) {       // (records at level 0 -- the state before anything was measured -- leave no mark)
-                const unsigned long long w[3] = {(unsigned long long)i, s.key.site ^ ((unsigned long long)s.key.kind << 63),
+                // (site, direction, element size, level) -- not the slot index: the same levels give the same signature
+                //  after the least-recently-used rule has moved a site to another record.  Order-independent (a sum of
+                //  per-record hashes), for the same reason
+                const unsigned long long w[2] = {s.key.site ^ ((unsigned long long)s.key.kind << 63) ^ ((unsigned long long)s.key.dt << 56),
                                                  (unsigned long long)level};
-                for (int k = 0; k < 3; ++k)
-                    for (int b = 0; b < 8; ++b) h = (h ^ ((w[k] >> (8 * b)) & 0xffull)) * 0x100000001b3ull;
+                unsigned long long hr = 0xcbf29ce484222325ull;
+                for (int k = 0; k < 2; ++k)
+                    for (int b = 0; b < 8; ++b) hr = (hr ^ ((w[k] >> (8 * b)) & 0xffull)) * 0x100000001b3ull;
+                h += hr | 1ull;
             }
             ++n;
         }
     }
-    if (signature) *signature = h == 0xcbf29ce484222325ull ? 0ull : h;
+    if (signature) *signature = h;
     return n;
+}
+
+// For callers that REPLAY captured launches (no library call per launch): read every record of the current device,
+// move the levels, and return a signature of the levels a call would run at now (0 when nothing is selected).  Every
+// kSelProbeEvery-th poll announces one level down for the records that sit at a level without windows -- the graph
+// captured under that signature is the probe.  Returns the number of records read.
+int msda_selector_poll(uint64_t *signature) { return selector_poll_impl(nullptr, 0, 0, signature); }
+
+// The same for the records of the given call sites only (ABI 6): a graph cache hashes the levels of the modules its
+// graphs hold -- a level move or a probe of some other module's record no longer changes its key (advisor, round 5) --
+// and decides itself when its records probe (`probe` != 0: records at a level without windows announce one level down).
+int msda_selector_poll_sites(const uint64_t *sites, int n_sites, int probe, uint64_t *signature) {
+    if (n_sites < 0 || (n_sites > 0 && !sites)) return fail(MSDA_EINVAL, "msda_selector_poll_sites: null site list");
+    static const uint64_t none = 0;
+    return selector_poll_impl(sites ? sites : &none, n_sites, probe, signature);
 }
 int msda_selector_reset(void) {
     std::lock_guard<std::mutex> lock(g_sel_mu);

@@ -75,6 +75,8 @@ struct SelSlot {
     unsigned long long stamp;       // last use (least-recently-used replacement)
     int level;                      // what the data ask for
     int eff;                        // what a capturing call runs at (= level, or one below while a probe is due)
+    bool polled;                    // msda_selector_poll() has announced `eff`: eager calls leave it alone from then on
+    unsigned long long pub_seen;    // publishers' sequence number at the last poll (launches arriving = record in use)
     unsigned calls;
     float frac, frac_inner;         // last measured shares (of the valid corners)
 };

@@ -78,6 +78,11 @@ class ClipCriterion:
         self.num_classes = num_classes
         self.matcher = matcher
         self.n_det_queries = n_det_queries
+        # (checked HERE, where every rank fails alike: a rank that raised on its own long clip in front of the count
+        #  all-reduce would leave the others waiting in it -- advisor, round 5)
+        if max_frame_length > _MAX_CLIP_FRAMES:
+            raise ValueError(f"max_frame_length {max_frame_length}: the distributed count all-reduce carries at most "
+                             f"{_MAX_CLIP_FRAMES} frames per clip")
         self.max_frame_length = max_frame_length
         self.n_aux = n_aux
         self.use_dab = use_dab
@@ -138,15 +143,22 @@ class ClipCriterion:
         if is_distributed():
             # a fixed-length vector: ranks whose clips differ in length (a sampler that mixes sample lengths) still issue
             # the SAME collective -- the reference's per-frame all-reduces (criterion.py:208-214) would deadlock there
-            if len(host) > _MAX_CLIP_FRAMES + 1:
-                raise ValueError(f"clip of {len(host) - 1} frames: the count all-reduce carries at most {_MAX_CLIP_FRAMES}")
-            padded = host + [0.0] * (_MAX_CLIP_FRAMES + 1 - len(host))
+            # (the constructor bounds max_frame_length; a longer clip is a data error on THIS rank only -- its extra frames
+            #  stay out of the vector, so the collective still matches the other ranks', and the error is raised after it)
+            too_long = len(host) > _MAX_CLIP_FRAMES + 1
+            sent = host[:_MAX_CLIP_FRAMES + 1]
+            padded = sent + [0.0] * (_MAX_CLIP_FRAMES + 1 - len(sent))
+            # second half: 1 for every frame this rank's clip has -- a frame's mean count is over the ranks that HAVE it
+            padded += [1.0] * len(sent) + [0.0] * (_MAX_CLIP_FRAMES + 1 - len(sent))
             counts = torch.as_tensor(padded, dtype=torch.float, device=self.device)
             torch.distributed.all_reduce(counts)
-            counts = torch.clamp(counts / distributed_world_size(), min=1)
-            total = counts[0]
+            if too_long:
+                raise ValueError(f"clip of {len(host) - 1} frames: the count all-reduce carries at most {_MAX_CLIP_FRAMES}")
+            half = _MAX_CLIP_FRAMES + 1
+            total = torch.clamp(counts[0] / distributed_world_size(), min=1)
             if with_log:
-                per_frame = counts[1:len(host)].tolist()
+                have = torch.clamp(counts[half + 1:half + len(host)], min=1)
+                per_frame = torch.clamp(counts[1:len(host)] / have, min=1).tolist()
         else:
             total = max(host[0], 1.0)
             per_frame = [max(c, 1.0) for c in host[1:]]

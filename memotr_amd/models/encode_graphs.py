@@ -23,7 +23,7 @@ import torch
 from ..functions import clip_ops
 from ..utils.nested_tensor import NestedTensor
 from .decoder_graphs import checked_capture
-from .graph_cache import GraphCache
+from .graph_cache import GraphCache, selector_signature
 
 MAX_GRAPHS = 6           # each holds the activations of a whole batched encode
 
@@ -67,8 +67,8 @@ class EncodeGraphs(GraphCache):
         bufver = sum(b._version for b in self.core.backbone.buffers())
         # (a capture bakes the kernel choice of the encoder's self-attention calls in: the selector's signature moves
         # when the measured off-window share asks for another kernel -- replayed launches keep counting, msda_select.h)
-        from .. import _lib
-        key = (slot, tuple(frame.tensors.shape), frame.sizes, amp, clip_ops.config_key(), bufver, _lib.selector_poll())
+        key = (slot, tuple(frame.tensors.shape), frame.sizes, amp, clip_ops.config_key(), bufver,
+               selector_signature(self, self.core.transformer.encoder))
         entry = self.lookup(key, lambda: self._capture(frame, amp))
         if entry is None:
             return None

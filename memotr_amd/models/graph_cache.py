@@ -18,6 +18,25 @@ MISS_LIMIT = 12
 RETRY_AFTER = 200
 
 
+PROBE_EVERY = 32         # polls of one cache between probes of its records that sit at a level without windows
+
+
+def selector_signature(owner, root) -> int:
+    """The kernel-selection signature of the deformable-attention modules under ``root`` (csrc/msda_select.h): a capture
+    bakes their kernel choice in, replayed launches keep counting the points that leave their windows, and a cache keyed
+    on this replays -- or captures -- the graph of the levels in force.  Only the modules the graphs of ``owner`` hold
+    are hashed (a level move or probe of some other module's record used to change every cache's key: advisor, round 5),
+    and ``owner`` counts its own polls: every ``PROBE_EVERY``-th one announces the probe one level down."""
+    from .. import _lib
+    from ..modules.ms_deform_attn import MSDeformAttn
+    mods = owner.__dict__.get("_sel_modules")
+    if mods is None:
+        mods = owner.__dict__["_sel_modules"] = [m for m in root.modules() if isinstance(m, MSDeformAttn)]
+    sites = [m.__dict__["_msda_site"] for m in mods if m.__dict__.get("_msda_site") is not None]
+    owner.__dict__["_sel_polls"] = polls = owner.__dict__.get("_sel_polls", 0) + 1
+    return _lib.selector_poll_sites(sites, probe=polls % PROBE_EVERY == 0)
+
+
 def require_graphs() -> bool:
     return os.environ.get("MEMOTR_REQUIRE_GRAPHS", "0") == "1"
 

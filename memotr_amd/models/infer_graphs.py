@@ -21,7 +21,7 @@ import torch
 from ..functions import clip_ops
 from ..utils.nested_tensor import NestedTensor
 from .decoder_graphs import DecoderLoop, checked_capture
-from .graph_cache import MISS_LIMIT, RETRY_AFTER, GraphCache, require_graphs  # noqa: F401 (re-exported for the tests)
+from .graph_cache import MISS_LIMIT, RETRY_AFTER, GraphCache, require_graphs, selector_signature  # noqa: F401 (re-exported for the tests)
 
 MAX_GRAPHS = 8
 
@@ -134,9 +134,8 @@ class InferGraphs:
         # the selector's signature: a capture bakes the kernel choice of the encoder's self-attention calls in; replayed
         # launches keep counting the points that leave their windows, and when the share asks for another kernel the
         # signature moves and the graph captured (or to be captured) at the new levels takes over (msda_select.h)
-        from .. import _lib
         key = (getattr(frame, "encode_slot", 0), tuple(frame.tensors.shape), geometry, clip_ops.config_key(),
-               _fingerprint(core), bufver, _lib.selector_poll())
+               _fingerprint(core), bufver, selector_signature(self, core.transformer.encoder))
         constants = {}
 
         def make_fn():

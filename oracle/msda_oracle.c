@@ -185,13 +185,15 @@
 DEFINE_ORACLE(float, f32)
 DEFINE_ORACLE(double, f64)
 
-/* The OTHER reading of .cuh:285-286.  `loc_h * spatial_h - 0.5` is one multiply and one subtract in the source; the
- * reference's setup.py (models/ops/setup.py:41-46) passes no -fmad=false, so nvcc's default contracts them into ONE
- * fused multiply-add: the product is not rounded before the subtraction.  Near an integer boundary floor() can then
- * differ from the uncontracted reading above (which is what the HIP kernels implement, `fp contract(off)`).  This probe
- * computes the contracted indices so that tests/test_oracle_golden.py can COUNT the points that flip at the BASELINE
- * shapes: the "bit-exact index arithmetic" claim is against the uncontracted reading, and the count says how far the
- * two readings are apart. */
+/* The OTHER reading of .cuh:285-286.  `loc_h * spatial_h - 0.5` is one multiply and one subtract in the source.  Whether
+ * the reference BINARY fuses them is UNDECIDED without nvcc (absent from this image): setup.py
+ * (models/ops/setup.py:41-46) passes no -fmad=false, which would let nvcc contract a same-type multiply + add; but the
+ * literal 0.5 is a double, so for scalar_t = float the expression is fptrunc(fpext(loc * size) - 0.5) -- a float
+ * multiply feeding a double subtract -- which a compiler may or may not narrow back to a float fma.  The oracle above
+ * and the HIP kernels (`fp contract(off)`) follow the uncontracted source.  This probe computes the contracted indices
+ * so that tests/test_oracle_golden.py can COUNT the points that flip at the BASELINE shapes: zero of 2.86 M corner
+ * indices on either benchmark distribution; 17,063, each by one pixel with a bilinear weight <= 2^-23 on the far side,
+ * for locations placed exactly on pixel centres. */
 void msda_oracle_indices_fma_f32(const int64_t *shapes, const float *loc, int N, int M, int L, int Lq, int P,
                                  int32_t *h_low, int32_t *w_low, uint8_t *gate) {
     const long n_pairs = (long)N * Lq * M;

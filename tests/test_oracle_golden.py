@@ -95,14 +95,15 @@ def test_gate_and_zero_padding_semantics():
 
 
 def test_index_claim_is_scoped_to_the_uncontracted_reading_of_the_reference():
-    """.cuh:285-286 is `loc * size - 0.5`; the oracle and the HIP kernels round the product first (two operations), an
-    nvcc build of the reference with its default -fmad=true contracts them into one fused multiply-add
-    (models/ops/setup.py:41-46 sets no -fmad=false).  How far apart are the two readings at the BASELINE encoder shape?
-      * sampling distributions with any noise in them (both bench distributions): no point lands on another pixel;
+    """.cuh:285-286 is `loc * size - 0.5`; the oracle and the HIP kernels round the product first (two operations).
+    Whether the reference binary fuses them into one multiply-add is UNDECIDED without nvcc (models/ops/setup.py:41-46
+    sets no -fmad=false, but the literal 0.5 is a double: a float multiply feeding a double subtract, which a compiler
+    may or may not narrow back to a float fma).  How far apart are the two readings at the BASELINE encoder shape?
+      * sampling distributions with any noise in them (both bench distributions): zero of 2.86 M indices flip;
       * locations EXACTLY on pixel centres (the encoder's reference points with zero / whole-pixel offsets -- a set of
-        measure zero, but the one a hand-made test would pick): ~1 % of the points floor to the neighbouring pixel, with
-        the fractional weight at the other end of [0, 1), i.e. the same interpolated value to one ulp.
-    The bit-exact index claim (include/msda_hip.h) is therefore a claim against the uncontracted reading."""
+        measure zero, but the one a hand-made test would pick): ~0.6 % of the points floor to the neighbouring pixel,
+        with the fractional weight at the other end of [0, 1), i.e. the same interpolated value to one ulp.
+    The bit-exact index claim (include/msda_hip.h) is a claim against the uncontracted source."""
     import torch
     from memotr_amd.synth import encoder_reference_points, make_inputs, pyramid_shapes, star_offsets, valid_ratios
     from oracle import msda_oracle as oracle

@@ -4,6 +4,8 @@ Results never depend on the level -- every level is checked against the C oracle
 sampling points near their queries keep the windowed kernels, uniformly random locations (the reference's own test
 distribution, models/ops/test.py:33) move the backward to the kernel without windows and the forward to the gather
 kernel within a few calls."""
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -240,5 +242,71 @@ def test_more_call_sites_than_records_reuse_the_least_recently_used(hip_lib):
         torch.cuda.synchronize()
         assert "msda_fwd_d32_win" in hip_lib.last_kernel(), hip_lib.last_kernel()
         np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-4, atol=2e-5)
-    assert hip_lib.selector_poll() in (0, hip_lib.selector_poll())       # (polling with 256 live records works)
+    # polling with every record of the table live works: all 256 are read, and the signature does not depend on
+    # which slot a site sits in (two polls in a row, no launches in between: the same levels, the same signature)
+    sig = ctypes.c_uint64(0)
+    assert hip_lib.lib.msda_selector_poll(ctypes.byref(sig)) == 256
+    assert hip_lib.selector_poll() == hip_lib.selector_poll()
     MSDA.set_call_site(0)
+
+
+def test_a_record_at_the_top_level_comes_back_down_under_replay(hip_lib, site):
+    """Advisor, round 5: the probe one level down that a poll announces used to be undone by the eager warm-up calls a
+    graph cache makes in front of its capture (an eager call reset the record's announced level), so the graph stored
+    under the probe's key held the top level's kernel and a record at the top level never came back under replay.
+    A miniature of the model's caches: keyed on the per-site signature, two eager warm-ups, then the capture.  Far data
+    drives the forward record to level 1 (gather); with a fresh cache, near data then has to bring it back to level 0
+    THROUGH the graph captured under the probe's key -- which must hold the windowed kernel."""
+    from memotr_amd import MultiScaleDeformableAttention as MSDA
+    for k, v in (("fwd_variant", 0), ("sel_level", -1), ("auto_select", 1)):
+        hip_lib.set_option(k, v)
+    near, far = _inputs("encoder_like"), _inputs("uniform")
+    want = {"near": _oracle(near)[0], "far": _oracle(far)[0]}
+    static = {k: v.clone() for k, v in near.items() if isinstance(v, torch.Tensor)}
+    from memotr_amd.MultiScaleDeformableAttention import tag_host_shapes
+    tag_host_shapes(static["shapes"], near["shapes_list"])
+    graphs, polls, log = {}, [0], []
+
+    def step(x):
+        for k in ("value", "loc", "attn"):
+            static[k].copy_(x[k])
+        polls[0] += 1
+        sig = hip_lib.selector_poll_sites([site], probe=polls[0] % 8 == 0)
+        if sig not in graphs:
+            hip_lib.set_call_site(site)
+            call = lambda: MSDA.ms_deform_attn_forward(static["value"], static["shapes"], static["level_start"],    # noqa: E731
+                                                       static["loc"], static["attn"], 64)
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(2):          # (make_graphed_callables' warm-up iterations: eager calls of the site)
+                    call()
+            torch.cuda.current_stream().wait_stream(s)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = call()
+            graphs[sig] = (g, out, hip_lib.last_kernel())
+        g, out, kernel = graphs[sig]
+        g.replay()
+        torch.cuda.synchronize()
+        log.append((sig, kernel))
+        return out
+
+    for i in range(24):
+        out = step(far)
+    np.testing.assert_allclose(out.cpu().numpy(), want["far"], rtol=1e-4, atol=2e-5)
+    assert "gather" in log[-2][1] and log[-2][0] != 0, log[-4:]       # at level 1, from a graph of the gather kernel
+    n_far = len(log)
+    # a fresh cache (a new geometry, a new model wrapper ...): the level-0 graph does not exist, so the probe's key has to
+    # be CAPTURED -- eager warm-ups included -- while the record sits at the top level
+    graphs.clear()
+    for i in range(64):
+        out = step(near)
+        if log[-1][0] == 0 and i > 8:
+            break
+    np.testing.assert_allclose(out.cpu().numpy(), want["near"], rtol=1e-4, atol=2e-5)
+    # back at level 0 from a graph that holds the windowed kernel: the one captured under the probe's key
+    assert log[-1][0] == 0 and "win" in log[-1][1], log[n_far:]
+    assert any(sig != 0 and "gather" in kernel for sig, kernel in log[n_far:]), log[n_far:]
+    hip_lib.selector_poll_sites([site])
+    assert hip_lib.selector_poll_sites([site]) == 0
