@@ -120,6 +120,31 @@ int msda_backward_bf16(const uint16_t *value, const int64_t *shapes_dev, const i
                        float *grad_value, float *grad_loc, float *grad_attn,
                        int zero_grad_value, const int64_t *shapes_host, void *stream);
 
+/* The same backward with caller-provided scratch (ABI 6; device memory, contents undefined on entry and exit).
+ * msda_backward_workspace_bytes(fused, ...) is what the NEXT backward call of this thread's call site can use: the
+ * fused prologue's block (fused != 0: msda_fused_workspace_bytes) plus -- when that call would build grad_value by
+ * sort + gather instead of float atomics ("bwd_variant" 13, or kernel-selection level 2: self-attention over the
+ * pyramid whose sampling points land far from their queries; memotr_amd/csrc/msda_bwd_sorted.h) -- 8 bytes per
+ * (query, head, point, corner) of records and a few tables; 0 when the call needs none.  `elem_bytes` is the size of a
+ * value element (4 / 2), `stream` the stream the call will go to (a capturing stream takes the level the last poll
+ * announced).  workspace == NULL or too small: exactly msda_backward_* (whole-row float atomics). */
+size_t msda_backward_workspace_bytes(int fused, int N, int S, int M, int D, int L, int Lq, int P, int elem_bytes,
+                                     void *stream);
+
+int msda_backward_ws_f32(const float *value, const int64_t *shapes_dev, const int64_t *lstart_dev,
+                         const float *loc, const float *attn, const float *grad_out,
+                         int N, int S, int M, int D, int L, int Lq, int P,
+                         float *grad_value, float *grad_loc, float *grad_attn,
+                         int zero_grad_value, const int64_t *shapes_host,
+                         void *workspace, size_t workspace_bytes, void *stream);
+
+int msda_backward_ws_bf16(const uint16_t *value, const int64_t *shapes_dev, const int64_t *lstart_dev,
+                          const float *loc, const float *attn, const uint16_t *grad_out,
+                          int N, int S, int M, int D, int L, int Lq, int P,
+                          float *grad_value, float *grad_loc, float *grad_attn,
+                          int zero_grad_value, const int64_t *shapes_host,
+                          void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- fused prologue: replaces the elementwise chain of the reference MODULE between its query projections
  * and the operator (models/ops/modules/ms_deform_attn.py:104-123) ----
  * Instead of materialised sampling locations and attention weights the kernels take
@@ -167,7 +192,9 @@ int msda_fused_backward_bf16(const uint16_t *value, const int64_t *shapes_dev, c
  * (device memory, contents undefined on entry and exit).  With it the region-tiled path runs as three kernels --
  * the prologue once per row into the workspace, the plain tiled kernel, the Jacobians in place in grad_proj --
  * instead of redoing the row softmax and the location arithmetic in each of the L workgroups a region takes
- * (298 -> ~250 us at the encoder shape).  workspace == NULL or too small: exactly msda_fused_backward_*. */
+ * (298 -> ~250 us at the encoder shape).  workspace == NULL or too small: exactly msda_fused_backward_*.
+ * A workspace of msda_backward_workspace_bytes(1, ...) bytes (>= msda_fused_workspace_bytes) also admits the
+ * sort + gather form of grad_value when the call site's sampling points land far from their queries. */
 size_t msda_fused_workspace_bytes(int N, int Lq, int M, int L, int P);
 
 int msda_fused_backward_ws_f32(const float *value, const int64_t *shapes_dev, const int64_t *lstart_dev,
@@ -240,7 +267,8 @@ int msda_fused_points_f32(const int64_t *shapes_dev, const float *proj, int proj
 
 /* ---- tuning knobs (benchmarks / tests only; defaults pick the fastest correct path) ----
  * key: "fwd_variant" (0 = auto, 1 = generic one-thread-per-output kernel, 3 = D = 32 gather, 12 = windowed forward) |
- *       "bwd_variant" (0 = auto, 1 = generic, 10 = fixed-point windows, 12 = counting sort), see DESIGN.md;
+ *       "bwd_variant" (0 = auto, 1 = generic, 10 = fixed-point windows, 12 = counting sort, 13 = global sort + gather
+ *       through the caller's workspace), see DESIGN.md;
  *       "fwd_block" | "bwd_block" (threads per block, multiple of 64), "fwd_grid_mult" | "bwd_grid_mult" (blocks per
  *       CU), "bwd_tile_margin" (LDS window margin in pixels, variant 10), "bwd_split" (1 = the three-kernel fused
  *       backward when a workspace is given),
@@ -251,7 +279,8 @@ int msda_fused_points_f32(const int64_t *shapes_dev, const float *proj, int proj
  *       ahead, register budget), "fwd_win_place" (1 = every workgroup measures its window placement, rounds 3-4;
  *       0 = from the call site's running means), profiling switches; tools/fwd_win_sweep.py lists them;
  *       "fwd_head_major" (head-major block numbering of the gather
- *       kernel), "bwd_rows" / "bwd_rows_block" (the 32-lanes-per-row backward of decoder-shaped calls),
+ *       kernel), "bwd_rows" / "bwd_rows_block" (the 32-lanes-per-row backward of decoder-shaped calls), "bwd_sorted" (1: selector
+ *       level 2 builds grad_value by sort + gather when the caller gave scratch; 0: the rows kernel's float atomics),
  *       "bwd_wide_log2", "bwd_ablate" / "fwd_win_ablate" (profiling only: results are wrong by construction),
  *       "bwd_bins_margin" / "bwd_bins_margin_hi" / "bwd_bins_strip" (counting-sort backward, variant 12: window margins
  *       of selector levels 0 / 1, region rows per strip of the block walk), "auto_select" (0: no selection, level 0),

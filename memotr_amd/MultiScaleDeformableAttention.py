@@ -169,10 +169,24 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
         if grad_output.numel() == 0:
             return [grad_value.to(value.dtype), grad_loc, grad_attn]
         keep, hptr = _host_ptr(spatial_shapes, suf in ("f32", "bf16") and D == 32 and Lq == S and L <= 4)
-        rc = getattr(_lib.lib, f"msda_backward_{suf}")(
-            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
-            attn_weight.data_ptr(), grad_output.data_ptr(), N, S, M, D, L, Lq, P, grad_value.data_ptr(),
-            grad_loc.data_ptr(), grad_attn.data_ptr(), 0, hptr, _stream(value.device))
+        stream = _stream(value.device)
+        # scratch for the sort + gather form of grad_value (sampling points far from their queries: no float atomics);
+        # 0 for every other call
+        ws_bytes = 0
+        if suf != "f64":
+            ws_bytes = int(_lib.lib.msda_backward_workspace_bytes(0, N, S, M, D, L, Lq, P, value.element_size(), stream))
+        if ws_bytes:
+            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=value.device)
+            rc = getattr(_lib.lib, f"msda_backward_ws_{suf}")(
+                value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
+                attn_weight.data_ptr(), grad_output.data_ptr(), N, S, M, D, L, Lq, P, grad_value.data_ptr(),
+                grad_loc.data_ptr(), grad_attn.data_ptr(), 0, hptr, ws.data_ptr(), ws_bytes, stream)
+            del ws
+        else:
+            rc = getattr(_lib.lib, f"msda_backward_{suf}")(
+                value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
+                attn_weight.data_ptr(), grad_output.data_ptr(), N, S, M, D, L, Lq, P, grad_value.data_ptr(),
+                grad_loc.data_ptr(), grad_attn.data_ptr(), 0, hptr, stream)
         del keep
     if rc != 0:
         _raise(rc, "ms_deform_attn_backward")
@@ -277,15 +291,17 @@ def ms_deform_attn_fused_backward(value, spatial_shapes, level_start_index, proj
             gref = ref_part.sum(2) if ref_part is not None else None
             return [grad_value.to(value.dtype), grad_proj, gref]
         keep, hptr = _host_ptr(spatial_shapes, D == 32 and Lq == S and L <= 4 and not need_ref_grad)
-        # scratch for the three-kernel form of the region-tiled backward (the prologue materialised once per row)
-        ws_bytes = int(_lib.lib.msda_fused_workspace_bytes(N, Lq, M, L, P)) if hptr else 0
+        # scratch: the three-kernel form of the region-tiled backward (the prologue materialised once per row) and, for
+        # sampling points far from their queries, the records of the sort + gather form of grad_value
+        stream = _stream(value.device)
+        ws_bytes = int(_lib.lib.msda_backward_workspace_bytes(1, N, S, M, D, L, Lq, P, value.element_size(), stream)) if hptr else 0
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=value.device) if ws_bytes else None
         rc = getattr(_lib.lib, f"msda_fused_backward_ws_{suf}")(
             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), proj.data_ptr(),
             proj.shape[2], reference_points.data_ptr(), reference_points.shape[3],
             pad_mask.data_ptr() if pad_mask is not None else None, grad_output.data_ptr(), N, S, M, D, L, Lq, P,
             grad_value.data_ptr(), grad_proj.data_ptr(), ref_part.data_ptr() if ref_part is not None else None, 0,
-            hptr, ws.data_ptr() if ws is not None else None, ws_bytes, _stream(value.device))
+            hptr, ws.data_ptr() if ws is not None else None, ws_bytes, stream)
         del keep, ws
     if rc != 0:
         _raise(rc, "ms_deform_attn_fused_backward")

@@ -24,6 +24,7 @@ _FUSED_BWD_ARGS = ([c_void_p] * 4 + [c_int, c_void_p, c_int, c_void_p, c_void_p]
                    [c_int, c_void_p, c_void_p])
 
 _FUSED_BWD_WS_ARGS = _FUSED_BWD_ARGS[:-1] + [c_void_p, ctypes.c_size_t, c_void_p]
+_BWD_WS_ARGS = _BWD_ARGS[:-1] + [c_void_p, ctypes.c_size_t, c_void_p]
 
 SYMBOLS = {
     "msda_abi_version": ([], c_int),
@@ -35,6 +36,9 @@ SYMBOLS = {
     "msda_backward_f32": (_BWD_ARGS, c_int),
     "msda_backward_f64": (_BWD_ARGS, c_int),
     "msda_backward_bf16": (_BWD_ARGS, c_int),
+    "msda_backward_ws_f32": (_BWD_WS_ARGS, c_int),
+    "msda_backward_ws_bf16": (_BWD_WS_ARGS, c_int),
+    "msda_backward_workspace_bytes": ([c_int] * 9 + [c_void_p], ctypes.c_size_t),
     "msda_fused_forward_f32": (_FUSED_FWD_ARGS, c_int),
     "msda_fused_forward_bf16": (_FUSED_FWD_ARGS, c_int),
     "msda_fused_backward_f32": (_FUSED_BWD_ARGS, c_int),

@@ -49,13 +49,19 @@ __device__ __forceinline__ float half32_max(float x) {
     return x;
 }
 
-template <typename TV, bool FUSED>
+// ATOMICS = false (round 6): everything but grad_value -- the sorted backward (msda_bwd_sorted.h) builds grad_value by a
+// sort + gather and takes grad_loc / grad_attn / the fused Jacobians from here; `zero` / `zero_n`: words that launch
+// clears on the side (the sort's bucket totals, which its counting kernel then adds to).
+template <typename TV, bool FUSED, bool ATOMICS = true>
 __global__ __launch_bounds__(256) void msda_bwd_d32_rows(
     const TV *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ lstart,
     const PointSrc fs, const TV *__restrict__ grad_out, int N, int S, int M, int L, int Lq, int P,
     float *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_attn,
-    float *__restrict__ grad_proj, float *__restrict__ grad_ref_part, unsigned value_bytes, unsigned gv_bytes) {
+    float *__restrict__ grad_proj, float *__restrict__ grad_ref_part, unsigned value_bytes, unsigned gv_bytes,
+    unsigned *__restrict__ zero = nullptr, unsigned zero_n = 0u) {
     constexpr unsigned D = 32;
+    if (!ATOMICS && zero != nullptr)
+        for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < zero_n; i += gridDim.x * blockDim.x) zero[i] = 0u;
     __shared__ int s_H[kMaxLevels], s_W[kMaxLevels], s_start[kMaxLevels];
     __shared__ u32x4 s_rec[8][kRowsMaxLP][2];      // per row slot and point: {4 corner elements} {lh, lw, a, gate}
     __shared__ float s_res[8][3 * kRowsMaxLP];     // per row slot: d/dx, d/dy (2t, 2t+1), d/dattn (2 LP + t)
@@ -153,10 +159,12 @@ __global__ __launch_bounds__(256) void msda_bwd_d32_rows(
                 const float hh = 1.f - lh, hw = 1.f - lw;
                 const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
                 const float tga = g * a;
-                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(w1 * tga, gr, (int)((off[i].x + (unsigned)c) * 4u), 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(w2 * tga, gr, (int)((off[i].y + (unsigned)c) * 4u), 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(w3 * tga, gr, (int)((off[i].z + (unsigned)c) * 4u), 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(w4 * tga, gr, (int)((off[i].w + (unsigned)c) * 4u), 0, 0);
+                if (ATOMICS) {
+                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(w1 * tga, gr, (int)((off[i].x + (unsigned)c) * 4u), 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(w2 * tga, gr, (int)((off[i].y + (unsigned)c) * 4u), 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(w3 * tga, gr, (int)((off[i].z + (unsigned)c) * 4u), 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(w4 * tga, gr, (int)((off[i].w + (unsigned)c) * 4u), 0, 0);
+                }
                 const float gw = hh * (v[i][1] - v[i][0]) + lh * (v[i][3] - v[i][2]);
                 const float gh = hw * (v[i][2] - v[i][0]) + lw * (v[i][3] - v[i][1]);
                 // a gated-off point contributes exactly nothing, also for non-finite gradients

@@ -25,7 +25,8 @@
 //             head per XCD
 //   backward: 0 auto (pyramid self-attention: 12, or rows / 10 by selector level and call form; other D = 32 calls:
 //             msda_bwd_d32_rows, 32 lanes per row) | 1 generic | 10 region-tiled fixed-point windows, one pyramid
-//             level per workgroup | 12 counting sort + register gather (msda_bwd_bins.h)
+//             level per workgroup | 12 counting sort + register gather (msda_bwd_bins.h) | 13 global sort + gather
+//             through a workspace, no fabric atomics (msda_bwd_sorted.h; selector level 2 when the caller gave scratch)
 //   (rounds 1-2 also had a hybrid LDS/L1 forward -- 8, 9 -- and an all-levels-per-workgroup backward -- 8, 9, 11:
 //    measured slower than what replaced them, DESIGN.md 4.1 / 4.2, and removed in round 5; those numbers now mean 0)
 //
@@ -73,6 +74,7 @@ __device__ __forceinline__ double t_exp(double x) { return exp(x); }
 #include "msda_fwd_win.h"
 #include "msda_bwd_rows.h"
 #include "msda_bwd_bins.h"
+#include "msda_bwd_sorted.h"
 
 // ----------------------------------------------------------------------------------------
 // host side
@@ -97,6 +99,7 @@ std::atomic<int> opt_auto_select{1};         // msda_select.h: follow the measur
 std::atomic<int> opt_sel_level{-1};          // >= 0: pin the selector's level (tests, benchmarks)
 std::atomic<int> opt_sel_up0{5}, opt_sel_up1{100}, opt_sel_down1{2}, opt_sel_down2{60};   // backward thresholds, 1/1000 of the valid corners
 std::atomic<int> opt_sel_fwd_up{50}, opt_sel_fwd_down{20};                                  // forward thresholds  // counting-sort backward: window margin (the window is only a table of counters)
+std::atomic<int> opt_bwd_sorted{1};       // selector level 2: grad_value by sort + gather when the caller gave scratch (0: the rows kernel)
 std::atomic<int> opt_bwd_rows{1};         // 0: few-query D = 32 calls keep the generic row-per-block backward
 std::atomic<int> opt_fwd_head_major{0};    // gather forward: head-major task walk (one head per XCD)
 std::atomic<int> opt_fwd_win_rlog{0};       // windowed forward: log2 of the region height on level 0 (0: auto)
@@ -429,6 +432,26 @@ int sel_level(SelSlot *s, int kind, bool &probe, bool capturing = false) {
     return level;
 }
 
+// What sel_level() would answer for this thread's call site, without counting a call or creating a record (the
+// workspace query: a caller sizes its scratch before the call).
+int sel_peek(int kind, int M, int L, int P, int dt, hipStream_t stream) {
+    const int pinned = opt_sel_level.load();
+    if (pinned >= 0) return pinned;
+    if (!opt_auto_select.load()) return 0;
+    SelKey k;
+    memset(&k, 0, sizeof(k));
+    (void)hipGetDevice(&k.dev);
+    k.kind = kind; k.site = g_site; k.M = M; k.L = L; k.P = P; k.dt = dt;
+    const bool capturing = stream_capturing(stream);
+    std::lock_guard<std::mutex> lock(g_sel_mu);
+    for (int i = 0; i < kSelSlots; ++i)
+        if (g_sel[i].used && g_sel[i].key == k) {
+            sel_refresh(&g_sel[i]);
+            return capturing ? g_sel[i].eff : g_sel[i].level;
+        }
+    return 0;
+}
+
 struct FusedArgs {     // null proj = the plain operator
     const float *proj = nullptr;
     int proj_stride = 0;
@@ -689,8 +712,77 @@ int backward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart,
             bins_margin = opt_bwd_bins_margin_hi.load();
             if (bins_shrink < 0) bins_shrink = 0;
         }
-        if (variant == 0) variant = sel >= 2 ? 1 : 12;
+        if (variant == 0) variant = sel >= 2 ? (opt_bwd_sorted.load() ? 13 : 1) : 12;
     }
+    // ---- variant 13: grad_value by sort + gather through the caller's scratch (msda_bwd_sorted.h); everything else of
+    //      the call from msda_bwd_d32_rows without its atomics.  Not tied to the pyramid: any D = 32 call the rows kernel
+    //      takes.  Too little scratch (or none): the rows kernel with its atomics, below ----
+    if constexpr (kD32Type) {
+        if (variant == 13) {
+            const long n_rows13 = (long)N * Lq * M;
+            const size_t fused_bytes = fused ? (((size_t)n_rows13 * L * P * 3 * sizeof(float) + 255) & ~(size_t)255) : 0;
+            SortPlan sp;
+            const bool fits = d32_ok(D, L, value_elems) && L * P <= kRowsMaxLP && n_rows13 < (1L << 31) &&
+                              workspace != nullptr && workspace_bytes > fused_bytes &&
+                              make_sort_plan(sp, N, S, M, L, Lq, P, sizeof(TV), (unsigned char *)workspace + fused_bytes) &&
+                              fused_bytes + sp.bytes <= workspace_bytes &&
+                              (size_t)sp.nbk * 4 <= 64 * 1024;
+            if (fits) {
+                const PointSrc src = make_src(loc, attn, fa, M, L, P);
+                const int threads = 256, per = threads / 32;
+                const int rgrid = clamp_grid((n_rows13 + per - 1) / per, 64);
+                const unsigned gv_bytes = (unsigned)(value_elems * 4);
+                const unsigned n_cursor = (unsigned)((size_t)N * M * sp.nbk);
+                const bool b16 = sizeof(TV) == 2;
+                // 1. grad_loc / grad_attn (fused: grad_proj, grad_ref_part); clears the bucket totals on the side
+                if (fused) {
+                    hipLaunchKernelGGL((msda_bwd_d32_rows<TV, true, false>), dim3(rgrid), dim3(threads), 0, stream, value, shapes,
+                                       lstart, src, grad_out, N, S, M, L, Lq, P, (float *)grad_value, (float *)nullptr,
+                                       (float *)nullptr, grad_proj, grad_ref_part, (unsigned)value_bytes, gv_bytes,
+                                       sp.cursor, n_cursor);
+                } else {
+                    hipLaunchKernelGGL((msda_bwd_d32_rows<TV, false, false>), dim3(rgrid), dim3(threads), 0, stream, value, shapes,
+                                       lstart, src, grad_out, N, S, M, L, Lq, P, (float *)grad_value, (float *)grad_loc,
+                                       (float *)grad_attn, (float *)nullptr, (float *)nullptr, (unsigned)value_bytes, gv_bytes,
+                                       sp.cursor, n_cursor);
+                }
+                if ((rc = check_launch("msda_bwd_d32_rows<no atomics>"))) return rc;
+                // 2. fused: the prologue once per point into the scratch (locations + softmax weights, the module's bits)
+                const float *p_loc = (const float *)loc, *p_attn = (const float *)attn;
+                if (fused) {
+                    float *loc_ws = workspace, *attn_ws = workspace + (size_t)n_rows13 * L * P * 2;
+                    if (L * P <= 16)
+                        hipLaunchKernelGGL(msda_fused_points16_kernel, dim3(clamp_grid((n_rows13 * 16 + 255) / 256, 32)),
+                                           dim3(256), 0, stream, shapes, src, n_rows13, M, L, P, loc_ws, attn_ws);
+                    else
+                        hipLaunchKernelGGL(msda_fused_points_kernel, dim3(clamp_grid((n_rows13 * 8 + 255) / 256, 16)),
+                                           dim3(256), 0, stream, shapes, src, n_rows13, M, L, P, loc_ws, attn_ws);
+                    if ((rc = check_launch("msda_fused_points_kernel"))) return rc;
+                    p_loc = loc_ws;
+                    p_attn = attn_ws;
+                }
+                // 3. count -> scan -> emit -> gather
+                const int pgrid = (N * M * sp.nchunk + 7) & ~7;
+                const size_t hist_lds = (size_t)sp.nbk * 4;
+                hipLaunchKernelGGL((msda_bwd_sort_points<false>), dim3(pgrid), dim3(kSortThreads), hist_lds, stream, shapes,
+                                   lstart, p_loc, p_attn, fa.mask, sp);
+                hipLaunchKernelGGL(msda_bwd_sort_scan, dim3(N * M), dim3(kSortThreads), 0, stream, sp);
+                hipLaunchKernelGGL((msda_bwd_sort_points<true>), dim3(pgrid), dim3(kSortThreads), hist_lds, stream, shapes,
+                                   lstart, p_loc, p_attn, fa.mask, sp);
+                if ((rc = check_launch("msda_bwd_sort_points"))) return rc;
+                const int ggrid = (N * M * sp.max_items + 7) & ~7;
+                const size_t glds = (size_t)(kSortSlice + 2) * 8 + (size_t)kSortBP * 8;
+                const unsigned go_bytes = (unsigned)((size_t)n_rows13 * 32 * sizeof(TV));
+                g_kernel = fused ? (b16 ? "msda_bwd_d32_sorted<bf16,fused>" : "msda_bwd_d32_sorted<fused>")
+                                 : (b16 ? "msda_bwd_d32_sorted<bf16>" : "msda_bwd_d32_sorted");
+                hipLaunchKernelGGL((msda_bwd_sort_gather<TV>), dim3(ggrid), dim3(kSortThreads), glds, stream, grad_out,
+                                   (float *)grad_value, sp, go_bytes, gv_bytes);
+                return check_launch(g_kernel);
+            }
+            variant = 1;        // (-> msda_bwd_d32_rows with its atomics, below)
+        }
+    }
+    if (variant == 13) variant = 1;
     if (variant == 0 || (variant >= 2 && variant != 10 && variant != 12)) variant = can_tile && P <= 8 ? 10 : 1;
     if (variant >= 2 && !can_tile) variant = 1;
     if constexpr (kD32Type) {
@@ -1085,6 +1177,45 @@ size_t msda_fused_workspace_bytes(int N, int Lq, int M, int L, int P) {
     return (size_t)N * Lq * M * L * P * 3 * sizeof(float);
 }
 
+// Scratch the NEXT backward call of this thread's call site can use (ABI 6): the fused prologue's block
+// (msda_fused_workspace_bytes) plus, when that call would build grad_value by sort + gather ("bwd_variant" 13, or
+// selector level 2 for self-attention over the pyramid), the sort's records and tables.  0: the call needs none.
+size_t msda_backward_workspace_bytes(int fused, int N, int S, int M, int D, int L, int Lq, int P, int elem_bytes,
+                                     void *stream) {
+    if (N <= 0 || S <= 0 || Lq <= 0 || M <= 0 || D <= 0 || L <= 0 || P <= 0) return 0;
+    const size_t n_pts = (size_t)N * Lq * M * L * P;
+    size_t bytes = fused ? n_pts * 3 * sizeof(float) : 0;
+    const int variant = opt_bwd_variant.load();
+    bool sorted = variant == 13;
+    if (variant == 0 && opt_bwd_sorted.load() && D == 32 && Lq == S && L <= kTileMaxL && (elem_bytes == 4 || elem_bytes == 2))
+        sorted = sel_peek(1, M, L, P, elem_bytes, (hipStream_t)stream) >= 2;
+    if (sorted && D == 32) {
+        SortPlan sp;
+        if (make_sort_plan(sp, N, S, M, L, Lq, P, (size_t)elem_bytes, nullptr)) bytes = ((bytes + 255) & ~(size_t)255) + sp.bytes;
+    }
+    return bytes;
+}
+
+int msda_backward_ws_f32(const float *value, const int64_t *shapes_dev, const int64_t *lstart_dev, const float *loc,
+                         const float *attn, const float *grad_out, int N, int S, int M, int D, int L, int Lq, int P,
+                         float *grad_value, float *grad_loc, float *grad_attn, int zero_grad_value,
+                         const int64_t *shapes_host, void *workspace, size_t workspace_bytes, void *stream) {
+    return backward_impl<float, float, float>(value, shapes_dev, lstart_dev, loc, attn, FusedArgs{}, grad_out, N, S, M,
+                                              D, L, Lq, P, grad_value, grad_loc, grad_attn, nullptr, nullptr,
+                                              zero_grad_value, shapes_host, (hipStream_t)stream, (float *)workspace,
+                                              workspace_bytes);
+}
+
+int msda_backward_ws_bf16(const uint16_t *value, const int64_t *shapes_dev, const int64_t *lstart_dev, const float *loc,
+                          const float *attn, const uint16_t *grad_out, int N, int S, int M, int D, int L, int Lq, int P,
+                          float *grad_value, float *grad_loc, float *grad_attn, int zero_grad_value,
+                          const int64_t *shapes_host, void *workspace, size_t workspace_bytes, void *stream) {
+    return backward_impl<bf16_t, float, float>((const bf16_t *)value, shapes_dev, lstart_dev, loc, attn, FusedArgs{},
+                                               (const bf16_t *)grad_out, N, S, M, D, L, Lq, P, grad_value, grad_loc,
+                                               grad_attn, nullptr, nullptr, zero_grad_value, shapes_host,
+                                               (hipStream_t)stream, (float *)workspace, workspace_bytes);
+}
+
 int msda_fused_backward_ws_f32(const float *value, const int64_t *shapes_dev, const int64_t *lstart_dev,
                                const float *proj, int proj_stride, const float *ref, int ref_dim,
                                const uint8_t *pad_mask, const float *grad_out, int N, int S, int M, int D, int L, int Lq,
@@ -1169,6 +1300,7 @@ static std::atomic<int> *find_opt(const char *key) {
     if (!strcmp(key, "sel_fwd_down")) return &opt_sel_fwd_down;
     if (!strcmp(key, "bwd_bins_strip")) return &opt_bwd_bins_strip;
     if (!strcmp(key, "bwd_rows")) return &opt_bwd_rows;
+    if (!strcmp(key, "bwd_sorted")) return &opt_bwd_sorted;
     if (!strcmp(key, "bwd_rows_block")) return &opt_bwd_rows_block;
     if (!strcmp(key, "fwd_win_rlog")) return &opt_fwd_win_rlog;
     if (!strcmp(key, "fwd_win_rlogx")) return &opt_fwd_win_rlogx;

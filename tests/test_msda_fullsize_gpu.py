@@ -26,11 +26,13 @@ def msda(hip_lib):
     return MSDA
 
 
-@pytest.fixture(autouse=True, params=[0, 10], ids=["bwd_default", "bwd_tile_lv"])
+@pytest.fixture(autouse=True, params=[0, 10, 13], ids=["bwd_default", "bwd_tile_lv", "bwd_sorted"])
 def _bwd_family(request, hip_lib):
     """Every test of this file runs with the default backward (the counting-sort kernel at the selector's level for
-    pyramids, the row kernel for decoder shapes) and with the fixed-point window family forced.  (Round 4 also forced
-    variant 12 -- the kernel the default already runs at these inputs.)"""
+    pyramids, the row kernel for decoder shapes), with the fixed-point window family forced, and (round 6) with the
+    global sort + gather form of grad_value forced (msda_bwd_sorted.h: what selector level 2 runs; no float atomics
+    but on the rows of sliced buckets).  (Round 4 also forced variant 12 -- the kernel the default already runs at these
+    inputs.)"""
     hip_lib.set_option("bwd_variant", request.param)
     yield
     for k in ("fwd_variant", "bwd_variant"):
@@ -101,7 +103,7 @@ def test_encoder_shape_forward_and_backward_match_oracle(msda, hip_lib, pyr, dis
         assert x["value"].shape[1] == 22323
     got = _hip(msda, x)
     kernel = hip_lib.last_kernel()
-    assert "tile" in kernel, kernel          # the training kernels for pyramid self-attention
+    assert "tile" in kernel or "sorted" in kernel, kernel          # the training kernels for pyramid self-attention
     _check(got, _oracle(_cpu(x)), f"{pyr}/{dist}")
 
 
@@ -124,7 +126,7 @@ def test_clip_batched_encoder_call_matches_oracle(msda, hip_lib, batch):
     x["value"] = torch.randn_like(x["value"])
     x["loc"] = (x["loc"] + 0.002 * torch.randn_like(x["loc"])).contiguous()     # frames differ
     got = _hip(msda, x)
-    assert "tile" in hip_lib.last_kernel()
+    assert "tile" in hip_lib.last_kernel() or "sorted" in hip_lib.last_kernel()
     _check(got, _oracle(_cpu(x)), f"batch{batch}")
 
 
@@ -304,7 +306,7 @@ def test_bf16_encoder_shape_forward_and_backward_match_oracle(msda, hip_lib, pyr
     out = msda.ms_deform_attn_forward(*args, 64)
     assert "bf16" in hip_lib.last_kernel() and "d32" in hip_lib.last_kernel(), hip_lib.last_kernel()
     gv, gl, ga = msda.ms_deform_attn_backward(*args, gob, 64)
-    assert "bf16" in hip_lib.last_kernel() and "tile" in hip_lib.last_kernel(), hip_lib.last_kernel()
+    assert "bf16" in hip_lib.last_kernel() and ("tile" in hip_lib.last_kernel() or "sorted" in hip_lib.last_kernel()), hip_lib.last_kernel()
     c = _cpu(x)
     c["value"], c["grad_out"] = vb.float().cpu().numpy(), gob.float().cpu().numpy()
     rout, rgv, rgl, rga = _oracle(c)

@@ -53,7 +53,7 @@ def test_every_backward_level_matches_the_oracle(hip_lib, site):
         x = _inputs(dist, osc)
         want = _oracle(x)
         args = (x["value"], x["shapes"], x["level_start"], x["loc"], x["attn"], x["grad_out"], 64)
-        for level, kernel in ((0, "tile_bins"), (1, "tile_bins"), (2, "rows")):
+        for level, kernel in ((0, "tile_bins"), (1, "tile_bins"), (2, "sorted")):
             hip_lib.set_option("sel_level", level)
             for _ in range(3):          # (three launches: both parities of the statistics record are exercised)
                 got = MSDA.ms_deform_attn_backward(*args)
@@ -302,7 +302,7 @@ def test_a_record_at_the_top_level_comes_back_down_under_replay(hip_lib, site):
     graphs.clear()
     for i in range(64):
         out = step(near)
-        if log[-1][0] == 0 and i > 8:
+        if i > 0 and log[-1][0] == 0 and log[-2][0] == 0:      # (one 0 is the probe; two in a row: the level is back)
             break
     np.testing.assert_allclose(out.cpu().numpy(), want["near"], rtol=1e-4, atol=2e-5)
     # back at level 0 from a graph that holds the windowed kernel: the one captured under the probe's key
