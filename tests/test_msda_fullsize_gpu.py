@@ -152,7 +152,7 @@ def test_fixed_point_window_accumulation_per_channel_scales(msda, hip_lib):
     scales = 10.0 ** (torch.rand(256, generator=g) * 7 - 4)
     x["grad_out"] = (x["grad_out"] * scales.cuda()).contiguous()
     got = _hip(msda, x)
-    assert "tile_" in hip_lib.last_kernel()
+    assert "tile_" in hip_lib.last_kernel() or "sorted" in hip_lib.last_kernel()
     want = _oracle(_cpu(x))
     gv, rgv = got[1].reshape(-1, 256), want[1].reshape(-1, 256)
     err = np.abs(gv - rgv).max(0) / np.abs(rgv).max(0)
@@ -253,7 +253,7 @@ def test_fixed_point_smooth_in_region_spread_is_bounded_by_the_local_magnitude(m
     g_normal = float(x["grad_out"].abs().max())
     x["grad_out"] = (x["grad_out"] * qs[None, :, None]).contiguous()
     got = _hip(msda, x)
-    assert "tile_" in hip_lib.last_kernel()
+    assert "tile_" in hip_lib.last_kernel() or "sorted" in hip_lib.last_kernel()
     c = _cpu(x)
     want = _oracle(c)
     err = np.abs(got[1] - want[1])[0]                                      # (S, M, D)
