@@ -163,11 +163,12 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     with torch.cuda.device(value.device):
         # bf16: accumulate grad_value in fp32, round once at the end
         acc_dtype = torch.float32 if suf == "bf16" else value.dtype
-        grad_value = torch.zeros(value.shape, dtype=acc_dtype, device=value.device)
         grad_loc = torch.empty_like(sampling_loc)
         grad_attn = torch.empty_like(attn_weight)
         if grad_output.numel() == 0:
-            return [grad_value.to(value.dtype), grad_loc, grad_attn]
+            return [torch.zeros(value.shape, dtype=value.dtype, device=value.device), grad_loc, grad_attn]
+        # (zeroed by the library -- `zero_grad_value` -- in the same launch as whatever else its chosen kernels want cleared)
+        grad_value = torch.empty(value.shape, dtype=acc_dtype, device=value.device)
         keep, hptr = _host_ptr(spatial_shapes, suf in ("f32", "bf16") and D == 32 and Lq == S and L <= 4)
         stream = _stream(value.device)
         # scratch for the sort + gather form of grad_value (sampling points far from their queries: no float atomics);
@@ -180,13 +181,13 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
             rc = getattr(_lib.lib, f"msda_backward_ws_{suf}")(
                 value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
                 attn_weight.data_ptr(), grad_output.data_ptr(), N, S, M, D, L, Lq, P, grad_value.data_ptr(),
-                grad_loc.data_ptr(), grad_attn.data_ptr(), 0, hptr, ws.data_ptr(), ws_bytes, stream)
+                grad_loc.data_ptr(), grad_attn.data_ptr(), 1, hptr, ws.data_ptr(), ws_bytes, stream)
             del ws
         else:
             rc = getattr(_lib.lib, f"msda_backward_{suf}")(
                 value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
                 attn_weight.data_ptr(), grad_output.data_ptr(), N, S, M, D, L, Lq, P, grad_value.data_ptr(),
-                grad_loc.data_ptr(), grad_attn.data_ptr(), 0, hptr, stream)
+                grad_loc.data_ptr(), grad_attn.data_ptr(), 1, hptr, stream)
         del keep
     if rc != 0:
         _raise(rc, "ms_deform_attn_backward")
@@ -281,7 +282,8 @@ def ms_deform_attn_fused_backward(value, spatial_shapes, level_start_index, proj
     if grad_output.dtype != value.dtype or grad_output.numel() != N * Lq * M * D:
         raise RuntimeError("grad_output must match the forward output (N, Lq, M*D) and value's dtype")
     with torch.cuda.device(value.device):
-        grad_value = torch.zeros(value.shape, dtype=torch.float32, device=value.device)
+        # (zeroed by the library, `zero_grad_value`, next to whatever else its chosen kernels want cleared)
+        grad_value = (torch.empty if grad_output.numel() else torch.zeros)(value.shape, dtype=torch.float32, device=value.device)
         used = 3 * M * L * P
         grad_proj = (torch.empty_like(proj) if proj.shape[2] == used else torch.zeros_like(proj))
         ref_part = None
@@ -300,7 +302,7 @@ def ms_deform_attn_fused_backward(value, spatial_shapes, level_start_index, proj
             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), proj.data_ptr(),
             proj.shape[2], reference_points.data_ptr(), reference_points.shape[3],
             pad_mask.data_ptr() if pad_mask is not None else None, grad_output.data_ptr(), N, S, M, D, L, Lq, P,
-            grad_value.data_ptr(), grad_proj.data_ptr(), ref_part.data_ptr() if ref_part is not None else None, 0,
+            grad_value.data_ptr(), grad_proj.data_ptr(), ref_part.data_ptr() if ref_part is not None else None, 1,
             hptr, ws.data_ptr() if ws is not None else None, ws_bytes, stream)
         del keep, ws
     if rc != 0:

@@ -28,20 +28,29 @@
 //           in that XCD's L2), fp32 accumulation in registers, and ONE plain 128-byte store per row -- atomics only for
 //           the rows of buckets that were sliced (coarse pyramid levels, where thousands of points share a pixel).
 //
-// grad_loc / grad_attn (and the fused prologue's Jacobians) are the dot products of msda_bwd_d32_rows, instantiated
-// without its atomics.  Non-finite gradients propagate through fp32 arithmetic like the reference's atomicAdd.
+// grad_loc / grad_attn come from msda_bwd_d32_dots below (the row phase of msda_bwd_d32_bins without a region; the fused
+// call: into the columns of grad_proj, the side kernels of msda_fused_side.h finish the Jacobians) -- or, when gradients
+// of the reference points are wanted, from msda_bwd_d32_rows instantiated without its atomics.  Non-finite gradients
+// propagate through fp32 arithmetic like the reference's atomicAdd.
 #pragma once
 
 constexpr int kSortBPLog = 6, kSortBP = 1 << kSortBPLog;      // destination pixels per bucket
 constexpr int kSortThreads = 256;
-constexpr int kSortSlice = 4608;         // records one gathering workgroup sorts (36 KB of LDS: four workgroups per CU)
+#ifndef MSDA_SORT_SLICE
+#define MSDA_SORT_SLICE 4608
+#endif
+#ifndef MSDA_SORT_UN
+#define MSDA_SORT_UN 8
+#endif
+constexpr int kSortSlice = MSDA_SORT_SLICE;   // records one gathering workgroup sorts (4608: 36 KB of LDS, four workgroups per CU)
 constexpr int kSortRecPerThread = kSortSlice / kSortThreads;
-constexpr int kSortMaxBuckets = 12288;   // per (batch, head): the histogram lives in LDS (48 KB)
+constexpr int kSortMaxBuckets = 8192;    // per (batch, head): the histogram lives in LDS (32 KB) next to the dots kernel's chunk
 
 struct SortPlan {
     int N, S, M, L, Lq, P;
-    int qc;                  // queries per counting / emitting workgroup
+    int qc;                  // queries per dots-and-count workgroup
     int nchunk;              // ... workgroups per (batch, head): ceil(Lq / qc)
+    int emult;               // chunks per EMIT workgroup (longer runs per bucket, fewer reservations)
     int nbk;                 // buckets per (batch, head): ceil(S / 64)
     int magic_lp;            // (i * magic_lp) >> 16 == i / (L * P) for i < qc * L * P
     unsigned cap;            // records per (batch, head) segment: Lq * L * P * 4
@@ -55,7 +64,8 @@ struct SortPlan {
 };
 
 // Layout of the scratch block; false when the call does not fit the kernels' 32-bit arithmetic.
-inline bool make_sort_plan(SortPlan &sp, int N, int S, int M, int L, int Lq, int P, size_t elem_bytes, void *workspace) {
+inline bool make_sort_plan(SortPlan &sp, int N, int S, int M, int L, int Lq, int P, size_t elem_bytes, void *workspace,
+                           int qc_opt = 0, int emult_opt = 0) {
     memset(&sp, 0, sizeof(sp));
     const long LP = (long)L * P;
     if (LP < 1 || LP > kRowsMaxLP || N < 1 || Lq < 1 || Lq >= (1 << 26)) return false;
@@ -63,15 +73,21 @@ inline bool make_sort_plan(SortPlan &sp, int N, int S, int M, int L, int Lq, int
     if (nbk > kSortMaxBuckets) return false;
     const long cap = (long)Lq * LP * 4, total = cap * N * M;
     if (total >= (1L << 31) || (long)N * Lq * M * 32 * (long)elem_bytes >= 0x7fffff00L) return false;
-    // enough counting workgroups to fill the chip, few enough that the count matrix stays small
-    int qc = 256;
-    while (qc > 32 && (long)N * M * ((Lq + qc - 1) / qc) < 1024) qc >>= 1;
-    const int items = qc * (int)LP;
+    // a chunk's grad_out rows (144 B each), item records (16 + 4 B) and its histogram live in LDS next to four other
+    // workgroups': 64 queries at L * P = 16 (28 KB); the emit kernel takes two chunks per workgroup at that size
+    int qc = 64;
+    while (qc > 8 && (size_t)(qc + 1) * 144 + (size_t)qc * LP * 20 > 28 * 1024) qc >>= 1;
+    if (qc_opt >= 8 && qc_opt <= 128 && (qc_opt & (qc_opt - 1)) == 0 && (size_t)(qc_opt + 1) * 144 + (size_t)qc_opt * LP * 20 <= 56 * 1024)
+        qc = qc_opt;       // ("bwd_sort_qc": measurements)
+    int emult = (long)N * M * (((Lq + qc - 1) / qc + 1) / 2) >= 1024 ? 2 : 1;
+    if (emult_opt >= 1 && emult_opt <= 8) emult = emult_opt;
+    const int items = emult * qc * (int)LP;
     const int magic = 65536 / (int)LP + 1;
     for (int i = 0; i < items; ++i)
         if (((i * magic) >> 16) != i / (int)LP) return false;
     sp.N = N; sp.S = S; sp.M = M; sp.L = L; sp.Lq = Lq; sp.P = P;
     sp.qc = qc; sp.nchunk = (Lq + qc - 1) / qc; sp.nbk = (int)nbk; sp.magic_lp = magic; sp.cap = (unsigned)cap;
+    sp.emult = emult;
     sp.max_items = (int)(cap / kSortSlice + nbk);
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t nbm = (size_t)N * M;
@@ -86,27 +102,329 @@ inline bool make_sort_plan(SortPlan &sp, int N, int S, int M, int L, int Lq, int
     return true;
 }
 
-// ---- count (EMIT = false) / emit (EMIT = true): one lane per (query, point) of one head ----
-template <bool EMIT>
-__global__ __launch_bounds__(kSortThreads) void msda_bwd_sort_points(const int64_t *__restrict__ shapes,
-                                                                      const int64_t *__restrict__ lstart,
-                                                                      const float *__restrict__ loc,
-                                                                      const float *__restrict__ attn,
-                                                                      const unsigned char *__restrict__ mask,
-                                                                      const SortPlan sp) {
+// Where a point's sampling location comes from: the operator's `loc`, or (fused_loc, the slim split fused backward) the
+// module's own arithmetic on the raw projection row and the reference points -- the bits msda_fused_points_f32 exposes.
+// The attention weight is materialised either way (src.attn: the operator's, or the workspace copy of the softmax).
+struct SortRaw {
+    f32x2 off, r01, r23;     // plain: off = the location itself
+    float a;
+};
+__device__ __forceinline__ SortRaw sort_load_raw(const PointSrc &src, int fused_loc, unsigned qrow, unsigned pm, unsigned m,
+                                                 unsigned L, unsigned LP, unsigned t, unsigned l, bool soft16) {
+    SortRaw r;
+    // (32-bit element indices: check_dims keeps every tensor below 2^31 elements and qrow * proj_stride below 1.5 * 2^31)
+    const float *const p_raw = fused_loc ? src.proj + (qrow * (unsigned)src.proj_stride + (m * LP + t) * 2u)
+                                         : src.loc + (pm * LP + t) * 2u;
+    const float *const rp = fused_loc ? src.ref + (qrow * L + l) * (unsigned)src.ref_dim : p_raw;
+    r.off = *reinterpret_cast<const f32x2 *>(p_raw);
+    r.r01 = *reinterpret_cast<const f32x2 *>(rp);
+    r.r23 = *reinterpret_cast<const f32x2 *>(fused_loc && src.ref_dim != 2 ? rp + 2 : p_raw);
+    // soft16: the row's logit -- its sixteen lanes turn it into the softmax weight (sort_row16_softmax)
+    r.a = soft16 ? src.proj[qrow * (unsigned)src.proj_stride + (unsigned)src.n_off + m * LP + t] : src.attn[pm * LP + t];
+    return r;
+}
+__device__ __forceinline__ f32x2 sort_location(const SortRaw &r, const PointSrc &src, int fused_loc, int P, int H, int W) {
+    return fused_loc ? fused_location_from(r.off, r.r01, r.r23, src.ref_dim, P, H, W) : r.off;
+}
+
+// The softmax weight of a point from its logit, by the sixteen lanes (one DPP row) that hold the L * P = 16 logits of a
+// (query, head) row: exp(logit - max) * (1 / sum) with the library's exact expf and ONE IEEE division per row, the sum
+// associated like msda_fused_attn16_rows_kernel's ((t, t + 8) pairs first, then 1, 2, 4) -- the same bits.
+__device__ __forceinline__ float sort_row16_softmax(float lg) {
+    float mx = lg;
+    mx = fmaxf(mx, MSDA_DPP(mx, 0xB1));
+    mx = fmaxf(mx, MSDA_DPP(mx, 0x4E));
+    mx = fmaxf(mx, MSDA_DPP(mx, 0x141));
+    mx = fmaxf(mx, MSDA_DPP(mx, 0x140));
+    const float e = expf(lg - mx);
+    float sum = e + MSDA_DPP(e, 0x128);          // row_ror:8 -> lane t ^ 8
+    sum += MSDA_DPP(sum, 0xB1);                  // t ^ 1
+    sum += MSDA_DPP(sum, 0x4E);                  // t ^ 2
+    sum += MSDA_DPP(sum, 0x141);                 // the other quad of the eight (all four lanes of a quad hold one value)
+    return e * (1.f / sum);
+}
+
+// ---- dots + count: grad_loc / grad_attn of a chunk of queries of one head, and the chunk's corner histogram ----
+// The row phase of msda_bwd_d32_bins without its region.  A workgroup owns (batch, head, chunk of `qc` queries):
+//   * the chunk's grad_out rows are staged in LDS once (fp32, 144-byte pitch);
+//   * one lane per (query, point) ITEM does the scalar work once -- location (the operator's, or fused_loc: the module's
+//     arithmetic on the raw projection), sample arithmetic, corner validity / padding mask -- leaves a 16-byte record
+//     {value byte offset of the top-left corner, lh, lw, attention} + a flag byte in LDS, and counts the item's valid
+//     corners into the chunk's histogram over the destination buckets (what the emit kernel reserves by, and -- added to
+//     the bucket totals -- what the scan turns into bucket starts);
+//   * four lanes x eight channels per item then compute the four corner dot products d_k = <grad_out_row, v_k> (16-byte
+//     loads of the corner rows, two DPP steps) from which all three gradients of the point derive: grad_attn =
+//     sum_k w_k d_k, d/dx = a W (hh (d1 - d0) + lh (d3 - d2)), d/dy = a H (hw (d2 - d0) + lw (d3 - d1)); lanes 0 / 1 / 2
+//     of the quad write them.
+// A first version without LDS -- every lane of a quad redoing the item's scalar work and loading its own copy of the
+// grad_out row and of the inputs, one task per round trip -- took 98 / 120 us (near / uniform locations) next to a
+// separate 15 us counting kernel: neither VALU- nor tail-bound (315 instead of 534 static VALU instructions and an
+// occupancy-sized grid changed nothing) but by the redundant small loads in front of every task's corner rows
+// (profiles/r06_sorted_ab.txt).
+// Workgroups are numbered head-major, one head per XCD: the head's slab of `value` stays in that L2.
+// grad_proj != null: the split fused backward -- the results go to the offset / logit columns of grad_proj
+// (offsets_done: as final offset gradients, d loc / d offset = 1 / (W, H) for 2-d reference points) and the finishing
+// kernels of msda_fused_side.h apply the remaining Jacobians in place.
+struct SortDotsLds {
+    unsigned o_rec, o_fl, o_hist, bytes;      // (grad_out rows at 0)
+};
+inline SortDotsLds sort_dots_lds(int qc, int LP, int nbk) {
+    SortDotsLds d;
+    auto up16 = [](unsigned x) { return (x + 15u) & ~15u; };
+    d.o_rec = up16((unsigned)(qc + 1) * kBinsGRow);
+    d.o_fl = d.o_rec + (unsigned)(qc * LP) * 16u;
+    d.o_hist = up16(d.o_fl + (unsigned)(qc * LP) * 4u);
+    d.bytes = d.o_hist + (unsigned)nbk * 4u;
+    return d;
+}
+
+template <typename TV>
+__global__ __launch_bounds__(kSortThreads) void msda_bwd_sort_dots(
+    const TV *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ lstart,
+    const PointSrc src, int fused_loc, int offsets_done, int soft16, const TV *__restrict__ grad_out,
+    float *__restrict__ grad_loc, float *__restrict__ grad_attn, float *__restrict__ grad_proj, const SortPlan sp,
+    const SortDotsLds ld, unsigned value_bytes) {
+    constexpr bool kB16 = sizeof(TV) == 2;
+    constexpr unsigned ROWB = 32u * (unsigned)sizeof(TV);
+    constexpr unsigned kChunkDelta = kB16 ? 16u : 64u;      // between a lane's two 16-byte chunks of a staged grad_out row
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     __shared__ int s_H[kMaxLevels], s_W[kMaxLevels], s_start[kMaxLevels];
-    unsigned *const hist = reinterpret_cast<unsigned *>(s_dyn);         // count: histogram; emit: next free record
-    const int tid = threadIdx.x;
-    // block -> (head, batch, chunk): head-major, one head per XCD like the gather (the records of a head are written
-    // and read through the same L2)
+    unsigned char *const G = s_dyn;
+    u32x4 *const R = reinterpret_cast<u32x4 *>(s_dyn + ld.o_rec);
+    unsigned *const FL = reinterpret_cast<unsigned *>(s_dyn + ld.o_fl);
+    unsigned *const hist = reinterpret_cast<unsigned *>(s_dyn + ld.o_hist);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int per = sp.N * sp.nchunk;                   // workgroups per head
-    const int n_blocks = per * sp.M;
     const int chunk8 = (int)(gridDim.x >> 3);
     const int sw = (int)(blockIdx.x & 7) * chunk8 + (int)(blockIdx.x >> 3);
-    if (sw >= n_blocks) return;
+    if (sw >= per * sp.M) return;
     const int m = sw / per, rem = sw - m * per;
     const int b = rem / sp.nchunk, ck = rem - b * sp.nchunk;
+    const int bm = b * sp.M + m;
+    const int L = sp.L, P = sp.P, LP = L * P, M = sp.M, nbk = sp.nbk;
+    if (tid < L) {
+        s_H[tid] = (int)shapes[2 * tid];
+        s_W[tid] = (int)shapes[2 * tid + 1];
+        s_start[tid] = (int)lstart[tid];
+    }
+    for (int i = tid; i < nbk; i += kSortThreads) hist[i] = 0u;
+    const int q0 = ck * sp.qc;
+    const int nq = sp.Lq - q0 < sp.qc ? sp.Lq - q0 : sp.qc;
+    const int n_items = nq * LP;
+    const unsigned qrow0 = (unsigned)b * (unsigned)sp.Lq + (unsigned)q0;
+    // ---- phase 0: the chunk's grad_out rows -> LDS (fp32); row nq is the zero row of items that do not exist ----
+    for (int idx = tid; idx < (nq + 1) * 8; idx += kSortThreads) {
+        const int r = idx >> 3;
+        const unsigned pm = (qrow0 + (unsigned)(r < nq ? r : 0)) * (unsigned)M + (unsigned)m;
+        f32x4 g = bins_load_g4<TV>(grad_out + (pm * 32u + (unsigned)((idx & 7) * 4)));
+        if (r >= nq) g = f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4 *>(G + (unsigned)r * kBinsGRow + (unsigned)(idx & 7) * 16u) = g;
+    }
+    __syncthreads();      // (level tables, cleared histogram)
+    // ---- phase 1: one lane per item; two items per iteration, their inputs requested together ----
+    const unsigned char *const mk = src.mask ? src.mask + (size_t)b * sp.S : nullptr;
+    for (int it0 = tid; it0 < n_items; it0 += 2 * kSortThreads) {
+        SortRaw raw[2];
+        unsigned tt[2], ll[2];
+        bool ok[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int it = it0 + u * kSortThreads;
+            ok[u] = it < n_items;
+            const int itc = ok[u] ? it : it0;
+            const int ql = (itc * sp.magic_lp) >> 16;
+            tt[u] = (unsigned)(itc - ql * LP);
+            ll[u] = tt[u] / (unsigned)P;
+            const unsigned qrow = qrow0 + (unsigned)ql;
+            raw[u] = sort_load_raw(src, fused_loc, qrow, qrow * (unsigned)M + (unsigned)m, (unsigned)m, (unsigned)L,
+                                   (unsigned)LP, tt[u], ll[u], soft16 != 0);
+        }
+        // (soft16: L * P = 16 -- the sixteen lanes of a DPP row hold one (query, head) row's logits, all of them existing
+        //  or none; the weights never pass through HBM)
+        if (soft16) {
+            raw[0].a = sort_row16_softmax(raw[0].a);
+            raw[1].a = sort_row16_softmax(raw[1].a);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (!ok[u]) continue;
+            const unsigned l = ll[u];
+            const int H = s_H[l], W = s_W[l];
+            const f32x2 xy = sort_location(raw[u], src, fused_loc, P, H, W);
+            const Sample<float> s = sample_setup<float>(xy.x, xy.y, H, W);
+            const bool gate = s.gate;
+            const int h0 = s.h_low, w0 = s.w_low;
+            const bool okh0 = gate && h0 >= 0, okh1 = gate && h0 + 1 <= H - 1, okw0 = w0 >= 0, okw1 = w0 + 1 <= W - 1;
+            bool v[4] = {okh0 && okw0, okh0 && okw1, okh1 && okw0, okh1 && okw1};
+            const int p00 = s_start[l] + h0 * W + w0;
+            const int px[4] = {p00, p00 + 1, p00 + W, p00 + W + 1};
+            if (mk != nullptr) {       // padded pixels: value reads as 0 and receives no gradient
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = v[c] && !mk[v[c] ? px[c] : 0];
+            }
+            // the histogram the emit kernel's tickets will follow: a pixel row's two corners count together unless
+            // they straddle a bucket boundary (msda_bwd_sort_emit draws its tickets by the same rule)
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const int c0 = 2 * pr, c1 = c0 + 1;
+                const bool both = v[c0] && v[c1] && ((unsigned)px[c0] & (unsigned)(kSortBP - 1)) != (unsigned)(kSortBP - 1);
+                if (both) {
+                    atomicAdd(&hist[px[c0] >> kSortBPLog], 2u);
+                } else {
+                    if (v[c0]) atomicAdd(&hist[px[c0] >> kSortBPLog], 1u);
+                    if (v[c1]) atomicAdd(&hist[px[c1] >> kSortBPLog], 1u);
+                }
+            }
+            u32x4 rec;
+            rec.x = (((unsigned)b * (unsigned)sp.S + (unsigned)p00) * (unsigned)M + (unsigned)m) * ROWB;
+            rec.y = __float_as_uint(gate ? s.lh : 0.f);
+            rec.z = __float_as_uint(gate ? s.lw : 0.f);
+            rec.w = __float_as_uint(raw[u].a);        // (the weight itself: the softmax Jacobian wants it for gated-off points too)
+            const int it = it0 + u * kSortThreads;
+            R[it] = rec;
+            FL[it] = (v[0] ? 1u : 0u) | (v[1] ? 2u : 0u) | (v[2] ? 4u : 0u) | (v[3] ? 8u : 0u) | (gate ? 16u : 0u);
+        }
+    }
+    __syncthreads();
+    // the chunk's histogram: its row of the count matrix, and into the bucket totals
+    {
+        unsigned *const my_cnt = sp.cnt + ((size_t)bm * sp.nchunk + ck) * nbk;
+        unsigned *const cursor = sp.cursor + (size_t)bm * nbk;
+        for (int i = tid; i < nbk; i += kSortThreads) {
+            const unsigned c = hist[i];
+            my_cnt[i] = c;
+            if (c) atomicAdd(&cursor[i], c);
+        }
+    }
+    // ---- phase 2: four lanes x eight channels per item, 16 items per wavefront step ----
+    const int grp = lane >> 2, j4 = lane & 3;
+    const unsigned ch_a = kB16 ? 2u * (unsigned)j4 : (unsigned)j4;      // this lane's two 16-byte chunks of a staged row
+    const __amdgpu_buffer_rsrc_t vr = make_rsrc(value, value_bytes);
+    const unsigned ps = (unsigned)M * ROWB;
+    const bool role_y = j4 == 1, role_a = j4 == 2;
+    const bool split = grad_proj != nullptr;
+    // the softmax Jacobian in place of the finishing kernel: L * P = 16, so a wavefront step IS one (query, head) row and
+    // its sixteen quads hold the row's d/d(attention) -- grad_logit_t = a_t (ga_t - sum_j a_j ga_j)
+    const bool fuse_jac = split && soft16 != 0;
+    struct Step {
+        u32x4 rec;
+        unsigned fl, t, l;
+        int r;
+        bool vi;
+        u32x4 ua[4], ub[4];
+    };
+    auto issue = [&](int st) -> Step {
+        Step x;
+        const int it = st * 16 + grp;
+        x.vi = it < n_items;
+        const int itc = x.vi ? it : n_items - 1;
+        x.rec = R[itc];
+        x.fl = x.vi ? FL[itc] : 0u;
+        x.r = (itc * sp.magic_lp) >> 16;
+        x.t = (unsigned)(itc - x.r * LP);
+        x.l = x.t / (unsigned)P;
+        const unsigned wps = (unsigned)s_W[x.l] * ps;
+        const unsigned base = x.rec.x + (unsigned)j4 * 16u;
+        const unsigned off[4] = {(x.fl & 1u) ? base : kOobOffset, (x.fl & 2u) ? base + ps : kOobOffset,
+                                 (x.fl & 4u) ? base + wps : kOobOffset, (x.fl & 8u) ? base + wps + ps : kOobOffset};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            x.ua[k] = buf_load_u4(vr, off[k]);
+            if (!kB16) x.ub[k] = __builtin_amdgcn_raw_buffer_load_b128(vr, (int)off[k], 64, 0);
+        }
+        return x;
+    };
+    const int n_steps = (n_items + 15) >> 4;
+    if (wave >= n_steps) return;
+    Step cur = issue(wave);
+    for (int st = wave; st < n_steps; st += kSortThreads / 64) {
+        // the next step's corner rows travel while this step's are used (a wavefront's steps were a chain of round trips)
+        const bool more = st + kSortThreads / 64 < n_steps;
+        Step nxt;
+        if (more) nxt = issue(st + kSortThreads / 64);
+        const u32x4 rec = cur.rec;
+        const unsigned fl = cur.fl, t = cur.t, l = cur.l;
+        const int r = cur.r;
+        const bool vi = cur.vi;
+        const unsigned char *const grow = G + (unsigned)(vi ? r : nq) * kBinsGRow + ch_a * 16u;
+        const f32x4 ga = *reinterpret_cast<const f32x4 *>(grow);
+        const f32x4 gb = *reinterpret_cast<const f32x4 *>(grow + kChunkDelta);
+        const int W = s_W[l], H = s_H[l];
+        float d[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            f32x4 va, vb;
+            if (kB16) {
+                const u32x4 u = cur.ua[k];
+                va = f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                           __uint_as_float(u.y & 0xffff0000u)};
+                vb = f32x4{__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u), __uint_as_float(u.w << 16),
+                           __uint_as_float(u.w & 0xffff0000u)};
+            } else {
+                va = __builtin_bit_cast(f32x4, cur.ua[k]);
+                vb = __builtin_bit_cast(f32x4, cur.ub[k]);
+            }
+            d[k] = bins_dot8(ga, va, gb, vb);
+            MSDA_QUAD_SUM(d[k]);
+        }
+        // a gated-off point contributes exactly nothing, also for non-finite gradients
+        const bool gate = (fl & 16u) != 0u;
+        const float lh = __uint_as_float(rec.y), lw = __uint_as_float(rec.z), a_raw = __uint_as_float(rec.w);
+        const float a = gate ? a_raw : 0.f;
+        const float hh = 1.f - lh, hw = 1.f - lw;
+        const float pp = role_y ? hw : hh, qq = role_y ? lw : lh;
+        const float d_a = role_y ? d[2] : d[1], d_c = role_y ? d[1] : d[2];
+        const float size_r = offsets_done ? 1.f : (role_y ? (float)H : (float)W);
+        const float r_loc = gate ? (a * size_r) * (pp * (d_a - d[0]) + qq * (d[3] - d_c)) : 0.f;
+        float r_att = gate ? (hh * hw) * d[0] + (hh * lw) * d[1] + (lh * hw) * d[2] + (lh * lw) * d[3] : 0.f;
+        if (fuse_jac) {
+            // sum over the row's sixteen points = over the wavefront's sixteen quads (the four lanes of a quad agree);
+            // associated like msda_fused_finish16_rows_kernel: (t, t + 8), (t, t + 4), then (0 + 2) + (1 + 3)
+            float dt = a_raw * r_att;
+            dt += __shfl_xor(dt, 32, 64);       // t ^ 8
+            dt += __shfl_xor(dt, 16, 64);       // t ^ 4
+            // now every lane holds D[t & 3] (D_i = (d_i + d_i+8) + (d_i+4 + d_i+12)); the other three, inside the DPP row:
+            const float o1 = MSDA_DPP(dt, 0x141);       // row_half_mirror: the quad (t & 3) ^ 1
+            const float o2 = MSDA_DPP(dt, 0x140);       // row_mirror:      the quad (t & 3) ^ 3
+            const float o3 = MSDA_DPP(o1, 0x140);       //                  the quad (t & 3) ^ 2
+            // (D_0 + D_2) + (D_1 + D_3): this lane's pair is D_p + D_p^2, the other D_p^1 + D_p^3 -- sums commute
+            const float dot = (dt + o3) + (o1 + o2);
+            r_att = a_raw * (r_att - dot);
+        }
+        if (vi && j4 < 3) {
+            const unsigned qrow = qrow0 + (unsigned)r, pm = qrow * (unsigned)M + (unsigned)m;
+            float *dst;
+            if (split)
+                dst = grad_proj + (qrow * (unsigned)src.proj_stride +
+                                   (role_a ? (unsigned)src.n_off + (unsigned)m * (unsigned)LP + t
+                                           : ((unsigned)m * (unsigned)LP + t) * 2u + (unsigned)j4));
+            else
+                dst = role_a ? grad_attn + (pm * (unsigned)LP + t) : grad_loc + ((pm * (unsigned)LP + t) * 2u + (unsigned)j4);
+            *dst = role_a ? r_att : r_loc;
+        }
+        if (!more) break;
+        cur = nxt;
+    }
+}
+
+// ---- emit: one lane per (query, point) of one head writes the point's corner records ----
+__global__ __launch_bounds__(kSortThreads) void msda_bwd_sort_emit(const int64_t *__restrict__ shapes,
+                                                                    const int64_t *__restrict__ lstart,
+                                                                    const PointSrc src, int fused_loc, int soft16,
+                                                                    const SortPlan sp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    __shared__ int s_H[kMaxLevels], s_W[kMaxLevels], s_start[kMaxLevels];
+    unsigned *const hist = reinterpret_cast<unsigned *>(s_dyn);         // next free record of every bucket
+    const int tid = threadIdx.x;
+    // block -> (head, batch, emit chunk): head-major, one head per XCD like the gather (the records of a head are
+    // written and read through the same L2).  An emit chunk is `emult` chunks of the dots kernel.
+    const int nech = (sp.nchunk + sp.emult - 1) / sp.emult;
+    const int per = sp.N * nech;
+    const int chunk8 = (int)(gridDim.x >> 3);
+    const int sw = (int)(blockIdx.x & 7) * chunk8 + (int)(blockIdx.x >> 3);
+    if (sw >= per * sp.M) return;
+    const int m = sw / per, rem = sw - m * per;
+    const int b = rem / nech, eck = rem - b * nech;
     const int bm = b * sp.M + m;
     const int L = sp.L, P = sp.P, LP = L * P, nbk = sp.nbk;
     if (tid < L) {
@@ -114,66 +432,90 @@ __global__ __launch_bounds__(kSortThreads) void msda_bwd_sort_points(const int64
         s_W[tid] = (int)shapes[2 * tid + 1];
         s_start[tid] = (int)lstart[tid];
     }
-    unsigned *const my_cnt = sp.cnt + ((size_t)bm * sp.nchunk + ck) * nbk;
-    unsigned *const cursor = sp.cursor + (size_t)bm * nbk;
-    if (EMIT) {
-        // this workgroup's share of every bucket: one returning atomic per non-empty bucket
+    // this workgroup's share of every bucket: one returning atomic per non-empty bucket
+    {
+        const int c0 = eck * sp.emult, c1 = c0 + sp.emult < sp.nchunk ? c0 + sp.emult : sp.nchunk;
+        const unsigned *const cnt0 = sp.cnt + ((size_t)bm * sp.nchunk + c0) * nbk;
+        unsigned *const cursor = sp.cursor + (size_t)bm * nbk;
         for (int i = tid; i < nbk; i += kSortThreads) {
-            const unsigned c = my_cnt[i];
+            unsigned c = 0u;
+            for (int j = 0; j < c1 - c0; ++j) c += cnt0[(size_t)j * nbk + i];
             hist[i] = c ? atomicAdd(&cursor[i], c) : 0u;
         }
-    } else {
-        for (int i = tid; i < nbk; i += kSortThreads) hist[i] = 0u;
     }
     __syncthreads();
-    const int q0 = ck * sp.qc;
-    const int nq = sp.Lq - q0 < sp.qc ? sp.Lq - q0 : sp.qc;
+    const int q0 = eck * sp.emult * sp.qc;
+    const int nq = sp.Lq - q0 < sp.emult * sp.qc ? sp.Lq - q0 : sp.emult * sp.qc;
     const int n_items = nq * LP;
-    const unsigned char *const mk = mask ? mask + (size_t)b * sp.S : nullptr;
-    for (int it = tid; it < n_items; it += kSortThreads) {
-        const int ql = (it * sp.magic_lp) >> 16, t = it - ql * LP;
-        const int l = t / P;
-        const unsigned q = (unsigned)(q0 + ql);
-        const unsigned pm = ((unsigned)b * (unsigned)sp.Lq + q) * (unsigned)sp.M + (unsigned)m;
-        const f32x2 xy = *reinterpret_cast<const f32x2 *>(loc + ((size_t)pm * LP + t) * 2);
-        const int H = s_H[l], W = s_W[l];
-        const Sample<float> s = sample_setup<float>(xy.x, xy.y, H, W);
-        if (!s.gate) continue;
-        const int h0 = s.h_low, w0 = s.w_low;
-        const bool okh0 = h0 >= 0, okh1 = h0 + 1 <= H - 1, okw0 = w0 >= 0, okw1 = w0 + 1 <= W - 1;
-        bool v[4] = {okh0 && okw0, okh0 && okw1, okh1 && okw0, okh1 && okw1};
-        const int p00 = s_start[l] + h0 * W + w0;
-        const int px[4] = {p00, p00 + 1, p00 + W, p00 + W + 1};
-        if (mk != nullptr) {       // padded pixels: value reads as 0 and receives no gradient
+    const unsigned char *const mk = src.mask ? src.mask + (size_t)b * sp.S : nullptr;
+    // two items per lane and iteration: their inputs are requested together (a lane's chain is load -> ticket -> store)
+    for (int it0 = tid; it0 < n_items; it0 += 2 * kSortThreads) {
+        SortRaw raw[2];
+        unsigned qq[2], ll[2];
+        bool ok[2];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] = v[c] && !mk[v[c] ? px[c] : 0];
+        for (int u = 0; u < 2; ++u) {
+            const int it = it0 + u * kSortThreads;
+            ok[u] = it < n_items;
+            const unsigned itc = (unsigned)(ok[u] ? it : it0);
+            const unsigned ql = itc / (unsigned)LP, t = itc - ql * (unsigned)LP;
+            ll[u] = t / (unsigned)P;
+            qq[u] = (unsigned)q0 + ql;
+            const unsigned qrow = (unsigned)b * (unsigned)sp.Lq + qq[u];
+            raw[u] = sort_load_raw(src, fused_loc, qrow, qrow * (unsigned)sp.M + (unsigned)m, (unsigned)m, (unsigned)L,
+                                   (unsigned)LP, t, ll[u], soft16 != 0);
         }
-        if (!EMIT) {
+        if (soft16) {       // (as in the dots kernel: the same function, the same bits)
+            raw[0].a = sort_row16_softmax(raw[0].a);
+            raw[1].a = sort_row16_softmax(raw[1].a);
+        }
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (v[c]) atomicAdd(&hist[px[c] >> kSortBPLog], 1u);
-        } else {
-            const float a = attn[(size_t)pm * LP + t];
+        for (int u = 0; u < 2; ++u) {
+            const unsigned q = qq[u], l = ll[u];
+            const int H = s_H[l], W = s_W[l];
+            const f32x2 xy = sort_location(raw[u], src, fused_loc, P, H, W);
+            const Sample<float> s = sample_setup<float>(xy.x, xy.y, H, W);
+            if (!(s.gate && ok[u])) continue;
+            const int h0 = s.h_low, w0 = s.w_low;
+            const bool okh0 = h0 >= 0, okh1 = h0 + 1 <= H - 1, okw0 = w0 >= 0, okw1 = w0 + 1 <= W - 1;
+            bool v[4] = {okh0 && okw0, okh0 && okw1, okh1 && okw0, okh1 && okw1};
+            const int p00 = s_start[l] + h0 * W + w0;
+            const int px[4] = {p00, p00 + 1, p00 + W, p00 + W + 1};
+            if (mk != nullptr) {       // padded pixels: value reads as 0 and receives no gradient
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = v[c] && !mk[v[c] ? px[c] : 0];
+            }
+            // The two corners of a pixel row are neighbours: unless they straddle a bucket boundary they take TWO
+            // consecutive tickets with one LDS atomic and leave as one 16-byte store (half the L2 write requests of the
+            // emit, which is bound by them: 11.4 M scattered 8-byte stores = 72 us, profiles/r06_sorted_stats_v1.txt)
+            const float a = raw[u].a;
             const float hh = 1.f - s.lh, hw = 1.f - s.lw;
-            const float wk[4] = {hh * hw, hh * s.lw, s.lh * hw, s.lh * s.lw};
+            const float wk[4] = {(hh * hw) * a, (hh * s.lw) * a, (s.lh * hw) * a, (s.lh * s.lw) * a};
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (v[c]) {
-                    const unsigned pos = atomicAdd(&hist[px[c] >> kSortBPLog], 1u);
-                    sp.rec[pos] = u32x2{(q << kSortBPLog) | ((unsigned)px[c] & (unsigned)(kSortBP - 1)), __float_as_uint(wk[c] * a)};
+            for (int pr = 0; pr < 2; ++pr) {
+                const int c0 = 2 * pr, c1 = c0 + 1;
+                const unsigned d0 = (unsigned)px[c0] & (unsigned)(kSortBP - 1), d1 = (unsigned)px[c1] & (unsigned)(kSortBP - 1);
+                const bool both = v[c0] && v[c1] && d0 != (unsigned)(kSortBP - 1);
+                if (both) {
+                    const unsigned pos = atomicAdd(&hist[px[c0] >> kSortBPLog], 2u);
+                    typedef u32x4 __attribute__((aligned(8))) u32x4_a8;
+                    *reinterpret_cast<u32x4_a8 *>(sp.rec + pos) =
+                        u32x4{(q << kSortBPLog) | d0, __float_as_uint(wk[c0]), (q << kSortBPLog) | d1, __float_as_uint(wk[c1])};
+                } else {
+                    if (v[c0]) {
+                        const unsigned pos = atomicAdd(&hist[px[c0] >> kSortBPLog], 1u);
+                        sp.rec[pos] = u32x2{(q << kSortBPLog) | d0, __float_as_uint(wk[c0])};
+                    }
+                    if (v[c1]) {
+                        const unsigned pos = atomicAdd(&hist[px[c1] >> kSortBPLog], 1u);
+                        sp.rec[pos] = u32x2{(q << kSortBPLog) | d1, __float_as_uint(wk[c1])};
+                    }
                 }
             }
         }
     }
-    if (!EMIT) {
-        __syncthreads();
-        for (int i = tid; i < nbk; i += kSortThreads) {
-            const unsigned c = hist[i];
-            my_cnt[i] = c;
-            if (c) atomicAdd(&cursor[i], c);
-        }
-    }
 }
+
 
 // exclusive prefix over the workgroup (256 threads), the total to every thread
 __device__ __forceinline__ unsigned sort_block_excl(unsigned x, unsigned *s_wave, unsigned &total) {
@@ -313,30 +655,40 @@ __global__ __launch_bounds__(kSortThreads, 4) void msda_bwd_sort_gather(const TV
     // bytes); bf16 rows: ONE 16-byte piece = channels 8 j4 .. 8 j4 + 7
     const unsigned ca = (unsigned)j4 * 16u;
     f32x4 acc_a = f32x4{0.f, 0.f, 0.f, 0.f}, acc_b = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (unsigned i = 0; i < nmax; i += 4) {
-        u32x2 e[4];
+    // eight entries (sixteen 16-byte loads) in flight per lane; the next batch's entries are read from LDS while this
+    // batch's rows travel (a workgroup's list walk is a chain of round trips: 4 per batch measured 117 us at uniform)
+    constexpr int UN = MSDA_SORT_UN;
+    u32x2 e[UN];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) e[k] = E[pe + (unsigned)k < lim ? pe + (unsigned)k : n];
-        pe += 4u;
-        f32x4 x[4], y[4];
+    for (int k = 0; k < UN; ++k) e[k] = E[pe + (unsigned)k < lim ? pe + (unsigned)k : n];
+    for (unsigned i = 0; i < nmax; i += UN) {
+        u32x4 x[UN], y[UN];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (kB16) {
-                const u32x4 u = buf_load_u4(gor, e[k].x + ca);
-                x[k] = f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
-                             __uint_as_float(u.y & 0xffff0000u)};
-                y[k] = f32x4{__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u), __uint_as_float(u.w << 16),
-                             __uint_as_float(u.w & 0xffff0000u)};
-            } else {
-                x[k] = buf_load_f4(gor, e[k].x + ca);
-                y[k] = buf_load_f4(gor, e[k].x + ca + 64u);
-            }
+        for (int k = 0; k < UN; ++k) {
+            x[k] = buf_load_u4(gor, e[k].x + ca);
+            if (!kB16) y[k] = buf_load_u4(gor, e[k].x + ca + 64u);
         }
+        float wk[UN];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float wk = __uint_as_float(e[k].y);
-            acc_a += wk * x[k];
-            acc_b += wk * y[k];
+        for (int k = 0; k < UN; ++k) wk[k] = __uint_as_float(e[k].y);
+        pe += (unsigned)UN;
+#pragma unroll
+        for (int k = 0; k < UN; ++k) e[k] = E[pe + (unsigned)k < lim ? pe + (unsigned)k : n];
+        __builtin_amdgcn_sched_barrier(0);      // (keep the requests above the FMAs)
+#pragma unroll
+        for (int k = 0; k < UN; ++k) {
+            f32x4 xa, xb;
+            if (kB16) {
+                xa = f32x4{__uint_as_float(x[k].x << 16), __uint_as_float(x[k].x & 0xffff0000u), __uint_as_float(x[k].y << 16),
+                           __uint_as_float(x[k].y & 0xffff0000u)};
+                xb = f32x4{__uint_as_float(x[k].z << 16), __uint_as_float(x[k].z & 0xffff0000u), __uint_as_float(x[k].w << 16),
+                           __uint_as_float(x[k].w & 0xffff0000u)};
+            } else {
+                xa = __builtin_bit_cast(f32x4, x[k]);
+                xb = __builtin_bit_cast(f32x4, y[k]);
+            }
+            acc_a += wk[k] * xa;
+            acc_b += wk[k] * xb;
         }
     }
     const unsigned pix = (bucket << kSortBPLog) + (unsigned)grp;

@@ -309,3 +309,18 @@ __global__ __launch_bounds__(256) void msda_fused_points16_kernel(const int64_t 
         }
     }
 }
+
+// Zero `n` 32-bit words at `p` (16-byte aligned: a tensor) and `extra_n` words at `extra`: grad_value on request, and what
+// the chosen backward wants cleared next to it.
+__global__ __launch_bounds__(256) void msda_zero_words_kernel(unsigned *__restrict__ p, size_t n, unsigned *__restrict__ extra,
+                                                              unsigned extra_n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x, i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if ((reinterpret_cast<uintptr_t>(p) & 15u) == 0u) {
+        u32x4 *const p4 = reinterpret_cast<u32x4 *>(p);
+        for (size_t i = i0; i < n / 4; i += stride) p4[i] = u32x4{0u, 0u, 0u, 0u};
+        for (size_t i = (n & ~(size_t)3) + i0; i < n; i += stride) p[i] = 0u;
+    } else {
+        for (size_t i = i0; i < n; i += stride) p[i] = 0u;
+    }
+    for (size_t i = i0; i < extra_n; i += stride) extra[i] = 0u;
+}

@@ -100,6 +100,7 @@ std::atomic<int> opt_sel_level{-1};          // >= 0: pin the selector's level (
 std::atomic<int> opt_sel_up0{5}, opt_sel_up1{100}, opt_sel_down1{2}, opt_sel_down2{60};   // backward thresholds, 1/1000 of the valid corners
 std::atomic<int> opt_sel_fwd_up{50}, opt_sel_fwd_down{20};                                  // forward thresholds  // counting-sort backward: window margin (the window is only a table of counters)
 std::atomic<int> opt_bwd_sorted{1};       // selector level 2: grad_value by sort + gather when the caller gave scratch (0: the rows kernel)
+std::atomic<int> opt_bwd_sort_qc{0}, opt_bwd_sort_emult{0};   // sorted backward: queries per dots workgroup / chunks per emit workgroup (0: auto)
 std::atomic<int> opt_bwd_rows{1};         // 0: few-query D = 32 calls keep the generic row-per-block backward
 std::atomic<int> opt_fwd_head_major{0};    // gather forward: head-major task walk (one head per XCD)
 std::atomic<int> opt_fwd_win_rlog{0};       // windowed forward: log2 of the region height on level 0 (0: auto)
@@ -681,11 +682,20 @@ int backward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart,
     } else if (!grad_value || !grad_loc || !grad_attn) {
         return fail(MSDA_EINVAL, "null gradient pointer");
     }
-    if (zero_grad_value) {
-        const hipError_t e = hipMemsetAsync(grad_value, 0, (size_t)N * S * M * D * sizeof(TG), stream);
-        if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
-    }
-    if ((long)N * Lq == 0) { g_err[0] = 0; return MSDA_OK; }
+    // grad_value is accumulated into: zeroed here on request -- by a kernel, not a memset node (a replayed hipGraph of
+    // ROCm 7.2 does not order MEMSET nodes behind the kernels before them unless DEBUG_CLR_GRAPH_PACKET_CAPTURE=0,
+    // tools/graph_memset_probe.py) -- together with whatever else the chosen path wants cleared (the sorted backward's
+    // bucket totals: one launch instead of two)
+    const size_t gv_words = (size_t)N * S * M * D * (sizeof(TG) / 4);
+    auto zero_launch = [&](unsigned *extra, unsigned extra_n) -> int {
+        if (!zero_grad_value && extra_n == 0u) return MSDA_OK;
+        const size_t n1 = zero_grad_value ? gv_words : 0;
+        const size_t blocks = (n1 / 4 + extra_n + 255) / 256;
+        hipLaunchKernelGGL(msda_zero_words_kernel, dim3((unsigned)(blocks < 2048 ? (blocks ? blocks : 1) : 2048)), dim3(256), 0, stream,
+                           reinterpret_cast<unsigned *>(grad_value), n1, extra, extra_n);
+        return check_launch("msda_zero_words_kernel");
+    };
+    if ((long)N * Lq == 0) return zero_launch(nullptr, 0u);
     int variant = opt_bwd_variant.load();
     const long value_elems = (long)N * S * M * D;
     const long value_bytes = value_elems * (long)sizeof(TV);
@@ -724,55 +734,88 @@ int backward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart,
             SortPlan sp;
             const bool fits = d32_ok(D, L, value_elems) && L * P <= kRowsMaxLP && n_rows13 < (1L << 31) &&
                               workspace != nullptr && workspace_bytes > fused_bytes &&
-                              make_sort_plan(sp, N, S, M, L, Lq, P, sizeof(TV), (unsigned char *)workspace + fused_bytes) &&
+                              make_sort_plan(sp, N, S, M, L, Lq, P, sizeof(TV), (unsigned char *)workspace + fused_bytes,
+                                             opt_bwd_sort_qc.load(), opt_bwd_sort_emult.load()) &&
                               fused_bytes + sp.bytes <= workspace_bytes &&
-                              (size_t)sp.nbk * 4 <= 64 * 1024;
+                              sort_dots_lds(sp.qc, L * P, sp.nbk).bytes <= 64u * 1024u;
             if (fits) {
+                // grad_value (on request) and the bucket totals start from zero: one launch
+                if ((rc = zero_launch(sp.cursor, (unsigned)((size_t)N * M * sp.nbk)))) return rc;
                 const PointSrc src = make_src(loc, attn, fa, M, L, P);
                 const int threads = 256, per = threads / 32;
                 const int rgrid = clamp_grid((n_rows13 + per - 1) / per, 64);
                 const unsigned gv_bytes = (unsigned)(value_elems * 4);
                 const unsigned n_cursor = (unsigned)((size_t)N * M * sp.nbk);
                 const bool b16 = sizeof(TV) == 2;
-                // 1. grad_loc / grad_attn (fused: grad_proj, grad_ref_part); clears the bucket totals on the side
+                // 1. fused: the softmax weights once per row into the scratch; the locations too unless the kernels below
+                //    can compute them from the raw projection themselves (the slim form of the split backward: L * P = 16,
+                //    16-byte aligned rows -- one lane per row in both side kernels)
+                PointSrc src_k = src;
+                int fused_loc = 0, offsets_done = 0, soft16 = 0;
+                bool slim = false;
                 if (fused) {
+                    float *loc_ws = workspace, *attn_ws = workspace + (size_t)n_rows13 * L * P * 2;
+                    slim = L * P == 16 && (fa.proj_stride % 4) == 0 && (src.n_off % 4) == 0 && grad_ref_part == nullptr &&
+                           (((uintptr_t)fa.proj | (uintptr_t)grad_proj | (uintptr_t)workspace) & 15) == 0 &&
+                           opt_bwd_side_rows.load() != 0;
+                    if (slim) {
+                        // L * P = 16, 2-d reference points (the encoder's): the sixteen lanes of a row compute its softmax
+                        // in the dots and emit kernels themselves (one function, the bits of msda_fused_attn16_rows_kernel)
+                        // and the dots kernel applies the softmax Jacobian -- no side kernel, no weights in HBM.  4-d
+                        // reference points keep the weights in the scratch for the finishing kernel's location Jacobian
+                        fused_loc = 1;
+                        offsets_done = fa.ref_dim == 2 ? 1 : 0;
+                        soft16 = offsets_done;
+                        if (!soft16)
+                            hipLaunchKernelGGL(msda_fused_attn16_rows_kernel, dim3(clamp_grid((n_rows13 + 255) / 256, 32)),
+                                               dim3(256), 0, stream, src, (unsigned)n_rows13, (unsigned)M, attn_ws);
+                    } else if (L * P <= 16) {
+                        hipLaunchKernelGGL(msda_fused_points16_kernel, dim3(clamp_grid((n_rows13 * 16 + 255) / 256, 32)),
+                                           dim3(256), 0, stream, shapes, src, n_rows13, M, L, P, loc_ws, attn_ws);
+                    } else {
+                        hipLaunchKernelGGL(msda_fused_points_kernel, dim3(clamp_grid((n_rows13 * 8 + 255) / 256, 16)),
+                                           dim3(256), 0, stream, shapes, src, n_rows13, M, L, P, loc_ws, attn_ws);
+                    }
+                    if ((rc = check_launch("msda_fused_points_kernel"))) return rc;
+                    src_k.loc = loc_ws;
+                    src_k.attn = attn_ws;
+                }
+                const unsigned go_bytes = (unsigned)((size_t)n_rows13 * 32 * sizeof(TV));
+                // 2. the bucket totals start from zero; then, per (batch, head, chunk of queries): grad_loc / grad_attn
+                //    (fused: the columns of grad_proj) and the chunk's corner histogram
+                const SortDotsLds dl = sort_dots_lds(sp.qc, L * P, sp.nbk);
+                const int pgrid = (N * M * sp.nchunk + 7) & ~7;
+                // (with gradients of the reference points wanted -- no caller of this package asks for them on this path --
+                //  the rows kernel without its atomics runs AFTER and overwrites the columns of grad_proj with its own,
+                //  finished, results next to grad_ref_part; the dots kernel then only counts)
+                hipLaunchKernelGGL((msda_bwd_sort_dots<TV>), dim3(pgrid), dim3(kSortThreads), dl.bytes, stream, value, shapes,
+                                   lstart, src_k, fused_loc, offsets_done, soft16, grad_out, (float *)grad_loc, (float *)grad_attn,
+                                   fused ? grad_proj : (float *)nullptr, sp, dl, (unsigned)value_bytes);
+                if ((rc = check_launch("msda_bwd_sort_dots"))) return rc;
+                if (fused && grad_ref_part != nullptr) {
                     hipLaunchKernelGGL((msda_bwd_d32_rows<TV, true, false>), dim3(rgrid), dim3(threads), 0, stream, value, shapes,
                                        lstart, src, grad_out, N, S, M, L, Lq, P, (float *)grad_value, (float *)nullptr,
                                        (float *)nullptr, grad_proj, grad_ref_part, (unsigned)value_bytes, gv_bytes,
-                                       sp.cursor, n_cursor);
-                } else {
-                    hipLaunchKernelGGL((msda_bwd_d32_rows<TV, false, false>), dim3(rgrid), dim3(threads), 0, stream, value, shapes,
-                                       lstart, src, grad_out, N, S, M, L, Lq, P, (float *)grad_value, (float *)grad_loc,
-                                       (float *)grad_attn, (float *)nullptr, (float *)nullptr, (unsigned)value_bytes, gv_bytes,
-                                       sp.cursor, n_cursor);
-                }
-                if ((rc = check_launch("msda_bwd_d32_rows<no atomics>"))) return rc;
-                // 2. fused: the prologue once per point into the scratch (locations + softmax weights, the module's bits)
-                const float *p_loc = (const float *)loc, *p_attn = (const float *)attn;
-                if (fused) {
-                    float *loc_ws = workspace, *attn_ws = workspace + (size_t)n_rows13 * L * P * 2;
+                                       (unsigned *)nullptr, 0u);
+                    if ((rc = check_launch("msda_bwd_d32_rows<no atomics>"))) return rc;
+                } else if (fused && !soft16) {       // (soft16: finished by the dots kernel)
                     if (L * P <= 16)
-                        hipLaunchKernelGGL(msda_fused_points16_kernel, dim3(clamp_grid((n_rows13 * 16 + 255) / 256, 32)),
-                                           dim3(256), 0, stream, shapes, src, n_rows13, M, L, P, loc_ws, attn_ws);
+                        hipLaunchKernelGGL(msda_fused_finish16_kernel, dim3(clamp_grid((n_rows13 * 16 + 255) / 256, 32)),
+                                           dim3(256), 0, stream, shapes, src_k, n_rows13, M, L, P, grad_proj, offsets_done);
                     else
-                        hipLaunchKernelGGL(msda_fused_points_kernel, dim3(clamp_grid((n_rows13 * 8 + 255) / 256, 16)),
-                                           dim3(256), 0, stream, shapes, src, n_rows13, M, L, P, loc_ws, attn_ws);
-                    if ((rc = check_launch("msda_fused_points_kernel"))) return rc;
-                    p_loc = loc_ws;
-                    p_attn = attn_ws;
+                        hipLaunchKernelGGL(msda_fused_finish_kernel, dim3(clamp_grid((n_rows13 * 8 + 255) / 256, 16)),
+                                           dim3(256), 0, stream, shapes, src_k, n_rows13, M, L, P, grad_proj);
+                    if ((rc = check_launch("msda_fused_finish_kernel"))) return rc;
                 }
-                // 3. count -> scan -> emit -> gather
-                const int pgrid = (N * M * sp.nchunk + 7) & ~7;
+                // 3. scan -> emit -> gather
                 const size_t hist_lds = (size_t)sp.nbk * 4;
-                hipLaunchKernelGGL((msda_bwd_sort_points<false>), dim3(pgrid), dim3(kSortThreads), hist_lds, stream, shapes,
-                                   lstart, p_loc, p_attn, fa.mask, sp);
+                const int egrid = (N * M * ((sp.nchunk + sp.emult - 1) / sp.emult) + 7) & ~7;
                 hipLaunchKernelGGL(msda_bwd_sort_scan, dim3(N * M), dim3(kSortThreads), 0, stream, sp);
-                hipLaunchKernelGGL((msda_bwd_sort_points<true>), dim3(pgrid), dim3(kSortThreads), hist_lds, stream, shapes,
-                                   lstart, p_loc, p_attn, fa.mask, sp);
-                if ((rc = check_launch("msda_bwd_sort_points"))) return rc;
+                hipLaunchKernelGGL(msda_bwd_sort_emit, dim3(egrid), dim3(kSortThreads), hist_lds, stream, shapes, lstart, src_k,
+                                   fused_loc, soft16, sp);
+                if ((rc = check_launch("msda_bwd_sort_emit"))) return rc;
                 const int ggrid = (N * M * sp.max_items + 7) & ~7;
                 const size_t glds = (size_t)(kSortSlice + 2) * 8 + (size_t)kSortBP * 8;
-                const unsigned go_bytes = (unsigned)((size_t)n_rows13 * 32 * sizeof(TV));
                 g_kernel = fused ? (b16 ? "msda_bwd_d32_sorted<bf16,fused>" : "msda_bwd_d32_sorted<fused>")
                                  : (b16 ? "msda_bwd_d32_sorted<bf16>" : "msda_bwd_d32_sorted");
                 hipLaunchKernelGGL((msda_bwd_sort_gather<TV>), dim3(ggrid), dim3(kSortThreads), glds, stream, grad_out,
@@ -783,6 +826,7 @@ int backward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart,
         }
     }
     if (variant == 13) variant = 1;
+    if ((rc = zero_launch(nullptr, 0u))) return rc;
     if (variant == 0 || (variant >= 2 && variant != 10 && variant != 12)) variant = can_tile && P <= 8 ? 10 : 1;
     if (variant >= 2 && !can_tile) variant = 1;
     if constexpr (kD32Type) {
@@ -1191,7 +1235,7 @@ size_t msda_backward_workspace_bytes(int fused, int N, int S, int M, int D, int 
         sorted = sel_peek(1, M, L, P, elem_bytes, (hipStream_t)stream) >= 2;
     if (sorted && D == 32) {
         SortPlan sp;
-        if (make_sort_plan(sp, N, S, M, L, Lq, P, (size_t)elem_bytes, nullptr)) bytes = ((bytes + 255) & ~(size_t)255) + sp.bytes;
+        if (make_sort_plan(sp, N, S, M, L, Lq, P, (size_t)elem_bytes, nullptr, opt_bwd_sort_qc.load(), opt_bwd_sort_emult.load())) bytes = ((bytes + 255) & ~(size_t)255) + sp.bytes;
     }
     return bytes;
 }
@@ -1301,6 +1345,8 @@ static std::atomic<int> *find_opt(const char *key) {
     if (!strcmp(key, "bwd_bins_strip")) return &opt_bwd_bins_strip;
     if (!strcmp(key, "bwd_rows")) return &opt_bwd_rows;
     if (!strcmp(key, "bwd_sorted")) return &opt_bwd_sorted;
+    if (!strcmp(key, "bwd_sort_qc")) return &opt_bwd_sort_qc;
+    if (!strcmp(key, "bwd_sort_emult")) return &opt_bwd_sort_emult;
     if (!strcmp(key, "bwd_rows_block")) return &opt_bwd_rows_block;
     if (!strcmp(key, "fwd_win_rlog")) return &opt_fwd_win_rlog;
     if (!strcmp(key, "fwd_win_rlogx")) return &opt_fwd_win_rlogx;

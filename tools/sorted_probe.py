@@ -29,13 +29,25 @@ def main():
     ap.add_argument("--fused", action="store_true")
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--bf16", action="store_true")
+    ap.add_argument("--only", default="", help="e.g. uniform or encoder_like:4 -- that case only (profiling runs)")
+    ap.add_argument("--variants", default="", help="e.g. 13 -- that family only")
+    ap.add_argument("--opt", default="", help="msda_set_option pairs, e.g. bwd_sort_qc=32,bwd_sort_emult=4")
     args = ap.parse_args()
     from memotr_amd import MultiScaleDeformableAttention as MSDA
     from memotr_amd import _lib
     from memotr_amd.MultiScaleDeformableAttention import tag_host_shapes
     from memotr_amd.synth import make_inputs, to_fused_inputs
+    for kv in filter(None, args.opt.split(",")):
+        k, v = kv.split("=")
+        _lib.set_option(k, int(v))
     cases = [("encoder_like", 1.0), ("encoder_like", 2.0), ("encoder_like", 3.0), ("encoder_like", 4.0),
              ("encoder_like", 6.0), ("encoder_like", 8.0), ("uniform", 1.0)]
+    if args.only:
+        d, _, o = args.only.partition(":")
+        cases = [(d, float(o) if o else 1.0)]
+    fams = ((12, 0), (12, 1), (0, 2), (13, -1))
+    if args.variants:
+        fams = tuple(f for f in fams if str(f[0]) in args.variants.split(","))
     print("dist x scale | bins m6 | bins m9 | rows | sorted (13)   [ms]  fused=%s batch=%d bf16=%s" % (args.fused, args.batch, args.bf16))
     for dist, osc in cases:
         x = make_inputs(dist=dist, off_scale=osc, device="cuda", seed=3, batch=args.batch)
@@ -49,7 +61,7 @@ def main():
         else:
             call = lambda: MSDA.ms_deform_attn_backward(value, x["shapes"], x["level_start"], x["loc"], x["attn"], go, 64)   # noqa: E731
         row = []
-        for variant, level in ((12, 0), (12, 1), (0, 2), (13, -1)):
+        for variant, level in fams:
             _lib.set_option("bwd_variant", variant)
             _lib.set_option("sel_level", level)
             _lib.set_option("bwd_sorted", 0 if variant == 0 else 1)      # (level 2 without the sorted form: the rows kernel)
