@@ -186,8 +186,17 @@ class FusedCall(MsdaCall):
         f = to_fused_inputs(x)
         self.proj, self.ref = f["proj"], f["ref"]
         self.gp = torch.empty_like(self.proj)
-        nbytes = int(self.lib.msda_fused_workspace_bytes(self.N, self.Lq, self.M, self.L, self.P))
-        self.ws = torch.empty((nbytes,), dtype=torch.uint8, device=self.proj.device)   # as the operator wrapper does
+        self.ws = torch.empty((0,), dtype=torch.uint8, device=self.proj.device)
+        self.elem = 4
+
+    def scratch(self):
+        """As the operator wrapper does before every backward call: what the call site's next backward can use (the fused
+        prologue's block; plus the sort's records when its sampling points land far from their queries)."""
+        need = int(self.lib.msda_backward_workspace_bytes(1, self.N, self.S, self.M, self.D, self.L, self.Lq, self.P, self.elem,
+                                                          torch.cuda.current_stream().cuda_stream))
+        if need > self.ws.numel():
+            self.ws = torch.empty((need,), dtype=torch.uint8, device=self.proj.device)
+        return self.ws
 
     def fwd(self):
         x = self.x
@@ -200,6 +209,7 @@ class FusedCall(MsdaCall):
 
     def bwd(self):
         x = self.x
+        self.scratch()
         rc = self.lib.msda_fused_backward_ws_f32(x["value"].data_ptr(), x["shapes"].data_ptr(),
                                                  x["level_start"].data_ptr(), self.proj.data_ptr(), self.proj.shape[2],
                                                  self.ref.data_ptr(), 2, None, x["grad_out"].data_ptr(), self.N, self.S,
@@ -219,6 +229,7 @@ class FusedCallBf16(FusedCall):
         self.vb = x["value"].bfloat16().contiguous()
         self.gob = x["grad_out"].bfloat16().contiguous()
         self.outb = torch.empty(self.N, self.Lq, self.M * self.D, device=self.vb.device, dtype=torch.bfloat16)
+        self.elem = 2
 
     def fwd(self):
         x = self.x
@@ -231,6 +242,7 @@ class FusedCallBf16(FusedCall):
 
     def bwd(self):
         x = self.x
+        self.scratch()
         rc = self.lib.msda_fused_backward_ws_bf16(self.vb.data_ptr(), x["shapes"].data_ptr(), x["level_start"].data_ptr(),
                                                   self.proj.data_ptr(), self.proj.shape[2], self.ref.data_ptr(), 2, None,
                                                   self.gob.data_ptr(), self.N, self.S, self.M, self.D, self.L, self.Lq,

@@ -285,7 +285,10 @@ int msda_fused_points_f32(const int64_t *shapes_dev, const float *proj, int proj
  *       "bwd_bins_margin" / "bwd_bins_margin_hi" / "bwd_bins_strip" (counting-sort backward, variant 12: window margins
  *       of selector levels 0 / 1, region rows per strip of the block walk), "auto_select" (0: no selection, level 0),
  *       "sel_level" (-1: follow the data; >= 0: pin the level), "sel_up0" / "sel_up1" / "sel_down1" / "sel_down2" /
- *       "sel_fwd_up" / "sel_fwd_down" (thresholds in 1/1000 of the valid corners).
+ *       "sel_fwd_up" / "sel_fwd_down" (thresholds in 1/1000 of the valid corners; "sel_up1_rows" / "sel_down2_rows": the
+ *       level 1 <-> 2 thresholds of call sites whose caller never asks msda_backward_workspace_bytes -- level 2 is then
+ *       the rows kernel's float atomics, worth it only past ~10 %), "bwd_sort_qc" / "bwd_sort_emult" (sorted backward:
+ *       queries per dots workgroup, chunks per emit workgroup; 0 = auto).
  * Returns MSDA_OK or MSDA_EINVAL for an unknown key / bad value. */
 int msda_set_option(const char *key, int value);
 int msda_get_option(const char *key, int *value);

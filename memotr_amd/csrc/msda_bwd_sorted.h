@@ -25,8 +25,9 @@
 //   gather  a workgroup per work item: counting sort of the slice's records by destination pixel in LDS (64 counters,
 //           integer tickets), then four lanes x eight channels per destination row walk the row's list:
 //           acc += w * grad_out[query, head, :] (16-byte loads, one head per XCD so that its 2.9 MB grad_out slab stays
-//           in that XCD's L2), fp32 accumulation in registers, and ONE plain 128-byte store per row -- atomics only for
-//           the rows of buckets that were sliced (coarse pyramid levels, where thousands of points share a pixel).
+//           in that XCD's L2), fp32 accumulation in registers, and ONE plain 128-byte store per row;
+//   reduce  the rows of sliced buckets (coarse pyramid levels, where thousands of points share a pixel): their slices'
+//           partial rows, kept in the scratch, added in slice order.  No float atomic anywhere in the call.
 //
 // grad_loc / grad_attn come from msda_bwd_d32_dots below (the row phase of msda_bwd_d32_bins without a region; the fused
 // call: into the columns of grad_proj, the side kernels of msda_fused_side.h finish the Jacobians) -- or, when gradients
@@ -59,6 +60,8 @@ struct SortPlan {
     unsigned *cursor;        // [N * M][nbk] bucket totals (count), then the next free record of the bucket (scan, emit)
     unsigned *nwork;         // [N * M]
     u32x4 *work;             // [N * M][max_items] {bucket, first record, records, sliced}
+    u32x2 *red;              // [N * M][nbk] {first work item, slices} of every bucket (slices > 1: its rows are reduced)
+    float *part;             // [N * M][max_items][64 rows][32] partial row sums of the slices of sliced buckets
     u32x2 *rec;              // [N * M][cap]
     size_t bytes;            // of the whole scratch block
 };
@@ -97,6 +100,8 @@ inline bool make_sort_plan(SortPlan &sp, int N, int S, int M, int L, int Lq, int
     sp.nwork = reinterpret_cast<unsigned *>(base + o); o += up(nbm * 4);
     sp.cnt = reinterpret_cast<unsigned *>(base + o); o += up(nbm * sp.nchunk * nbk * 4);
     sp.work = reinterpret_cast<u32x4 *>(base + o); o += up(nbm * sp.max_items * 16);
+    sp.red = reinterpret_cast<u32x2 *>(base + o); o += up(nbm * nbk * 8);
+    sp.part = reinterpret_cast<float *>(base + o); o += up(nbm * sp.max_items * (size_t)kSortBP * 128);
     sp.rec = reinterpret_cast<u32x2 *>(base + o); o += up(nbm * cap * 8);
     sp.bytes = o;
     return true;
@@ -562,6 +567,7 @@ __global__ __launch_bounds__(kSortThreads) void msda_bwd_sort_scan(const SortPla
         const unsigned t = cursor[k];
         cursor[k] = start;
         const unsigned ns = (t + (unsigned)kSortSlice - 1u) / (unsigned)kSortSlice;
+        sp.red[(size_t)bm * nbk + k] = u32x2{wi, ns};
         if (ns) {
             const unsigned len = (t + ns - 1u) / ns;        // equal slices, none above kSortSlice
             for (unsigned s = 0; s < ns; ++s) {
@@ -578,8 +584,7 @@ __global__ __launch_bounds__(kSortThreads) void msda_bwd_sort_scan(const SortPla
 template <typename TV>
 __global__ __launch_bounds__(kSortThreads, 4) void msda_bwd_sort_gather(const TV *__restrict__ grad_out,
                                                                          float *__restrict__ grad_value,
-                                                                         const SortPlan sp, unsigned go_bytes,
-                                                                         unsigned gv_bytes) {
+                                                                         const SortPlan sp, unsigned go_bytes) {
     constexpr bool kB16 = sizeof(TV) == 2;
     constexpr unsigned ROWB = 32u * (unsigned)sizeof(TV);
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
@@ -692,20 +697,60 @@ __global__ __launch_bounds__(kSortThreads, 4) void msda_bwd_sort_gather(const TV
         }
     }
     const unsigned pix = (bucket << kSortBPLog) + (unsigned)grp;
-    if (cnt == 0u || pix >= (unsigned)sp.S) return;
     // fp32 grad_value row: the bytes of this lane's two pieces
     const unsigned oa = kB16 ? (unsigned)j4 * 32u : ca, ob = kB16 ? (unsigned)j4 * 32u + 16u : ca + 64u;
-    const unsigned goff = (((unsigned)b * (unsigned)sp.S + pix) * (unsigned)sp.M + (unsigned)m) * 128u;
-    if (!sliced) {
-        float *const dst = grad_value + (goff >> 2);
+    if (sliced) {
+        // a slice of a heavy bucket (the coarse pyramid levels: thousands of points share a pixel): its partial row sums go
+        // to the scratch, msda_bwd_sort_reduce adds the bucket's slices in a fixed order.  (Float atomics here -- 8 per lane
+        // -- were 5 M lane-atomics and 68 of the gather's 90 MB of writes at the encoder shape, profiles/r06_pmc_bwd_sorted_*.txt)
+        float *const dst = sp.part + (((size_t)bm * sp.max_items + item) * kSortBP + (unsigned)grp) * 32u;
         *reinterpret_cast<f32x4 *>(dst + (oa >> 2)) = acc_a;
         *reinterpret_cast<f32x4 *>(dst + (ob >> 2)) = acc_b;
-    } else {
-        const __amdgpu_buffer_rsrc_t gvr = make_rsrc(grad_value, gv_bytes);
+        return;
+    }
+    if (cnt == 0u || pix >= (unsigned)sp.S) return;
+    const unsigned goff = (((unsigned)b * (unsigned)sp.S + pix) * (unsigned)sp.M + (unsigned)m) * 128u;
+    float *const dst = grad_value + (goff >> 2);
+    *reinterpret_cast<f32x4 *>(dst + (oa >> 2)) = acc_a;
+    *reinterpret_cast<f32x4 *>(dst + (ob >> 2)) = acc_b;
+}
+
+// ---- reduce: the rows of sliced buckets = the sum of their slices' partial rows, slice by slice ----
+__global__ __launch_bounds__(kSortThreads) void msda_bwd_sort_reduce(float *__restrict__ grad_value, const SortPlan sp) {
+    const int per = sp.N * sp.nbk;
+    const int chunk8 = (int)(gridDim.x >> 3);
+    const int sw = (int)(blockIdx.x & 7) * chunk8 + (int)(blockIdx.x >> 3);
+    if (sw >= per * sp.M) return;
+    const int m = sw / per, rem = sw - m * per;
+    const int b = rem / sp.nbk, k = rem - b * sp.nbk;
+    const int bm = b * sp.M + m;
+    const u32x2 rd = sp.red[(size_t)bm * sp.nbk + k];
+    if (rd.y <= 1u) return;
+    const int tid = threadIdx.x, row = tid >> 2, j4 = tid & 3;
+    const unsigned pix = ((unsigned)k << kSortBPLog) + (unsigned)row;
+    const float *src = sp.part + (((size_t)bm * sp.max_items + rd.x) * kSortBP + (unsigned)row) * 32u + (unsigned)j4 * 4u;
+    f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f}, c = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr size_t kStep = (size_t)kSortBP * 32u;
+    unsigned sl = 0;
+    for (; sl + 4 <= rd.y; sl += 4, src += 4 * kStep) {       // (four slices requested together, added in slice order)
+        f32x4 x[4], y[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc_a[i], gvr, (int)(goff + oa + (unsigned)i * 4u), 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc_b[i], gvr, (int)(goff + ob + (unsigned)i * 4u), 0, 0);
+            x[i] = *reinterpret_cast<const f32x4 *>(src + i * kStep);
+            y[i] = *reinterpret_cast<const f32x4 *>(src + i * kStep + 16);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a += x[i];
+            c += y[i];
         }
     }
+    for (; sl < rd.y; ++sl, src += kStep) {
+        a += *reinterpret_cast<const f32x4 *>(src);
+        c += *reinterpret_cast<const f32x4 *>(src + 16);
+    }
+    if (pix >= (unsigned)sp.S) return;
+    float *const dst = grad_value + ((((size_t)b * sp.S + pix) * sp.M + m) * 32u + (unsigned)j4 * 4u);
+    *reinterpret_cast<f32x4 *>(dst) = a;
+    *reinterpret_cast<f32x4 *>(dst + 16) = c;
 }

@@ -97,7 +97,11 @@ std::atomic<int> opt_bwd_bins_margin{6};     // small-margin level (level 0 of t
 std::atomic<int> opt_bwd_bins_margin_hi{9};  // large-margin level (level 1): the largest window that keeps 5 workgroups per CU
 std::atomic<int> opt_auto_select{1};         // msda_select.h: follow the measured off-window share (0: level 0 always)
 std::atomic<int> opt_sel_level{-1};          // >= 0: pin the selector's level (tests, benchmarks)
-std::atomic<int> opt_sel_up0{5}, opt_sel_up1{100}, opt_sel_down1{2}, opt_sel_down2{60};   // backward thresholds, 1/1000 of the valid corners
+// backward thresholds, 1/1000 of the valid corners.  Level 2 is the sorted backward when the caller provides scratch
+// (0.21-0.28 ms at every offset scale, profiles/r06_sorted_probe.txt: it overtakes the large-margin windows once ~0.2 % of
+// the corners leave them) and the rows kernel's float atomics otherwise (0.5-1.1 ms: only past 10 %)
+std::atomic<int> opt_sel_up0{5}, opt_sel_up1{2}, opt_sel_down1{2}, opt_sel_down2{1};
+std::atomic<int> opt_sel_up1_rows{100}, opt_sel_down2_rows{60};
 std::atomic<int> opt_sel_fwd_up{50}, opt_sel_fwd_down{20};                                  // forward thresholds  // counting-sort backward: window margin (the window is only a table of counters)
 std::atomic<int> opt_bwd_sorted{1};       // selector level 2: grad_value by sort + gather when the caller gave scratch (0: the rows kernel)
 std::atomic<int> opt_bwd_sort_qc{0}, opt_bwd_sort_emult{0};   // sorted backward: queries per dots workgroup / chunks per emit workgroup (0: auto)
@@ -353,16 +357,20 @@ SelSlot *sel_acquire(int kind, int M, int L, int P, int dt, hipStream_t stream) 
     s.seen = s.host[9];
     memset(s.last, 0, sizeof(s.last));
     s.level = s.eff = 0; s.calls = 0u; s.frac = s.frac_inner = -1.f;      // (-1: nothing measured yet)
-    s.polled = false; s.pub_seen = s.seen;
+    s.polled = false; s.pub_seen = s.seen; s.scratch = false;
     s.stamp = ++g_sel_clock;
     s.used = true;
     return &s;
 }
 
-SelRule sel_rule(int kind) {
+SelRule sel_rule(int kind, bool scratch = true) {
     SelRule r;
     if (kind == 0) { r.up0 = opt_sel_fwd_up.load(); r.down1 = opt_sel_fwd_down.load(); r.up1 = r.down2 = 0; }
-    else { r.up0 = opt_sel_up0.load(); r.up1 = opt_sel_up1.load(); r.down1 = opt_sel_down1.load(); r.down2 = opt_sel_down2.load(); }
+    else {
+        r.up0 = opt_sel_up0.load(); r.down1 = opt_sel_down1.load();
+        r.up1 = scratch ? opt_sel_up1.load() : opt_sel_up1_rows.load();
+        r.down2 = scratch ? opt_sel_down2.load() : opt_sel_down2_rows.load();
+    }
     return r;
 }
 
@@ -384,7 +392,7 @@ void sel_refresh(SelSlot *s) {
         return;
     }
     const int kind = s->key.kind, top = kind == 0 ? 1 : 2;
-    const SelRule r = sel_rule(kind);
+    const SelRule r = sel_rule(kind, s->scratch);
     for (int ran = 0; ran < kSelLevels; ++ran) {
         const unsigned long long dv = cur[ran][0] - s->last[ran][0];
         if (dv < kSelMinSample || dv > (1ull << 62)) continue;
@@ -447,6 +455,7 @@ int sel_peek(int kind, int M, int L, int P, int dt, hipStream_t stream) {
     std::lock_guard<std::mutex> lock(g_sel_mu);
     for (int i = 0; i < kSelSlots; ++i)
         if (g_sel[i].used && g_sel[i].key == k) {
+            g_sel[i].scratch = true;        // (a caller that asks will bring scratch: level 2 is then the sorted backward)
             sel_refresh(&g_sel[i]);
             return capturing ? g_sel[i].eff : g_sel[i].level;
         }
@@ -819,8 +828,16 @@ int backward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart,
                 g_kernel = fused ? (b16 ? "msda_bwd_d32_sorted<bf16,fused>" : "msda_bwd_d32_sorted<fused>")
                                  : (b16 ? "msda_bwd_d32_sorted<bf16>" : "msda_bwd_d32_sorted");
                 hipLaunchKernelGGL((msda_bwd_sort_gather<TV>), dim3(ggrid), dim3(kSortThreads), glds, stream, grad_out,
-                                   (float *)grad_value, sp, go_bytes, gv_bytes);
-                return check_launch(g_kernel);
+                                   (float *)grad_value, sp, go_bytes);
+                if ((rc = check_launch(g_kernel))) return rc;
+                hipLaunchKernelGGL(msda_bwd_sort_reduce, dim3((N * M * sp.nbk + 7) & ~7), dim3(kSortThreads), 0, stream,
+                                   (float *)grad_value, sp);
+                {
+                    const char *name = g_kernel;
+                    rc = check_launch("msda_bwd_sort_reduce");
+                    g_kernel = name;
+                }
+                return rc;
             }
             variant = 1;        // (-> msda_bwd_d32_rows with its atomics, below)
         }
@@ -1338,6 +1355,8 @@ static std::atomic<int> *find_opt(const char *key) {
     if (!strcmp(key, "sel_level")) return &opt_sel_level;
     if (!strcmp(key, "sel_up0")) return &opt_sel_up0;
     if (!strcmp(key, "sel_up1")) return &opt_sel_up1;
+    if (!strcmp(key, "sel_up1_rows")) return &opt_sel_up1_rows;
+    if (!strcmp(key, "sel_down2_rows")) return &opt_sel_down2_rows;
     if (!strcmp(key, "sel_down1")) return &opt_sel_down1;
     if (!strcmp(key, "sel_down2")) return &opt_sel_down2;
     if (!strcmp(key, "sel_fwd_up")) return &opt_sel_fwd_up;

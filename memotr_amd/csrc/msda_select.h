@@ -18,7 +18,8 @@
 //   * the host reads that record at the next call of the same call site -- whatever has arrived; a few calls of
 //     delay are harmless, the offsets drift over thousands of steps -- takes the difference to what it saw last per
 //     level, and moves between LEVELS:
-//       backward  0: bins, small margin   1: bins, large margin   2: no windows (rows kernel)
+//       backward  0: bins, small margin   1: bins, large margin   2: no windows (sort + gather through the caller's
+//                 scratch, msda_bwd_sorted.h -- round 6; whole-row float atomics, msda_bwd_rows.h, for callers without)
 //       forward   0: windows              1: head-major gather
 //     with hysteresis; a level without windows produces no statistics, so every `kSelProbeEvery`-th call probes one
 //     level down;
@@ -76,6 +77,7 @@ struct SelSlot {
     int level;                      // what the data ask for
     int eff;                        // what a capturing call runs at (= level, or one below while a probe is due)
     bool polled;                    // msda_selector_poll() has announced `eff`: eager calls leave it alone from then on
+    bool scratch;                   // the site's caller sizes scratch for its backward calls (msda_backward_workspace_bytes): level 2 = sorted
     unsigned long long pub_seen;    // publishers' sequence number at the last poll (launches arriving = record in use)
     unsigned calls;
     float frac, frac_inner;         // last measured shares (of the valid corners)

@@ -310,3 +310,26 @@ def test_a_record_at_the_top_level_comes_back_down_under_replay(hip_lib, site):
     assert any(sig != 0 and "gather" in kernel for sig, kernel in log[n_far:]), log[n_far:]
     # (the level may leave 0 once more while the record's window placement -- running means measured on the far data --
     #  catches up with the near data: what is pinned here is the probe graph's kernel and the way back)
+
+
+def test_offsets_past_the_large_windows_take_the_sorted_backward(hip_lib, site):
+    """Round 6: level 2 is the sort + gather backward (memotr_amd/csrc/msda_bwd_sorted.h) for callers that size scratch
+    through msda_backward_workspace_bytes -- this package's wrappers do.  Its cost does not depend on where the points
+    land (like the reference's, ms_deform_im2col_cuda.cuh:301-403), so the record moves to it as soon as a few per mille
+    of the corners leave the large windows ("sel_up1" 2), not at the 10 % the rows kernel's float atomics needed."""
+    from memotr_amd import MultiScaleDeformableAttention as MSDA
+    assert hip_lib.get_option("sel_up1") == 2 and hip_lib.get_option("sel_up1_rows") == 100
+    x = _inputs("encoder_like", 4.0)
+    want = _oracle(x)
+    levels = []
+    for _ in range(12):
+        got = MSDA.ms_deform_attn_backward(x["value"], x["shapes"], x["level_start"], x["loc"], x["attn"], x["grad_out"], 64)
+        torch.cuda.synchronize()
+        levels.append(hip_lib.selector_last()[0])
+    assert levels[-1] == 2 and "sorted" in hip_lib.last_kernel(), (levels, hip_lib.last_kernel(), hip_lib.selector_last())
+    _check_bwd(got, want, "x4 offsets, sorted")
+    hip_lib.set_option("bwd_sorted", 0)            # the same level without the sorted form: the rows kernel
+    got = MSDA.ms_deform_attn_backward(x["value"], x["shapes"], x["level_start"], x["loc"], x["attn"], x["grad_out"], 64)
+    assert "rows" in hip_lib.last_kernel(), hip_lib.last_kernel()
+    _check_bwd(got, want, "x4 offsets, rows")
+    hip_lib.set_option("bwd_sorted", 1)
