@@ -37,13 +37,23 @@ CONFIGS = [
     ("win 16x16 512 thr m2222", dict(fwd_variant=12, fwd_win_margins=0x2222)),
     ("win 16x16 512 thr m4333", dict(fwd_variant=12, fwd_win_margins=0x4333)),
     ("win 16x16 256 thr", dict(fwd_variant=12, fwd_win_rlog=4, fwd_win_block=256)),
+    # round 6: fewer levels in LDS (level 1 through the vector L1 next to level 0): half the fill, ~44 KB of windows
+    ("r6 win l0=2 (levels 2-3 in LDS) e0", dict(fwd_variant=12, fwd_win_l0=2, fwd_win_early=0)),
+    ("r6 win l0=2 e2", dict(fwd_variant=12, fwd_win_l0=2, fwd_win_early=2)),
+    ("r6 win l0=2 16x8 e2", dict(R3, fwd_win_rlogx=4, fwd_win_block=512, fwd_win_l0=2, fwd_win_early=2)),
+    ("r6 win l0=2 8x8 256 w3 e4", dict(R3, fwd_win_block=256, fwd_win_l0=2)),
+    ("r6 win l0=3 e2", dict(fwd_variant=12, fwd_win_l0=3, fwd_win_early=2)),
+    ("r6 win margins 3,3,2,2 (levels 2-3 smaller)", dict(fwd_variant=12, fwd_win_margins=0x2233)),
 ]
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default="gpurun_out/fwd_win_sweep.txt")
+    ap.add_argument("--only", default="", help="substring filter on the configuration names (the default is always kept)")
     args = ap.parse_args()
+    if args.only:
+        CONFIGS[:] = [c for i, c in enumerate(CONFIGS) if i == 0 or args.only in c[0]]
     os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
     lines = []
 

@@ -18,7 +18,7 @@ for P in "$P1" "$P2" "$P3" "$P4" "$P5" "$P6"; do
   rocprofv3 --kernel-trace --output-format csv --pmc $P -d "$OUT/p$i" -o p -- python tools/pmc_probe.py "$@" > "$OUT/p$i.log" 2>&1
 done
 python - "$OUT" "$*" > gpurun_out/pmc_${TAG}.txt <<'PY'
-import csv, glob, sys, collections
+import csv, glob, re, sys, collections
 root = sys.argv[1]
 print("# tools/pmc_probe.sh", sys.argv[2])
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -26,7 +26,8 @@ dur = collections.defaultdict(list)
 for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         if "msda" in r["Kernel_Name"]:
-            k = r["Kernel_Name"].split("::")[-1].split("(")[0]
+            m_ = re.search(r"msda_\w+(<[^>]*>)?", r["Kernel_Name"])      # (argument types hold "::" too)
+            k = m_.group(0) if m_ else r["Kernel_Name"][:60]
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in agg.items():
     print(k)
