@@ -45,3 +45,21 @@ def test_a_launcher_that_started_the_wrong_world_is_reported_as_such():
     r = _run(["--gpus", "2"], WORLD_SIZE="3", RANK="0", LOCAL_RANK="0", MEMOTR_BENCH_DEVICE_COUNT="4")
     assert r.returncode != 0
     assert "WORLD_SIZE=3" in r.stderr or "needs a GPU" in r.stderr
+
+
+def test_eight_rank_launch_rehearsal_rendezvous_thread_pools_and_one_json_line():
+    """Round-5 verdict, item 7: the 8-GPU launch minus the GPUs.  `python bench.py --gpus 8` with a stubbed device count
+    starts eight ranks itself; they rendezvous on 127.0.0.1, size their torch thread pools by an eighth of the
+    container's CPU quota (eight ranks share it on the driver's box: 16 CPUs -> 2 per rank, one of them for the pool),
+    all-reduce once, and exactly one JSON line comes out -- rank 0's."""
+    r = _run(["--gpus", "8", "--steps", "1", "--warmup", "0"], MEMOTR_BENCH_DEVICE_COUNT="8", MEMOTR_BENCH_REHEARSAL="1")
+    assert r.returncode == 0, r.stderr[-1500:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-800:]
+    out = json.loads(lines[0])
+    assert out["rehearsal"] and out["n_gpus"] == 8 and out["local_world"] == 8
+    assert out["rank_sum"] == 36.0                                    # 1 + 2 + ... + 8: every rank took part
+    from memotr_amd.utils.host import cpu_quota
+    want = max(1, int(cpu_quota() * 0.5 / 8))
+    assert out["torch_threads"] == want and out["torch_threads_sum"] == 8.0 * want, out
+    assert abs(out["cpu_quota_per_rank"] - cpu_quota() / 8) < 1e-9
