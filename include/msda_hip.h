@@ -283,7 +283,10 @@ int msda_fused_points_f32(const int64_t *shapes_dev, const float *proj, int proj
  *       level 2 builds grad_value by sort + gather when the caller gave scratch; 0: the rows kernel's float atomics),
  *       "bwd_wide_log2", "bwd_ablate" / "fwd_win_ablate" (profiling only: results are wrong by construction),
  *       "bwd_bins_margin" / "bwd_bins_margin_hi" / "bwd_bins_strip" (counting-sort backward, variant 12: window margins
- *       of selector levels 0 / 1, region rows per strip of the block walk), "auto_select" (0: no selection, level 0),
+ *       of selector levels 0 / 1, region rows per strip of the block walk), "auto_select" (0: no selection, level 0), "deterministic" (1: the
+ *       FORWARD keeps one summation order whatever the selector's statistics say -- identical calls return identical bits,
+ *       like the reference's atomic-free forward; the backward accumulates in an order that varies from run to run, like
+ *       the reference's atomicAdd),
  *       "sel_level" (-1: follow the data; >= 0: pin the level), "sel_up0" / "sel_up1" / "sel_down1" / "sel_down2" /
  *       "sel_fwd_up" / "sel_fwd_down" (thresholds in 1/1000 of the valid corners; "sel_up1_rows" / "sel_down2_rows": the
  *       level 1 <-> 2 thresholds of call sites whose caller never asks msda_backward_workspace_bytes -- level 2 is then

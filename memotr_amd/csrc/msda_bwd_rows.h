@@ -93,8 +93,8 @@ __global__ __launch_bounds__(256) void msda_bwd_d32_rows(
         if (FUSED) {
             const float lg = c < LP ? fused_logits(fs, qrow, m, LP)[c] : -INFINITY;
             mx = half32_max(lg);
-            e_t = expf(lg - mx);
-            rsum = 1.f / half32_sum(e_t);
+            e_t = sm_exp(lg, mx);                   // (msda_common.h: the one softmax arithmetic; half32_sum IS its tree)
+            rsum = sm_rcp(half32_sum(e_t));
         }
         if (c < LP) {
             const int t = c, l = t / P;
@@ -192,8 +192,8 @@ __global__ __launch_bounds__(256) void msda_bwd_d32_rows(
                 const float *lg = fused_logits(fs, qrow, m, LP);
                 float *gp = grad_proj + (size_t)qrow * fs.proj_stride;
                 float dot = 0.f;
-                for (int j = 0; j < LP; ++j) dot += (expf(lg[j] - mx) * rsum) * res[2 * LP + j];
-                const float a_t = expf(lg[t] - mx) * rsum;
+                for (int j = 0; j < LP; ++j) dot += (sm_exp(lg[j], mx) * rsum) * res[2 * LP + j];
+                const float a_t = sm_exp(lg[t], mx) * rsum;
                 gp[fs.n_off + m * LP + t] = a_t * (res[2 * LP + t] - dot);
                 if (fs.ref_dim == 2) {
                     gp[(m * LP + t) * 2] = gx / (float)s_W[l];

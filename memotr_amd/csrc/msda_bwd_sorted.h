@@ -133,20 +133,20 @@ __device__ __forceinline__ f32x2 sort_location(const SortRaw &r, const PointSrc 
 }
 
 // The softmax weight of a point from its logit, by the sixteen lanes (one DPP row) that hold the L * P = 16 logits of a
-// (query, head) row: exp(logit - max) * (1 / sum) with the library's exact expf and ONE IEEE division per row, the sum
-// associated like msda_fused_attn16_rows_kernel's ((t, t + 8) pairs first, then 1, 2, 4) -- the same bits.
+// (query, head) row: msda_common.h's arithmetic (sm_exp / sm_rcp, adjacent-pair tree = the butterflies t ^ 1, 2, 4, 8),
+// the bits of the windowed forward and of msda_fused_attn16_rows_kernel.
 __device__ __forceinline__ float sort_row16_softmax(float lg) {
     float mx = lg;
     mx = fmaxf(mx, MSDA_DPP(mx, 0xB1));
     mx = fmaxf(mx, MSDA_DPP(mx, 0x4E));
     mx = fmaxf(mx, MSDA_DPP(mx, 0x141));
     mx = fmaxf(mx, MSDA_DPP(mx, 0x140));
-    const float e = expf(lg - mx);
-    float sum = e + MSDA_DPP(e, 0x128);          // row_ror:8 -> lane t ^ 8
-    sum += MSDA_DPP(sum, 0xB1);                  // t ^ 1
+    const float e = sm_exp(lg, mx);
+    float sum = e + MSDA_DPP(e, 0xB1);           // t ^ 1
     sum += MSDA_DPP(sum, 0x4E);                  // t ^ 2
     sum += MSDA_DPP(sum, 0x141);                 // the other quad of the eight (all four lanes of a quad hold one value)
-    return e * (1.f / sum);
+    sum += MSDA_DPP(sum, 0x140);                 // the other eight
+    return e * sm_rcp(sum);
 }
 
 // ---- dots + count: grad_loc / grad_attn of a chunk of queries of one head, and the chunk's corner histogram ----

@@ -196,7 +196,7 @@ __global__ __launch_bounds__(kTileThreads, PTS <= 2 ? MSDA_LV_WGS : 2) void msda
             const f32x2 xy = point_location<FUSED>(src, pm, qrow, m, L, P, t, l, H, W);
             px_[p] = xy.x;
             py_[p] = xy.y;
-            pa[p] = FUSED ? expf(lg[t] - mx) * rsum : src.attn[pm * (unsigned)LP + (unsigned)t];
+            pa[p] = FUSED ? sm_exp(lg[t], mx) * rsum : src.attn[pm * (unsigned)LP + (unsigned)t];
         }
     }
     __syncthreads();      // the zeroed window / shared scalars are in place

@@ -18,10 +18,10 @@ __global__ __launch_bounds__(256) void msda_softmax_jacobian_kernel(const PointS
         float mx, rsum;
         row_softmax_stats<8>(lg, LP, sub, mx, rsum);
         float dot = 0.f;
-        for (int t = sub; t < LP; t += 8) dot += (expf(lg[t] - mx) * rsum) * ga[t];
+        for (int t = sub; t < LP; t += 8) dot += (sm_exp(lg[t], mx) * rsum) * ga[t];
         dot = row_sum<8>(dot);
         if (ok)
-            for (int t = sub; t < LP; t += 8) ga[t] = (expf(lg[t] - mx) * rsum) * (ga[t] - dot);
+            for (int t = sub; t < LP; t += 8) ga[t] = (sm_exp(lg[t], mx) * rsum) * (ga[t] - dot);
     }
 }
 
@@ -100,8 +100,9 @@ __global__ __launch_bounds__(256) void msda_fused_finish16_kernel(const int64_t 
 
 // The two side kernels of the slim split backward with ONE lane per (query, head) row (L*P == 16, row pitches multiples
 // of 4): the sixteen logits / weights / gradients of a row are four 16-byte accesses of that lane, the softmax and its
-// Jacobian run in registers -- no cross-lane traffic, a sixteenth of the threads, one index division per row.  The sums
-// associate exactly like the 16-lane butterflies above ((t, t + 8) first, then 4, 2, 1 / 1, 2, 4), so the bits are theirs.
+// Jacobian run in registers -- no cross-lane traffic, a sixteenth of the threads, one index division per row.  The
+// softmax is msda_common.h's (sm_exp / sm_rcp, adjacent-pair tree); the Jacobian's dot product associates like the 16-lane
+// butterflies above ((t, t + 8) first, then 4, then (0 + 2) + (1 + 3)), so the bits are theirs.
 __global__ __launch_bounds__(256) void msda_fused_attn16_rows_kernel(const PointSrc fs, unsigned n_rows, unsigned M,
                                                                     float *__restrict__ attn_out) {
     for (unsigned pm = blockIdx.x * blockDim.x + threadIdx.x; pm < n_rows; pm += gridDim.x * blockDim.x) {
@@ -117,13 +118,12 @@ __global__ __launch_bounds__(256) void msda_fused_attn16_rows_kernel(const Point
         float mx = lg[0];
 #pragma unroll
         for (int t = 1; t < 16; ++t) mx = fmaxf(mx, lg[t]);
-        float e[16], s8[8];
+        float e[16], q[4];
 #pragma unroll
-        for (int t = 0; t < 16; ++t) e[t] = expf(lg[t] - mx);
+        for (int t = 0; t < 16; ++t) e[t] = sm_exp(lg[t], mx);
 #pragma unroll
-        for (int t = 0; t < 8; ++t) s8[t] = e[t] + e[t + 8];
-        const float sum = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
-        const float rsum = 1.f / sum;
+        for (int k = 0; k < 4; ++k) q[k] = (e[4 * k] + e[4 * k + 1]) + (e[4 * k + 2] + e[4 * k + 3]);
+        const float rsum = sm_rcp((q[0] + q[1]) + (q[2] + q[3]));       // (the adjacent-pair tree of msda_common.h)
         f32x4 *op = reinterpret_cast<f32x4 *>(attn_out + (size_t)pm * 16u);
 #pragma unroll
         for (int k = 0; k < 4; ++k) op[k] = f32x4{e[4 * k] * rsum, e[4 * k + 1] * rsum, e[4 * k + 2] * rsum, e[4 * k + 3] * rsum};

@@ -67,10 +67,11 @@ __device__ __forceinline__ void stage_records_fwd(u32x4 *rec, const PointSrc &sr
         lg = fused_logits(src, qrow, m, LP);
         if (two) {
             const float l0 = sub < LP ? lg[sub] : -INFINITY, l1 = sub + LANES < LP ? lg[sub + LANES] : -INFINITY;
+            // (the one softmax arithmetic of the fused kernels, msda_common.h: chunk butterflies, then the chunks in order)
             mx = row_max<LANES>(fmaxf(l0, l1));
-            e0 = expf(l0 - mx);
-            e1 = expf(l1 - mx);
-            rsum = 1.f / row_sum<LANES>(e0 + e1);
+            e0 = sm_exp(l0, mx);
+            e1 = sm_exp(l1, mx);
+            rsum = sm_rcp(row_sum<LANES>(e0) + row_sum<LANES>(e1));
         } else {
             row_softmax_stats<LANES>(lg, LP, sub, mx, rsum);
         }
@@ -80,7 +81,7 @@ __device__ __forceinline__ void stage_records_fwd(u32x4 *rec, const PointSrc &sr
         const int l = (int)(((float)t + 0.5f) * rcp_p);      // == t / P (the product stays 0.5/P away from integers)
         const int H = s_H[l], W = s_W[l];
         const f32x2 xy = point_location<FUSED>(src, pmc, qrow, m, L, P, t, l, H, W);
-        const float a_in = FUSED ? (two ? (t == sub ? e0 : e1) : expf(lg[t] - mx)) * rsum
+        const float a_in = FUSED ? (two ? (t == sub ? e0 : e1) : sm_exp(lg[t], mx)) * rsum
                                  : src.attn[pmc * (unsigned)LP + (unsigned)t];
         Sample<float> s = sample_setup<float>(xy.x, xy.y, H, W);
         const bool live = s.gate && row_ok;

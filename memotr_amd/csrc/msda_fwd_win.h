@@ -587,15 +587,13 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
         // -- staging: this lane's point, straight-line --
             float a_in;
             if (FUSED) {
-                // exp2 / rcp approximations (<= 2 ulp on a weight): the forward's tolerance is 1e-3, the backward
-                // recomputes its own weights with the library's exact form (expf, one IEEE division).  Round 5 tried
-                // that form here -- the weights would then be, bit for bit, the ones the backward differentiates -- and
-                // measured +1.5-2 us on the fused call (47.2 vs 45.5 us): ~25 more instructions in a staging that is
-                // already 6 us longer than the plain kernel's.  Kept approximate; the difference to the exact weights
-                // is asserted to stay below 4e-7 (tests/test_msda_fwd_win_gpu.py).
+                // the one softmax arithmetic of the fused kernels (msda_common.h: exp2 / rcp, adjacent-pair tree -- row16_sum
+                // IS that tree): the weights are, bit for bit, the ones the backward differentiates and
+                // msda_fused_points_f32 exposes.  (Rounds 3-5 had the exact expf / division in the backward only; bringing
+                // THEM here cost 1.5-2 us, so round 6 took this form there.)
                 const float mx = row16_max(raw.w);
-                const float e = __builtin_amdgcn_exp2f((raw.w - mx) * 1.4426950408889634f);
-                a_in = e * __builtin_amdgcn_rcpf(row16_sum(e));
+                const float e = sm_exp(raw.w, mx);
+                a_in = e * sm_rcp(row16_sum(e));
             } else {
                 a_in = raw.w;
             }

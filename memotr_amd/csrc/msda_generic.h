@@ -267,15 +267,15 @@ __global__ __launch_bounds__(256) void msda_fused_points_kernel(const int64_t *_
             if (ok) {
                 loc_out[(pm * LP + t) * 2] = xy.x;
                 loc_out[(pm * LP + t) * 2 + 1] = xy.y;
-                attn_out[pm * LP + t] = expf(lg[t] - mx) * rsum;
+                attn_out[pm * LP + t] = sm_exp(lg[t], mx) * rsum;
             }
         }
     }
 }
 
 // The same for L*P <= 16 with one lane per point (16 lanes per row): every lane reads and writes consecutive
-// addresses.  The softmax sum adds in the order of the 8-lane form above ((t, t+8) pairs first, then the butterfly
-// over 8 lanes), so both produce the same bits.
+// addresses.  The softmax is the one of msda_common.h (sm_exp / sm_rcp, adjacent-pair tree): the same bits as the 8-lane
+// form above and as every forward and backward kernel.
 __global__ __launch_bounds__(256) void msda_fused_points16_kernel(const int64_t *__restrict__ shapes, const PointSrc fs,
                                                                  long n_rows, int M, int L, int P,
                                                                  float *__restrict__ loc_out,
@@ -293,12 +293,12 @@ __global__ __launch_bounds__(256) void msda_fused_points16_kernel(const int64_t 
         float mx = lg;
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
-        const float e = expf(lg - mx);
-        float sum = e + __shfl_xor(e, 8, 16);
-        sum += __shfl_xor(sum, 1, 16);
+        const float e = sm_exp(lg, mx);
+        float sum = e + __shfl_xor(e, 1, 16);       // (the adjacent-pair tree of msda_common.h)
         sum += __shfl_xor(sum, 2, 16);
         sum += __shfl_xor(sum, 4, 16);
-        const float rsum = 1.f / sum;
+        sum += __shfl_xor(sum, 8, 16);
+        const float rsum = sm_rcp(sum);
         if (ok) {
             if (loc_out != nullptr) {     // (null: the consumer computes the locations itself, msda_bwd_bins.h)
                 const int l = t / P;

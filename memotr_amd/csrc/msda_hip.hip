@@ -95,6 +95,7 @@ std::atomic<int> opt_bwd_rows_block{0};   // threads per workgroup of msda_bwd_d
 std::atomic<int> opt_bwd_bins_strip{4};   // counting-sort backward: region rows per strip of the block -> region walk
 std::atomic<int> opt_bwd_bins_margin{6};     // small-margin level (level 0 of the selector)
 std::atomic<int> opt_bwd_bins_margin_hi{9};  // large-margin level (level 1): the largest window that keeps 5 workgroups per CU
+std::atomic<int> opt_deterministic{0};       // 1: the forward keeps ONE summation order whatever the statistics say (pyramid: the windowed kernel)
 std::atomic<int> opt_auto_select{1};         // msda_select.h: follow the measured off-window share (0: level 0 always)
 std::atomic<int> opt_sel_level{-1};          // >= 0: pin the selector's level (tests, benchmarks)
 // backward thresholds, 1/1000 of the valid corners.  Level 2 is the sorted backward when the caller provides scratch
@@ -519,6 +520,11 @@ int forward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart, 
             slot = sel_acquire(0, M, L, P, (int)sizeof(TV), stream);
             bool probe = false;
             sel = sel_level(slot, 0, probe, slot != nullptr && stream_capturing(stream));
+            // "deterministic": the windowed and the gather kernel add a row's points in different orders (same values to
+            // 2e-5, different last bits), and the selector moves a call site between them from statistics of EARLIER calls;
+            // with the option on, identical calls return identical bits -- the windowed kernel's, whose results do not depend
+            // on where its windows sit (the record keeps measuring, nothing follows it)
+            if (opt_deterministic.load()) sel = 0;
             if (sel >= 1) { variant = 3; sel_head_major = true; }
         }
     } else if (variant == 12 && can32 && shapes_host != nullptr) {
@@ -1352,6 +1358,7 @@ static std::atomic<int> *find_opt(const char *key) {
     if (!strcmp(key, "bwd_bins_margin")) return &opt_bwd_bins_margin;
     if (!strcmp(key, "bwd_bins_margin_hi")) return &opt_bwd_bins_margin_hi;
     if (!strcmp(key, "auto_select")) return &opt_auto_select;
+    if (!strcmp(key, "deterministic")) return &opt_deterministic;
     if (!strcmp(key, "sel_level")) return &opt_sel_level;
     if (!strcmp(key, "sel_up0")) return &opt_sel_up0;
     if (!strcmp(key, "sel_up1")) return &opt_sel_up1;
