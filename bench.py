@@ -188,6 +188,7 @@ class FusedCall(MsdaCall):
         self.gp = torch.empty_like(self.proj)
         self.ws = torch.empty((0,), dtype=torch.uint8, device=self.proj.device)
         self.elem = 4
+        self.have_out = False        # fwd() has filled self.out for these inputs
 
     def scratch(self):
         """As the operator wrapper does before every backward call: what the call site's next backward can use (the fused
@@ -206,13 +207,16 @@ class FusedCall(MsdaCall):
                                              self.out.data_ptr(), self.hptr, torch.cuda.current_stream().cuda_stream)
         if rc:
             raise RuntimeError(self._lib.last_error())
+        self.have_out = True
 
     def bwd(self):
         x = self.x
         self.scratch()
-        rc = self.lib.msda_fused_backward_ws_f32(x["value"].data_ptr(), x["shapes"].data_ptr(),
+        # (as the autograd function does: the forward's output rides along -- `self.out` holds it, fwd() wrote it)
+        rc = self.lib.msda_fused_backward_out_f32(x["value"].data_ptr(), x["shapes"].data_ptr(),
                                                  x["level_start"].data_ptr(), self.proj.data_ptr(), self.proj.shape[2],
-                                                 self.ref.data_ptr(), 2, None, x["grad_out"].data_ptr(), self.N, self.S,
+                                                 self.ref.data_ptr(), 2, None, x["grad_out"].data_ptr(),
+                                                 self.out.data_ptr() if self.have_out else None, self.N, self.S,
                                                  self.M, self.D, self.L, self.Lq, self.P, self.gv.data_ptr(),
                                                  self.gp.data_ptr(), None, 1, self.hptr, self.ws.data_ptr(),
                                                  self.ws.numel(), torch.cuda.current_stream().cuda_stream)
@@ -243,9 +247,9 @@ class FusedCallBf16(FusedCall):
     def bwd(self):
         x = self.x
         self.scratch()
-        rc = self.lib.msda_fused_backward_ws_bf16(self.vb.data_ptr(), x["shapes"].data_ptr(), x["level_start"].data_ptr(),
+        rc = self.lib.msda_fused_backward_out_bf16(self.vb.data_ptr(), x["shapes"].data_ptr(), x["level_start"].data_ptr(),
                                                   self.proj.data_ptr(), self.proj.shape[2], self.ref.data_ptr(), 2, None,
-                                                  self.gob.data_ptr(), self.N, self.S, self.M, self.D, self.L, self.Lq,
+                                                  self.gob.data_ptr(), None, self.N, self.S, self.M, self.D, self.L, self.Lq,
                                                   self.P, self.gv.data_ptr(), self.gp.data_ptr(), None, 1, self.hptr,
                                                   self.ws.data_ptr(), self.ws.numel(),
                                                   torch.cuda.current_stream().cuda_stream)

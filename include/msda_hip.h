@@ -213,6 +213,29 @@ int msda_fused_backward_ws_bf16(const uint16_t *value, const int64_t *shapes_dev
                                 int zero_grad_value, const int64_t *shapes_host,
                                 void *workspace, size_t workspace_bytes, void *stream);
 
+/* The fused backward given the forward's OUTPUT of the same call (ABI 6; `fwd_out` (N, Lq, M*D), value's dtype; NULL:
+ * exactly msda_fused_backward_ws_*).  The softmax Jacobian's sum over a row's points, sum_j a_j dL/da_j, equals
+ * <grad_out_row, out_row> (out = sum_j a_j sampled_j), so a kernel that owns one pyramid level of a region can finish its
+ * logits' gradients without the other levels' results: for the encoder's calls (fp32, L*P = 16, 2-d reference points,
+ * 16-byte aligned projection rows) the default backward is then ONE kernel -- no attention-weight kernel in front, no
+ * Jacobian kernel behind, no workspace (150 -> ~135 us at the encoder shape).  An autograd function passes the tensor its
+ * forward returned (the next layer's Linear keeps it alive anyway).  Other calls ignore it. */
+int msda_fused_backward_out_f32(const float *value, const int64_t *shapes_dev, const int64_t *lstart_dev,
+                                const float *proj, int proj_stride, const float *ref, int ref_dim,
+                                const uint8_t *pad_mask, const float *grad_out, const float *fwd_out,
+                                int N, int S, int M, int D, int L, int Lq, int P,
+                                float *grad_value, float *grad_proj, float *grad_ref_part,
+                                int zero_grad_value, const int64_t *shapes_host,
+                                void *workspace, size_t workspace_bytes, void *stream);
+
+int msda_fused_backward_out_bf16(const uint16_t *value, const int64_t *shapes_dev, const int64_t *lstart_dev,
+                                 const float *proj, int proj_stride, const float *ref, int ref_dim,
+                                 const uint8_t *pad_mask, const uint16_t *grad_out, const uint16_t *fwd_out,
+                                 int N, int S, int M, int D, int L, int Lq, int P,
+                                 float *grad_value, float *grad_proj, float *grad_ref_part,
+                                 int zero_grad_value, const int64_t *shapes_host,
+                                 void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- kernel selection (round 4, records reworked in round 5 = ABI 5, per-site poll = ABI 6; memotr_amd/csrc/msda_select.h) ----
  * The cost of the reference kernels does not depend on where the sampling points land
  * (ms_deform_im2col_cuda.cuh:237-403); the windowed kernels here are fast for points near their query and slow
@@ -279,7 +302,7 @@ int msda_fused_points_f32(const int64_t *shapes_dev, const float *proj, int proj
  *       ahead, register budget), "fwd_win_place" (1 = every workgroup measures its window placement, rounds 3-4;
  *       0 = from the call site's running means), profiling switches; tools/fwd_win_sweep.py lists them;
  *       "fwd_head_major" (head-major block numbering of the gather
- *       kernel), "bwd_rows" / "bwd_rows_block" (the 32-lanes-per-row backward of decoder-shaped calls), "bwd_sorted" (1: selector
+ *       kernel), "bwd_rows" / "bwd_rows_block" (the 32-lanes-per-row backward of decoder-shaped calls), "bwd_soft" (1: the one-kernel fused backward when the forward's output is given; 0: the side kernels), "bwd_sorted" (1: selector
  *       level 2 builds grad_value by sort + gather when the caller gave scratch; 0: the rows kernel's float atomics),
  *       "bwd_wide_log2", "bwd_ablate" / "fwd_win_ablate" (profiling only: results are wrong by construction),
  *       "bwd_bins_margin" / "bwd_bins_margin_hi" / "bwd_bins_strip" (counting-sort backward, variant 12: window margins

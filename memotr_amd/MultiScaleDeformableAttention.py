@@ -269,8 +269,10 @@ def ms_deform_attn_fused_forward(value, spatial_shapes, level_start_index, proj,
 
 
 def ms_deform_attn_fused_backward(value, spatial_shapes, level_start_index, proj, reference_points, pad_mask,
-                                  grad_output, n_heads, n_points, need_ref_grad=False):
-    """-> [grad_value, grad_proj, grad_reference_points | None]."""
+                                  grad_output, n_heads, n_points, need_ref_grad=False, fwd_output=None):
+    """-> [grad_value, grad_proj, grad_reference_points | None].  ``fwd_output``: the tensor the fused forward of the same
+    call returned, when the caller still holds it (an autograd function does): the encoder's backward is then one kernel
+    (include/msda_hip.h, msda_fused_backward_out_*)."""
     named = [("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
              ("proj", proj), ("reference_points", reference_points), ("grad_output", grad_output)]
     if pad_mask is not None:
@@ -298,10 +300,14 @@ def ms_deform_attn_fused_backward(value, spatial_shapes, level_start_index, proj
         stream = _stream(value.device)
         ws_bytes = int(_lib.lib.msda_backward_workspace_bytes(1, N, S, M, D, L, Lq, P, value.element_size(), stream)) if hptr else 0
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=value.device) if ws_bytes else None
-        rc = getattr(_lib.lib, f"msda_fused_backward_ws_{suf}")(
+        if fwd_output is not None and not (fwd_output.is_contiguous() and fwd_output.dtype == value.dtype
+                                           and fwd_output.numel() == grad_output.numel()):
+            fwd_output = None
+        rc = getattr(_lib.lib, f"msda_fused_backward_out_{suf}")(
             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), proj.data_ptr(),
             proj.shape[2], reference_points.data_ptr(), reference_points.shape[3],
-            pad_mask.data_ptr() if pad_mask is not None else None, grad_output.data_ptr(), N, S, M, D, L, Lq, P,
+            pad_mask.data_ptr() if pad_mask is not None else None, grad_output.data_ptr(),
+            fwd_output.data_ptr() if fwd_output is not None else None, N, S, M, D, L, Lq, P,
             grad_value.data_ptr(), grad_proj.data_ptr(), ref_part.data_ptr() if ref_part is not None else None, 1,
             hptr, ws.data_ptr() if ws is not None else None, ws_bytes, stream)
         del keep, ws

@@ -25,6 +25,8 @@ _FUSED_BWD_ARGS = ([c_void_p] * 4 + [c_int, c_void_p, c_int, c_void_p, c_void_p]
 
 _FUSED_BWD_WS_ARGS = _FUSED_BWD_ARGS[:-1] + [c_void_p, ctypes.c_size_t, c_void_p]
 _BWD_WS_ARGS = _BWD_ARGS[:-1] + [c_void_p, ctypes.c_size_t, c_void_p]
+# ... + fwd_out after grad_out
+_FUSED_BWD_OUT_ARGS = _FUSED_BWD_WS_ARGS[:9] + [c_void_p] + _FUSED_BWD_WS_ARGS[9:]
 
 SYMBOLS = {
     "msda_abi_version": ([], c_int),
@@ -45,6 +47,8 @@ SYMBOLS = {
     "msda_fused_backward_bf16": (_FUSED_BWD_ARGS, c_int),
     "msda_fused_backward_ws_f32": (_FUSED_BWD_WS_ARGS, c_int),
     "msda_fused_backward_ws_bf16": (_FUSED_BWD_WS_ARGS, c_int),
+    "msda_fused_backward_out_f32": (_FUSED_BWD_OUT_ARGS, c_int),
+    "msda_fused_backward_out_bf16": (_FUSED_BWD_OUT_ARGS, c_int),
     "msda_fused_workspace_bytes": ([c_int] * 5, ctypes.c_size_t),
     "msda_sample_indices_f32": ([c_void_p, c_void_p] + [c_int] * 5 + [c_void_p] * 4, c_int),
     "msda_fused_points_f32": ([c_void_p, c_void_p, c_int, c_void_p, c_int] + [c_int] * 5 + [c_void_p] * 3, c_int),

@@ -52,6 +52,12 @@ struct BinsPlan {
     unsigned o_x, o_fl, o_st, o_rowp, o_rowa, o_rowq, o_cnt, o_start, o_comp, o_misc;
     int fused_loc;           // split fused backward: locations from the raw projection + reference points (src.proj / src.ref)
     int offsets_done;        // ... and final offset gradients (2-d reference points: d loc / d offset = 1 / (W, H))
+    // soft (round 6): no side kernel at all.  The item's lane forms its softmax weight from the row's sixteen logits
+    // (msda_common.h's arithmetic, the bits every other kernel forms) and the row phase writes the FINAL logit gradient
+    // a_t (ga_t - sum_j a_j ga_j): the sum over the row's points is <grad_out_row, out_row> -- out = sum_j a_j sampled_j
+    // is the forward's output, which the caller still holds -- so no level needs another level's results
+    int soft;
+    unsigned o_dot;          // soft: <grad_out_row, out_row> per staged row
 };
 
 __device__ __forceinline__ unsigned bins_incl_scan(unsigned x, int lane) {
@@ -107,11 +113,12 @@ __device__ __forceinline__ int bins_mul24(int a, int b) { return __mul24(a, b); 
         (x) += MSDA_DPP((x), 0x4E); /* quad_perm [2,3,0,1] */     \
     } while (0)
 
-template <int NI, typename TV>
+template <int NI, typename TV, bool SOFT = false>
 __global__ __launch_bounds__(kTileThreads, MSDA_BINS_WGS) void msda_bwd_d32_bins(
     const TV *__restrict__ value, const int64_t *__restrict__ lstart, const PointSrc src,
     const TV *__restrict__ grad_out, float *__restrict__ grad_value, float *__restrict__ grad_loc,
-    float *__restrict__ grad_attn, float *__restrict__ grad_proj, const TilePlan pl, const BinsPlan bp) {
+    float *__restrict__ grad_attn, float *__restrict__ grad_proj, const TilePlan pl, const BinsPlan bp,
+    const TV *__restrict__ fwd_out = nullptr) {
     constexpr int D = 32;
     constexpr unsigned ROWB = 32u * (unsigned)sizeof(TV);
     constexpr bool kB16 = sizeof(TV) == 2;
@@ -186,7 +193,7 @@ __global__ __launch_bounds__(kTileThreads, MSDA_BINS_WGS) void msda_bwd_d32_bins
     //      not exist read row 0 and are zeroed afterwards: no branch stands between the requests ----
     constexpr int kStageIters = ((kTileMaxRows + 1) * 8 + kTileThreads - 1) / kTileThreads;
     const int n_stage = (rows + 1) * 8;
-    f32x4 st_g[kStageIters];
+    f32x4 st_g[kStageIters], st_o[kStageIters];
     bool st_ok[kStageIters];
 #pragma unroll
     for (int i = 0; i < kStageIters; ++i) {
@@ -195,14 +202,17 @@ __global__ __launch_bounds__(kTileThreads, MSDA_BINS_WGS) void msda_bwd_d32_bins
         const unsigned pm = ROWP[r];
         st_ok[i] = pm != 0xffffffffu;
         st_g[i] = bins_load_g4<TV>(grad_out + ((st_ok[i] ? pm : 0u) * (unsigned)D + (unsigned)((idx & 7) * 4)));
+        st_o[i] = SOFT ? bins_load_g4<TV>(fwd_out + ((st_ok[i] ? pm : 0u) * (unsigned)D + (unsigned)((idx & 7) * 4)))
+                          : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     int it_r[NI];
     bool it_live[NI], it_gate[NI];
     int it_h0[NI], it_w0[NI];
-    float it_lh[NI], it_lw[NI], it_a[NI];
+    float it_lh[NI], it_lw[NI], it_a[NI], it_araw[NI];
     {
         f32x2 raw[NI], r01[NI], r23[NI];
         float araw[NI];
+        f32x4 lg4[NI];
         bool okk[NI];
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
@@ -225,7 +235,14 @@ __global__ __launch_bounds__(kTileThreads, MSDA_BINS_WGS) void msda_bwd_d32_bins
             raw[k] = *reinterpret_cast<const f32x2 *>(p_raw);
             r01[k] = *reinterpret_cast<const f32x2 *>(bp.fused_loc ? rp : p_raw);
             r23[k] = *reinterpret_cast<const f32x2 *>(bp.fused_loc && src.ref_dim != 2 ? rp + 2 : p_raw);
-            araw[k] = src.attn[pmc * (unsigned)LP + t];
+            if (SOFT) {          // (L * P = 16: the row's logits.  P = 4: the row's four items of this level are an aligned
+                                 //  quad of lanes -- each takes a quarter of the logits, the softmax is shared by DPP)
+                const f32x4 *lp = reinterpret_cast<const f32x4 *>(src.proj + (qrow * (unsigned)src.proj_stride + (unsigned)src.n_off + (unsigned)(m * 16)));
+                lg4[k] = lp[p];
+                araw[k] = 0.f;
+            } else {
+                araw[k] = src.attn[pmc * (unsigned)LP + t];
+            }
         }
 #pragma unroll
         for (int i = 0; i < kStageIters; ++i) {
@@ -233,6 +250,40 @@ __global__ __launch_bounds__(kTileThreads, MSDA_BINS_WGS) void msda_bwd_d32_bins
             if (idx < n_stage)
                 *reinterpret_cast<f32x4 *>(G + (unsigned)(idx >> 3) * kBinsGRow + (unsigned)(idx & 7) * 16u) =
                     st_ok[i] ? st_g[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (SOFT) {          // <grad_out_row, out_row>: eight consecutive lanes hold a row's eight chunks
+                const f32x4 pr = st_g[i] * st_o[i];
+                float d8 = (pr.x + pr.y) + (pr.z + pr.w);
+                d8 = row_sum<8>(d8);
+                if (idx < n_stage && (idx & 7) == 0)
+                    reinterpret_cast<float *>(s_dyn + bp.o_dot)[idx >> 3] = st_ok[i] ? d8 : 0.f;
+            }
+        }
+        if (SOFT) {     // (P = 4, L = 4) the items' softmax weights (msda_common.h: sm_exp / sm_rcp, adjacent-pair tree)
+#pragma unroll
+            for (int k = 0; k < NI; ++k) {
+                // lane p of the quad holds logits 4 p .. 4 p + 3 of its row: Q_p = (e0 + e1) + (e2 + e3), the sum is
+                // (Q_0 + Q_1) + (Q_2 + Q_3) by the quad butterflies; this item's point is l P + p = logit p of lane l
+                const f32x4 g4 = lg4[k];
+                float mx = fmaxf(fmaxf(g4.x, g4.y), fmaxf(g4.z, g4.w));
+                mx = fmaxf(mx, MSDA_DPP(mx, 0xB1));
+                mx = fmaxf(mx, MSDA_DPP(mx, 0x4E));
+                const float e0 = sm_exp(g4.x, mx), e1 = sm_exp(g4.y, mx), e2 = sm_exp(g4.z, mx), e3 = sm_exp(g4.w, mx);
+                float sum = (e0 + e1) + (e2 + e3);
+                sum += MSDA_DPP(sum, 0xB1);
+                sum += MSDA_DPP(sum, 0x4E);
+                const float rs = sm_rcp(sum);
+                // quad lane l's four values, then component p of them
+                const unsigned ql = (unsigned)l;
+                auto bcast = [&](float v) {
+                    const float b0 = MSDA_DPP(v, 0x00), b1 = MSDA_DPP(v, 0x55), b2 = MSDA_DPP(v, 0xAA), b3 = MSDA_DPP(v, 0xFF);
+                    return ql == 0u ? b0 : (ql == 1u ? b1 : (ql == 2u ? b2 : b3));
+                };
+                const float c0 = bcast(e0), c1 = bcast(e1), c2 = bcast(e2), c3 = bcast(e3);
+                const int it = tid + k * kTileThreads;
+                const int itc = it < n_items ? it : 0;
+                const int p = itc & 3;
+                araw[k] = (p == 0 ? c0 : (p == 1 ? c1 : (p == 2 ? c2 : c3))) * rs;
+            }
         }
         float sx = 0.f, sy = 0.f, cn = 0.f;
 #pragma unroll
@@ -250,6 +301,7 @@ __global__ __launch_bounds__(kTileThreads, MSDA_BINS_WGS) void msda_bwd_d32_bins
             it_lh[k] = gate ? s.lh : 0.f;
             it_lw[k] = gate ? s.lw : 0.f;
             it_a[k] = gate ? a : 0.f;
+            it_araw[k] = a;                        // (soft: the softmax Jacobian wants the weight of gated-off points too)
             if (gate) {
                 sx += (float)s.w_low + s.lw;
                 sy += (float)s.h_low + s.lh;
@@ -312,7 +364,7 @@ __global__ __launch_bounds__(kTileThreads, MSDA_BINS_WGS) void msda_bwd_d32_bins
         const float lh = it_lh[k], lw = it_lw[k], a = it_a[k];
         const float hh = 1.f - lh, hw = 1.f - lw;
         const float wk[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
-        unsigned fl = it_live[k] ? 0x100u : 0u;
+        unsigned fl = (it_live[k] ? 0x100u : 0u) | (it_gate[k] ? 0x200u : 0u);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             cr[k][c] = 0xffffffffu;
@@ -344,7 +396,7 @@ __global__ __launch_bounds__(kTileThreads, MSDA_BINS_WGS) void msda_bwd_d32_bins
             rec.x = (((unsigned)b * (unsigned)pl.S + (unsigned)(lstart_l + bins_mul24(h0, W) + w0)) * (unsigned)M + (unsigned)m) * ROWB;
             rec.y = __float_as_uint(lh);
             rec.z = __float_as_uint(lw);
-            rec.w = __float_as_uint(a);
+            rec.w = __float_as_uint(it_araw[k]);
             R[it] = rec;
             FL[it] = fl;
         }
@@ -450,7 +502,8 @@ __global__ __launch_bounds__(kTileThreads, MSDA_BINS_WGS) void msda_bwd_d32_bins
                 d[k] = bins_dot8(ga, va[k], gb, vb[k]);
                 MSDA_QUAD_SUM(d[k]);
             }
-            const float lh = __uint_as_float(rec.y), lw = __uint_as_float(rec.z), a = __uint_as_float(rec.w);
+            const float lh = __uint_as_float(rec.y), lw = __uint_as_float(rec.z), a_raw = __uint_as_float(rec.w);
+            const float a = (fl & 0x200u) ? a_raw : 0.f;
             const float hh = 1.f - lh, hw = 1.f - lw;
             const float wk[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
             // d/dx = a (hh (d1 - d0) + lh (d3 - d2)) W,  d/dy = a (hw (d2 - d0) + lw (d3 - d1)) H: one expression, the
@@ -458,7 +511,9 @@ __global__ __launch_bounds__(kTileThreads, MSDA_BINS_WGS) void msda_bwd_d32_bins
             const float pp = role_y ? hw : hh, qq = role_y ? lw : lh;
             const float d_a = role_y ? d[2] : d[1], d_c = role_y ? d[1] : d[2];
             const float r_loc = (a * size_r) * (pp * (d_a - d[0]) + qq * (d[3] - d_c));
-            const float r_att = wk[0] * d[0] + wk[1] * d[1] + wk[2] * d[2] + wk[3] * d[3];
+            float r_att = wk[0] * d[0] + wk[1] * d[1] + wk[2] * d[2] + wk[3] * d[3];
+            // soft: the final logit gradient a_t (ga_t - <grad_out_row, out_row>)
+            if (SOFT) r_att = a_raw * (r_att - reinterpret_cast<const float *>(s_dyn + bp.o_dot)[r]);
             const float outv = role_a ? r_att : r_loc;
             if ((fl & 0x100u) && j4 < 3) dst_base[(rowa << sh_row) + col + ((unsigned)p << sh_p)] = outv;
             if (!(pl.ablate & 2) && __builtin_amdgcn_ballot_w64((fl & 0xf0u) != 0u) != 0ull) {   // rare: corners outside the window

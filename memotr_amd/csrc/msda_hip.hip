@@ -104,6 +104,7 @@ std::atomic<int> opt_sel_level{-1};          // >= 0: pin the selector's level (
 std::atomic<int> opt_sel_up0{5}, opt_sel_up1{2}, opt_sel_down1{2}, opt_sel_down2{1};
 std::atomic<int> opt_sel_up1_rows{100}, opt_sel_down2_rows{60};
 std::atomic<int> opt_sel_fwd_up{50}, opt_sel_fwd_down{20};                                  // forward thresholds  // counting-sort backward: window margin (the window is only a table of counters)
+std::atomic<int> opt_bwd_soft{1};         // fused counting-sort backward: softmax + its Jacobian in the kernel when the caller passes the forward's output
 std::atomic<int> opt_bwd_sorted{1};       // selector level 2: grad_value by sort + gather when the caller gave scratch (0: the rows kernel)
 std::atomic<int> opt_bwd_sort_qc{0}, opt_bwd_sort_emult{0};   // sorted backward: queries per dots workgroup / chunks per emit workgroup (0: auto)
 std::atomic<int> opt_bwd_rows{1};         // 0: few-query D = 32 calls keep the generic row-per-block backward
@@ -248,6 +249,9 @@ bool make_bins_plan(BinsPlan &bp, const TilePlan &pl, int ni, size_t &lds) {
     o += (size_t)C * 64 * 4;
     bp.o_misc = (unsigned)o;
     o += 16 + (size_t)(kTileThreads / 64) * 16 * 4 + 16;
+    o = up16(o);
+    bp.o_dot = (unsigned)o;                     // (soft) <grad_out_row, out_row> per staged row
+    o += up16((size_t)(pl.rows + 1) * 4);
     lds = o;
     return lds <= 64 * 1024;
 }
@@ -686,8 +690,13 @@ int backward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart,
                   const FusedArgs &fa, const TV *grad_out, int N, int S, int M, int D, int L, int Lq, int P,
                   TG *grad_value, TC *grad_loc, TC *grad_attn, float *grad_proj, float *grad_ref_part,
                   int zero_grad_value, const int64_t *shapes_host, hipStream_t stream, float *workspace = nullptr,
-                  size_t workspace_bytes = 0) {
+                  size_t workspace_bytes = 0, const TV *fwd_out = nullptr) {
     const bool fused = fa.proj != nullptr;
+    // `fwd_out` (round 6): the forward's output of the same call, when the caller still holds it.  sum_j a_j ga_j of the
+    // softmax Jacobian IS <grad_out_row, out_row>, so with it the counting-sort backward needs no side kernel
+    const bool soft_ok = fused && fwd_out != nullptr && sizeof(TV) == 4 && L * P == 16 && fa.ref_dim == 2 &&
+                         (fa.proj_stride % 4) == 0 && ((2 * M * L * P) % 4) == 0 && (((uintptr_t)fa.proj) & 15) == 0 &&
+                         L == 4 && P == 4 && grad_ref_part == nullptr && opt_bwd_soft.load() != 0;
     int rc = fused ? check_dims(value, shapes, lstart, fa.proj, fa.ref, grad_out, N, S, M, D, L, Lq, P)
                    : check_dims(value, shapes, lstart, loc, attn, grad_out, N, S, M, D, L, Lq, P);
     if (rc) return rc;
@@ -854,8 +863,9 @@ int backward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart,
     if (variant >= 2 && !can_tile) variant = 1;
     if constexpr (kD32Type) {
         if (variant == 12) {        // counting-sort gather (msda_bwd_bins.h); the one-kernel fused form stays with tile_lv
-            const bool will_split = fa.proj != nullptr && opt_bwd_split.load() != 0 && workspace != nullptr &&
-                                    workspace_bytes >= (size_t)N * Lq * M * L * P * 3 * sizeof(float);
+            const bool will_split = fa.proj != nullptr && opt_bwd_split.load() != 0 &&
+                                    (soft_ok || (workspace != nullptr &&
+                                                 workspace_bytes >= (size_t)N * Lq * M * L * P * 3 * sizeof(float)));
             if (P > 8 || (fa.proj != nullptr && !will_split)) variant = 10;
         }
         if (variant == 10 || variant == 12) {       // one pyramid level per workgroup
@@ -895,8 +905,9 @@ int backward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart,
                 // Split fused backward (needs the caller's workspace): materialise the prologue once -- the tiled
                 // kernel would otherwise redo the row softmax and the location arithmetic in each of its L
                 // workgroups per region -- run the plain kernel on it, finish the Jacobians in place.
-                const bool split = fused && opt_bwd_split.load() != 0 && workspace != nullptr &&
-                                   workspace_bytes >= (size_t)n_rows * L * P * 3 * sizeof(float);
+                const bool soft = soft_ok && variant == 12 && opt_bwd_split.load() != 0;      // (no workspace needed)
+                const bool split = fused && opt_bwd_split.load() != 0 &&
+                                   (soft || (workspace != nullptr && workspace_bytes >= (size_t)n_rows * L * P * 3 * sizeof(float)));
                 // The counting-sort kernel computes the locations itself (one lane per point: the arithmetic is
                 // cheap there) and, for 2-d reference points, writes the final offset gradients: the two side
                 // kernels then move a third of the bytes (attention weights out, the softmax Jacobian in place).
@@ -905,7 +916,8 @@ int backward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart,
                 bp.fused_loc = slim ? 1 : 0;
                 bp.offsets_done = offsets_done;
                 bool rows16 = false;
-                if (split) {
+                bp.soft = soft ? 1 : 0;
+                if (split && !soft) {
                     float *loc_ws = workspace, *attn_ws = workspace + (size_t)n_rows * L * P * 2;
                     // one lane per row (16 points as four 16-byte accesses): the slim path's two side kernels
                     rows16 = slim && L * P == 16 && (fa.proj_stride % 4) == 0 && (src.n_off % 4) == 0 &&
@@ -941,9 +953,21 @@ int backward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart,
         g_kernel = NAME;                                                                                             \
         hipLaunchKernelGGL((msda_bwd_d32_bins<NI, TV>), dim3(grid), dim3(kTileThreads), lds, stream, value, lstart,  \
                            src, grad_out, (float *)grad_value, (float *)grad_loc, (float *)grad_attn, grad_proj, pl, \
-                           bp);                                                                                      \
+                           bp, (const TV *)nullptr);                                                                 \
     } while (0)
-                if (variant == 12) {
+                if (variant == 12 && soft) {       // (fp32, L = P = 4) everything of the fused backward in the one kernel
+                    if constexpr (sizeof(TV) == 4) {
+                        g_kernel = bins_ni == 2 ? "msda_bwd_d32_tile_bins<split,soft>" : "msda_bwd_d32_tile_bins<3,split,soft>";
+                        if (bins_ni == 2)
+                            hipLaunchKernelGGL((msda_bwd_d32_bins<2, TV, true>), dim3(grid), dim3(kTileThreads), lds, stream, value,
+                                               lstart, src, grad_out, (float *)grad_value, (float *)grad_loc, (float *)grad_attn,
+                                               grad_proj, pl, bp, fwd_out);
+                        else
+                            hipLaunchKernelGGL((msda_bwd_d32_bins<3, TV, true>), dim3(grid), dim3(kTileThreads), lds, stream, value,
+                                               lstart, src, grad_out, (float *)grad_value, (float *)grad_loc, (float *)grad_attn,
+                                               grad_proj, pl, bp, fwd_out);
+                    }
+                } else if (variant == 12) {
                     if (bins_ni == 2) MSDA_LAUNCH_BINS(2, split ? (b16 ? "msda_bwd_d32_tile_bins<bf16,split>" : "msda_bwd_d32_tile_bins<split>")
                                                                 : (b16 ? "msda_bwd_d32_tile_bins<bf16>" : "msda_bwd_d32_tile_bins"));
                     else MSDA_LAUNCH_BINS(3, split ? (b16 ? "msda_bwd_d32_tile_bins<3,bf16,split>" : "msda_bwd_d32_tile_bins<3,split>")
@@ -956,7 +980,7 @@ int backward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart,
 #undef MSDA_LAUNCH_LV
 #undef MSDA_LAUNCH_BINS
                 rc = check_launch(g_kernel);
-                if (rc || !fused) return rc;
+                if (rc || !fused || soft) return rc;
                 const int jgrid = clamp_grid((n_rows * 8 + 255) / 256, 16);
                 if (split) {
                     if (rows16 && offsets_done) {
@@ -1239,6 +1263,37 @@ int msda_fused_backward_bf16(const uint16_t *value, const int64_t *shapes_dev, c
                                                (hipStream_t)stream);
 }
 
+// The fused backward given the forward's output of the same call (ABI 6): see backward_impl -- with it the default
+// backward of the encoder's self-attention is ONE kernel (no attention-weight kernel in front, no Jacobian kernel behind).
+int msda_fused_backward_out_f32(const float *value, const int64_t *shapes_dev, const int64_t *lstart_dev,
+                                const float *proj, int proj_stride, const float *ref, int ref_dim,
+                                const uint8_t *pad_mask, const float *grad_out, const float *fwd_out, int N, int S, int M,
+                                int D, int L, int Lq, int P, float *grad_value, float *grad_proj, float *grad_ref_part,
+                                int zero_grad_value, const int64_t *shapes_host, void *workspace, size_t workspace_bytes,
+                                void *stream) {
+    if (!proj) return fail(MSDA_EINVAL, "null pointer argument");
+    return backward_impl<float, float, float>(value, shapes_dev, lstart_dev, nullptr, nullptr,
+                                              fused_args(proj, proj_stride, ref, ref_dim, pad_mask), grad_out, N, S, M,
+                                              D, L, Lq, P, grad_value, nullptr, nullptr, grad_proj, grad_ref_part,
+                                              zero_grad_value, shapes_host, (hipStream_t)stream, (float *)workspace,
+                                              workspace_bytes, fwd_out);
+}
+
+int msda_fused_backward_out_bf16(const uint16_t *value, const int64_t *shapes_dev, const int64_t *lstart_dev,
+                                 const float *proj, int proj_stride, const float *ref, int ref_dim,
+                                 const uint8_t *pad_mask, const uint16_t *grad_out, const uint16_t *fwd_out, int N, int S,
+                                 int M, int D, int L, int Lq, int P, float *grad_value, float *grad_proj,
+                                 float *grad_ref_part, int zero_grad_value, const int64_t *shapes_host, void *workspace,
+                                 size_t workspace_bytes, void *stream) {
+    if (!proj) return fail(MSDA_EINVAL, "null pointer argument");
+    return backward_impl<bf16_t, float, float>((const bf16_t *)value, shapes_dev, lstart_dev, nullptr, nullptr,
+                                               fused_args(proj, proj_stride, ref, ref_dim, pad_mask),
+                                               (const bf16_t *)grad_out, N, S, M, D, L, Lq, P, grad_value, nullptr,
+                                               nullptr, grad_proj, grad_ref_part, zero_grad_value, shapes_host,
+                                               (hipStream_t)stream, (float *)workspace, workspace_bytes,
+                                               (const bf16_t *)fwd_out);
+}
+
 size_t msda_fused_workspace_bytes(int N, int Lq, int M, int L, int P) {
     if (N < 0 || Lq < 0 || M <= 0 || L <= 0 || P <= 0) return 0;
     return (size_t)N * Lq * M * L * P * 3 * sizeof(float);
@@ -1371,6 +1426,7 @@ static std::atomic<int> *find_opt(const char *key) {
     if (!strcmp(key, "bwd_bins_strip")) return &opt_bwd_bins_strip;
     if (!strcmp(key, "bwd_rows")) return &opt_bwd_rows;
     if (!strcmp(key, "bwd_sorted")) return &opt_bwd_sorted;
+    if (!strcmp(key, "bwd_soft")) return &opt_bwd_soft;
     if (!strcmp(key, "bwd_sort_qc")) return &opt_bwd_sort_qc;
     if (!strcmp(key, "bwd_sort_emult")) return &opt_bwd_sort_emult;
     if (!strcmp(key, "bwd_rows_block")) return &opt_bwd_rows_block;

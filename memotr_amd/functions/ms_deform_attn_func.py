@@ -62,20 +62,23 @@ class MSDeformAttnFusedFunction(Function):
         ctx.shapes_host = getattr(value_spatial_shapes, "_msda_host", None)
         output = MSDA.ms_deform_attn_fused_forward(value, value_spatial_shapes, value_level_start_index, proj,
                                                    reference_points, padding_mask, ctx.n_heads, ctx.n_points)
+        # (the output too: sum_j a_j dL/da_j of the softmax Jacobian is <grad_output_row, output_row>, which lets the
+        #  backward finish in one kernel -- include/msda_hip.h, msda_fused_backward_out_*; the consumer's Linear keeps the
+        #  tensor alive for its weight gradient anyway)
         ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, proj, reference_points,
-                              padding_mask)
+                              padding_mask, output)
         return output
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_output):
-        value, shapes, level_start, proj, reference_points, padding_mask = ctx.saved_tensors
+        value, shapes, level_start, proj, reference_points, padding_mask, output = ctx.saved_tensors
         if ctx.shapes_host is not None and getattr(shapes, "_msda_host", None) is None:
             shapes._msda_host = (ctx.shapes_host[0], shapes._version)
         MSDA.set_call_site(ctx.site)
         grad_value, grad_proj, grad_ref = MSDA.ms_deform_attn_fused_backward(
             value, shapes, level_start, proj, reference_points, padding_mask, grad_output.contiguous(), ctx.n_heads,
-            ctx.n_points, need_ref_grad=ctx.needs_input_grad[4])
+            ctx.n_points, need_ref_grad=ctx.needs_input_grad[4], fwd_output=output)
         MSDA.set_call_site(0)
         if ctx.zero_rows is not None and ctx.zero_rows.numel():
             grad_value.view(-1, grad_value.shape[-2] * grad_value.shape[-1]).index_fill_(0, ctx.zero_rows, 0)

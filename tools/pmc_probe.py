@@ -23,6 +23,8 @@ for w in words:
     if "=" in w:
         k, v = w.split("=")
         _lib.set_option(k, int(v, 0))
+if op == "bwd" and hasattr(call, "have_out"):
+    call.fwd()        # (the backward of the model's call gets the forward's output)
 fn = call.fwd if op == "fwd" else call.bwd
 for _ in range(6):
     fn()
