@@ -2,7 +2,7 @@
 # the bench lines kept under profiles/ per round (run on the GPU box from the repo root):  tools/bench_lines.sh [bdd|rest|all] [r04]
 # (REFIND=1: MIOpen's exhaustive find into a scratch db -- ~9 GPU-minutes for the BDD100K pyramid; the default uses the
 #  find-db that travels with the package, memotr_amd/tuning/miopen_db, which bench.py points MIOpen at)
-R=${2:-r05}
+R=${2:-r06}
 mkdir -p gpurun_out/lines gpurun_out/miopen/db gpurun_out/miopen/cache
 if [ "${REFIND:-0}" = "1" ]; then
   export MIOPEN_USER_DB_PATH=$PWD/gpurun_out/miopen/db
