@@ -679,8 +679,11 @@ def main():
     rank, _, world = init_dist(args.gpus)
     # torch sizes its CPU thread pool from the machine, not from the container's CFS quota; the spinning workers then
     # get the whole process throttled (memotr_amd/utils/host.py: 30.7 -> 95 frames/s on the online-tracking loop)
-    from memotr_amd.utils.host import respect_cpu_quota
+    from memotr_amd.utils.host import pin_near_gpu, respect_cpu_quota
     respect_cpu_quota(processes=int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+    # ... and from two CPUs next to the GPU's PCIe root, a different pair per local rank (memotr_amd/utils/host.py: +2 % on
+    # the train step of a two-socket box)
+    pinned = pin_near_gpu(torch.cuda.current_device(), int(os.environ.get("LOCAL_RANK", "0")))
     if args.workload == "msda":
         result = run_msda(args, rank, world)
     elif args.workload == "infer":
@@ -721,6 +724,7 @@ def main():
     else:
         raise SystemExit(f"unknown workload {args.workload}")
     if rank == 0:
+        result["pinned_cpus"] = pinned
         print(json.dumps(result), flush=True)
     if world > 1:   # rank 0 did extra kernel timing: leave together
         import torch.distributed as dist

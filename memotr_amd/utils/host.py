@@ -47,3 +47,51 @@ def respect_cpu_quota(reserve: float = 0.5, processes: int = 1) -> int:
     if torch.get_num_threads() > want:
         torch.set_num_threads(want)
     return torch.get_num_threads()
+
+
+def _parse_cpulist(text: str):
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def pin_near_gpu(device_index: int = 0, local_rank: int = 0, n_cpus: int = 2):
+    """Pin this process (its launch thread, autograd's thread and whatever it starts later) to ``n_cpus`` CPUs of the NUMA
+    node the GPU hangs off, a different pair per local rank.
+
+    Why (round 6, ``profiles/r06_host_cpu_probe.txt``, the clip train step on a 2-socket EPYC 9575F box, GPU on node 0):
+    left to the scheduler the process floats over 256 hardware threads of two sockets -- 38.99 frames/s; ``taskset -c 0,1``
+    39.78, one CPU 39.62, the SMT pair (0, 128) 39.72, four or eight CPUs 39.1-39.2, two CPUs of the OTHER socket 38.88, a
+    pair split across the sockets 38.06.  The step issues ~9 k launches from two threads that hand work to the HIP
+    runtime's own threads through shared memory: keeping them on one L3 next to the GPU's PCIe root is worth 2 %, and at
+    eight ranks per node it is what keeps a rank's threads off the other ranks' cores.  ``MEMOTR_PIN_CPUS=0`` switches it
+    off; an affinity mask somebody already narrowed (<= 8 CPUs) is left alone.  Returns the CPUs chosen, or None."""
+    if os.environ.get("MEMOTR_PIN_CPUS", "1") == "0" or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        if len(allowed) <= 8:
+            return None
+        import torch
+        p = torch.cuda.get_device_properties(device_index)
+        bdf = "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
+        with open(f"/sys/bus/pci/devices/{bdf}/local_cpulist") as f:
+            local = [c for c in _parse_cpulist(f.read()) if c in set(allowed)]
+        if len(local) < n_cpus:
+            return None
+        start = (local_rank * n_cpus) % (len(local) - n_cpus + 1)
+        chosen = local[start:start + n_cpus]
+        # every thread that exists already (the HIP runtime's, torch's pool: the device had to be initialised to be asked
+        # where it sits) and, through inheritance, every later one
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                os.sched_setaffinity(int(tid), chosen)
+            except OSError:
+                pass
+        return chosen
+    except Exception:       # (no sysfs, an exotic topology, a sandbox that forbids it: speed only)
+        return None
