@@ -17,7 +17,7 @@ from conftest import golden_cases, load_golden
 pytestmark = pytest.mark.gpu
 
 FWD_VARIANTS = [0, 1, 3]
-BWD_VARIANTS = [0, 1, 10, 12]
+BWD_VARIANTS = [0, 1, 10, 12, 13]       # 13 (round 6): grad_value by global sort + gather (D = 32 fp32 / bf16; else falls back)
 
 
 @pytest.fixture(scope="module")
@@ -248,8 +248,17 @@ def test_region_tiled_kernels_match_oracle(msda, hip_lib, case, margin):
                 np.testing.assert_allclose(gv, rgv, err_msg=f"bins level {level} strip {strip}", **tol(np.float32, 8))
                 np.testing.assert_allclose(gl, rgl, **tol(np.float32, 100))
                 np.testing.assert_allclose(ga, rga, **tol(np.float32, 40))
+        # 13 (round 6): grad_value by global sort + gather through the wrapper's scratch -- no windows, no float atomics
+        hip_lib.set_option("sel_level", -1)
+        hip_lib.set_option("bwd_variant", 13)
+        gv, gl, ga = run_bwd(msda, g)
+        assert hip_lib.last_kernel() == "msda_bwd_d32_sorted", hip_lib.last_kernel()
+        np.testing.assert_allclose(gv, rgv, err_msg="sorted", **tol(np.float32, 8))
+        np.testing.assert_allclose(gl, rgl, **tol(np.float32, 100))
+        np.testing.assert_allclose(ga, rga, **tol(np.float32, 40))
     finally:
         hip_lib.set_option("fwd_variant", 0)
+        hip_lib.set_option("bwd_variant", 0)
         hip_lib.set_option("bwd_tile_margin", 4)
         hip_lib.set_option("bwd_bins_margin", 6)
         hip_lib.set_option("bwd_bins_margin_hi", 9)
