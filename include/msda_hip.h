@@ -298,7 +298,8 @@ int msda_fused_points_f32(const int64_t *shapes_dev, const float *proj, int proj
  *       "fwd_win_auto" (1 = fp32 self-attention over the pyramid takes the windowed forward, variant 12; 0 = the
  *       gather kernel), "fwd_win_rlog" / "fwd_win_rlogx" / "fwd_win_block" (log2 of the region height / width on the
  *       finest level and threads per workgroup; 0 = auto: 16 x 16 pixels, 512 threads), "fwd_win_margins" (per level as
- *       0xL3L2L1L0), "fwd_win_l0" (first windowed level), "fwd_win_early" / "fwd_win_wps" (level-0 rows requested
+ *       0xL3L2L1L0), "fwd_win_l0" (first windowed level), "fwd_win_bf16" (1: bf16 rows take the
+ *       windowed forward too; measured slower than the gather kernel, default 0), "fwd_win_early" / "fwd_win_wps" (level-0 rows requested
  *       ahead, register budget), "fwd_win_place" (1 = every workgroup measures its window placement, rounds 3-4;
  *       0 = from the call site's running means), profiling switches; tools/fwd_win_sweep.py lists them;
  *       "fwd_head_major" (head-major block numbering of the gather

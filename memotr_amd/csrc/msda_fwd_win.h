@@ -50,7 +50,8 @@ struct WinPlan {
     int wmagic[kWinMaxL];          // (x * magic) >> 16 == x / ww for x < ww * wh
     int wbase[kWinMaxL + 1];       // first window pixel of level l; [kWinMaxL] = all window pixels = the zero row
     float ratw[kWinMaxL][kWinMaxL], rath[kWinMaxL][kWinMaxL];   // [lq][l] = W_l / W_lq, H_l / H_lq
-    int groups;                    // 8-pixel fill groups (window pixels + the zero row, rounded up)
+    int groups;                    // 1-KiB fill groups (8 fp32 / 16 bf16 pixels; window pixels + the zero row, rounded up)
+    int gplog;                     // log2 of the pixels per fill group
     int wgroups_max;               // ... of the largest window (a masked call needs <= 8 per wavefront)
     float rcpH[kWinMaxL], rcpW[kWinMaxL], rcpP;   // correctly rounded 1/H, 1/W, 1/P (div_small)
     unsigned value_bytes;
@@ -218,16 +219,33 @@ __device__ __forceinline__ float row16_sum(float x) {
     return x;
 }
 
+// four consecutive channels of a window row in LDS as floats: fp32 rows (16 bytes) or bf16 rows (8 bytes)
+template <typename TV>
+__device__ __forceinline__ f32x4 win_lds_ch4(const unsigned char *p);
+template <>
+__device__ __forceinline__ f32x4 win_lds_ch4<float>(const unsigned char *p) { return *reinterpret_cast<const f32x4 *>(p); }
+template <>
+__device__ __forceinline__ f32x4 win_lds_ch4<bf16_t>(const unsigned char *p) {
+    const u32x2 u = *reinterpret_cast<const u32x2 *>(p);
+    return f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                 __uint_as_float(u.y & 0xffff0000u)};
+}
+__device__ __forceinline__ void win_store4(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
+__device__ __forceinline__ void win_store4(bf16_t *p, f32x4 v) {
+    *reinterpret_cast<u32x2 *>(p) = u32x2{bf16_bits_rne(v.x) | (bf16_bits_rne(v.y) << 16), bf16_bits_rne(v.z) | (bf16_bits_rne(v.w) << 16)};
+}
+
 // One point whose record may be an LDS address (inside its window) or a `value` byte offset (bit 0 of word 1 set),
 // lane by lane: loads and FMAs in one place.
+template <typename TV>
 __device__ __forceinline__ f32x4 win_mixed_point(const u32x4 r, const unsigned char *s_dyn, unsigned zero_off,
                                                  __amdgpu_buffer_rsrc_t vr, unsigned sub16, f32x4 acc) {
     const bool g = (r.y & 1u) != 0u;
-    f32x4 v0 = *reinterpret_cast<const f32x4 *>(s_dyn + ((g ? zero_off : r.y) + sub16));
-    f32x4 v1 = *reinterpret_cast<const f32x4 *>(s_dyn + ((g ? zero_off : r.w) + sub16));
+    f32x4 v0 = win_lds_ch4<TV>(s_dyn + ((g ? zero_off : r.y) + sub16));
+    f32x4 v1 = win_lds_ch4<TV>(s_dyn + ((g ? zero_off : r.w) + sub16));
     if (g) {
-        v0 = buf_load_f4(vr, (r.y & ~1u) + sub16);
-        v1 = buf_load_f4(vr, r.w + sub16);
+        v0 = buf_load_ch4<TV>(vr, (r.y & ~1u) + sub16);
+        v1 = buf_load_ch4<TV>(vr, r.w + sub16);
     }
     acc += __uint_as_float(r.x) * v0;
     acc += __uint_as_float(r.z) * v1;
@@ -257,10 +275,16 @@ __device__ __forceinline__ void win_place(WinTables &tb, const WinPlan &pl, int 
 // after them (their latency hides behind the LDS phase at the price of 10 registers per point held across it).
 // TRACE: the timeline build (tools/fwd_win_timeline.py) -- s_memtime stamps at the phase boundaries; the production
 // instantiations hold none of it (as a run-time test the stamps cost 1.1 us per launch, round 4).
-template <bool FUSED, int WPS, int NE, bool TRACE = false>
-__global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(const float *__restrict__ value,
+// TV: float, or bf16_t (round 6: 64-byte rows -- windows of half the bytes, 16 pixels per fill instruction, 8-byte LDS
+// reads widened in registers; locations, weights and accumulation stay fp32)
+template <typename TV, bool FUSED, int WPS, int NE, bool TRACE = false>
+__global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(const TV *__restrict__ value,
                                                            const int64_t *__restrict__ lstart, const PointSrc src,
-                                                           float *__restrict__ out, const WinPlan pl) {
+                                                           TV *__restrict__ out, const WinPlan pl) {
+    constexpr unsigned kPix = 32u * (unsigned)sizeof(TV);      // bytes of one head's pixel row
+    constexpr unsigned kCh = kPix / 8u;                         // ... of a lane's four channels
+    constexpr int kGPlog = sizeof(TV) == 4 ? 3 : 4;             // log2 pixels per 1-KiB fill group
+    constexpr int kLPPlog = sizeof(TV) == 4 ? 3 : 2;            // log2 lanes per pixel of a fill instruction
     __shared__ WinTables tb;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
 
@@ -391,18 +415,18 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
     const int g_row = ((lane >> 5) << 1) + ((g_inner == (g_odd != 0)) ? 0 : 1);
     const int g_half = g_j >> 3;
     const int g_chunk = (g_half ? 3 - (g_j & 3) : (g_j & 3)) + 4 * g_odd;
-    const unsigned sub16 = (unsigned)g_chunk * 16u;
+    const unsigned sub16 = (unsigned)g_chunk * kCh;
 
     const __amdgpu_buffer_rsrc_t vr = make_rsrc(value, pl.value_bytes);
-    const unsigned zero_off = (unsigned)tb.wbase[kWinMaxL] * 128u;
+    const unsigned zero_off = (unsigned)tb.wbase[kWinMaxL] * kPix;
     const unsigned win_bytes = (unsigned)pl.groups * 1024u;
     u32x4 *rec_w = reinterpret_cast<u32x4 *>(s_dyn + win_bytes) + wave * 128;     // 64 records of 32 bytes
     const u32x4 *rec_g = rec_w + g_row * 32 + g_half;                               // + 2 * t
     int *s_rowq = reinterpret_cast<int *>(s_dyn + win_bytes + (unsigned)nw * 2048u);   // query of region row r, -1: none
     // sampled (dx, dy, count) per level of every first-step row: lives in wave 0's record space until the steps start
     float *s_part = reinterpret_cast<float *>(s_dyn + win_bytes);
-    const unsigned pix_stride = (unsigned)M * 128u;
-    const unsigned row_base = ((unsigned)b * (unsigned)pl.S * (unsigned)M + (unsigned)m) * 128u;
+    const unsigned pix_stride = (unsigned)M * kPix;
+    const unsigned row_base = ((unsigned)b * (unsigned)pl.S * (unsigned)M + (unsigned)m) * kPix;
     const unsigned q_base = (unsigned)b * (unsigned)pl.Lq;
     const int lwin0 = pl.lwin0;
 
@@ -416,14 +440,14 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
         //      instruction wait a memory round trip (and, vmcnt being in-order, for every DMA before it).  The bytes
         //      are requested below, next to the fill, and padded pixels are zeroed in LDS once both have landed.
         for (int l = lwin0; l <= L; ++l) {        // l == L: the group that holds the zero row
-            const int g0 = tb.wbase[l < L ? l : kWinMaxL] >> 3;
-            const int g1 = l < L ? (tb.wbase[l + 1 < L ? l + 1 : kWinMaxL] >> 3) : pl.groups;
+            const int g0 = tb.wbase[l < L ? l : kWinMaxL] >> kGPlog;
+            const int g1 = l < L ? (tb.wbase[l + 1 < L ? l + 1 : kWinMaxL] >> kGPlog) : pl.groups;
             const int lc = l < L ? l : L - 1;
             const int ww = tb.ww[lc], npx = l < L ? ww * tb.wh[lc] : 0, magic = tb.wmagic[lc];
             const int oy = tb.oy[lc], ox = tb.ox[lc], H = tb.H[lc], W = tb.W[lc];
-            const unsigned lbase = row_base + (unsigned)tb.lstart[lc] * pix_stride + (unsigned)(lane & 7) * 16u;
+            const unsigned lbase = row_base + (unsigned)tb.lstart[lc] * pix_stride + (unsigned)(lane & ((1 << kLPPlog) - 1)) * 16u;
             for (int g = g0 + wave; g < g1; g += nw) {
-                const int local = (g - g0) * 8 + (lane >> 3);
+                const int local = ((g - g0) << kGPlog) + (lane >> kLPPlog);
                 const int wy = (local * magic) >> 16, wx = local - wy * ww;
                 const int gy = oy + wy, gx = ox + wx;
                 const bool inside = (local < npx) & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
@@ -440,9 +464,9 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
             for (int l = 0; l < kWinMaxL; ++l) {
                 mpad[l] = 0;
                 if (l >= lwin0 && l < L) {
-                    const int g0 = tb.wbase[l] >> 3, g1 = tb.wbase[l + 1 < L ? l + 1 : kWinMaxL] >> 3;
-                    const int g = g0 + wave + (lane >> 3) * nw;
-                    const int local = (g - g0) * 8 + (lane & 7);
+                    const int g0 = tb.wbase[l] >> kGPlog, g1 = tb.wbase[l + 1 < L ? l + 1 : kWinMaxL] >> kGPlog;
+                    const int g = g0 + wave + (lane >> kGPlog) * nw;
+                    const int local = ((g - g0) << kGPlog) + (lane & ((1 << kGPlog) - 1));
                     const int ww = tb.ww[l], wy = (local * tb.wmagic[l]) >> 16, wx = local - wy * ww;
                     const int gy = tb.oy[l] + wy, gx = tb.ox[l] + wx;
                     const bool inside = (g < g1) & (local < ww * tb.wh[l]) & ((unsigned)gy < (unsigned)tb.H[l]) &
@@ -561,8 +585,8 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
     const int c_ww = tb.ww[s_l];
     const unsigned c_wwm1 = c_windowed ? (unsigned)(c_ww - 1) : 0u, c_whm1 = c_windowed ? (unsigned)(tb.wh[s_l] - 1) : 0u;
     const int c_ox = tb.ox[s_l], c_oy = tb.oy[s_l];
-    const unsigned c_wbase = (unsigned)tb.wbase[s_l] * 128u;
-    const unsigned c_wrow = (unsigned)c_ww * 128u;
+    const unsigned c_wbase = (unsigned)tb.wbase[s_l] * kPix;
+    const unsigned c_wrow = (unsigned)c_ww * kPix;
     const unsigned c_wps = (unsigned)cW * pix_stride;
     const unsigned c_lbase = row_base + (unsigned)tb.lstart[s_l] * pix_stride;     // pixel 0 of the level, this head
     const unsigned c_flag = c_windowed ? 1u : 0u;          // word 0 of a windowed level's record: bit 0 = global path
@@ -620,7 +644,7 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
             // inside its window: LDS byte addresses (the window holds zeros outside the level / on padded pixels)
             const int wx = w0 - c_ox, wy = h0 - c_oy;
             const bool inwin = live && (unsigned)wx < c_wwm1 && (unsigned)wy < c_whm1;
-            const unsigned lbase = c_wbase + (unsigned)(win_mul24(wy, c_ww) + wx) * 128u;
+            const unsigned lbase = c_wbase + (unsigned)(win_mul24(wy, c_ww) + wx) * kPix;
             // otherwise: byte offsets into `value`, out of range for corners that do not exist
             const bool need = live && !inwin;
             const bool okh0 = (unsigned)h0 < (unsigned)cH, okh1 = (unsigned)(h0 + 1) < (unsigned)cH;
@@ -637,14 +661,14 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
                 const WinRow wq_ = win_row(tb, L, st_ * 4 + s_rs, b, m, M, pl.Lq);      // (not the table: first step, no barrier yet)
                 const int qq = wq_.ok ? (int)(wq_.qrow - q_base) : -1;
                 if (c_pt && qq >= 0)
-                    out[(size_t)((q_base + (unsigned)qq) * (unsigned)M + (unsigned)m) * 32u + (unsigned)s_t] =
+                    reinterpret_cast<float *>(out)[(size_t)((q_base + (unsigned)qq) * (unsigned)M + (unsigned)m) * 32u + (unsigned)s_t] =
                         (need && c_windowed) ? 2.f : ((live && c_windowed) ? 1.f : 0.f);
             }
             const unsigned o00 = c_lbase + (unsigned)win_mul24(cell, (int)pix_stride);      // (signed: cell is -W - 1 ... H W)
             ra.y = inwin ? lbase : (need ? (ok00 ? o00 : kOobOffset) | c_flag : c_dead);
             ra.w = inwin ? lbase + c_wrow : (need ? (ok10 ? o00 + c_wps : kOobOffset) : c_dead);
-            rb.y = inwin ? lbase + 128u : (need ? (ok01 ? o00 + pix_stride : kOobOffset) | c_flag : c_dead);
-            rb.w = inwin ? lbase + c_wrow + 128u : (need ? (ok11 ? o00 + c_wps + pix_stride : kOobOffset) : c_dead);
+            rb.y = inwin ? lbase + kPix : (need ? (ok01 ? o00 + pix_stride : kOobOffset) | c_flag : c_dead);
+            rb.w = inwin ? lbase + c_wrow + kPix : (need ? (ok11 ? o00 + c_wps + pix_stride : kOobOffset) : c_dead);
             if (c_pt) {
                 rec_w[2 * lane] = ra;
                 rec_w[2 * lane + 1] = rb;
@@ -680,10 +704,10 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
 #pragma unroll
                 for (int l = 0; l < kWinMaxL; ++l) {
                     if (mpad[l]) {
-                        const int g = (tb.wbase[l] >> 3) + wave + (lane >> 3) * nw;
-                        f32x4 *px = reinterpret_cast<f32x4 *>(s_dyn + ((size_t)g * 8 + (size_t)(lane & 7)) * 128);
+                        const int g = (tb.wbase[l] >> kGPlog) + wave + (lane >> kGPlog) * nw;
+                        f32x4 *px = reinterpret_cast<f32x4 *>(s_dyn + (((size_t)g << kGPlog) + (size_t)(lane & ((1 << kGPlog) - 1))) * kPix);
 #pragma unroll
-                        for (int c = 0; c < 8; ++c) px[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        for (int c = 0; c < (int)(kPix / 16u); ++c) px[c] = f32x4{0.f, 0.f, 0.f, 0.f};
                     }
                 }
             }
@@ -702,8 +726,8 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
                     for (int i = 0; i < 4; ++i) r[i] = rp[2 * i];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        v[i][0] = *reinterpret_cast<const f32x4 *>(s_dyn + (r[i].y + sub16));
-                        v[i][1] = *reinterpret_cast<const f32x4 *>(s_dyn + (r[i].w + sub16));
+                        v[i][0] = win_lds_ch4<TV>(s_dyn + (r[i].y + sub16));
+                        v[i][1] = win_lds_ch4<TV>(s_dyn + (r[i].w + sub16));
                     }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -720,11 +744,11 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const bool g = (r[i].y & 1u) != 0u;
-                        v[i][0] = *reinterpret_cast<const f32x4 *>(s_dyn + ((g ? zero_off : r[i].y) + sub16));
-                        v[i][1] = *reinterpret_cast<const f32x4 *>(s_dyn + ((g ? zero_off : r[i].w) + sub16));
+                        v[i][0] = win_lds_ch4<TV>(s_dyn + ((g ? zero_off : r[i].y) + sub16));
+                        v[i][1] = win_lds_ch4<TV>(s_dyn + ((g ? zero_off : r[i].w) + sub16));
                         if (g) {
-                            v[i][0] = buf_load_f4(vr, (r[i].y & ~1u) + sub16);
-                            v[i][1] = buf_load_f4(vr, r[i].w + sub16);
+                            v[i][0] = buf_load_ch4<TV>(vr, (r[i].y & ~1u) + sub16);
+                            v[i][1] = buf_load_ch4<TV>(vr, r[i].w + sub16);
                         }
                     }
 #pragma unroll
@@ -734,7 +758,7 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
                     }
                 }
             }
-            for (; t0 < LP; ++t0) acc = win_mixed_point(rec_g[2 * t0], s_dyn, zero_off, vr, sub16, acc);
+            for (; t0 < LP; ++t0) acc = win_mixed_point<TV>(rec_g[2 * t0], s_dyn, zero_off, vr, sub16, acc);
             return acc;
     };
     // the two pixel halves of a row meet, the row leaves
@@ -749,7 +773,7 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
             const int q = s_rowq[step * 4 + g_row];
             if (g_half == 0 && q >= 0) {
                 const unsigned pm = win_umul24(q_base + (unsigned)q, (unsigned)M) + (unsigned)m;
-                *reinterpret_cast<f32x4 *>(out + ((size_t)pm * 32u + (unsigned)g_chunk * 4u)) = acc;
+                win_store4(out + ((size_t)pm * 32u + (unsigned)g_chunk * 4u), acc);
             }
     };
     {
@@ -771,8 +795,8 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
             for (int i = 0; i < NEA; ++i) gr[i] = rec_g[2 * i];
 #pragma unroll
             for (int i = 0; i < NEA; ++i) {
-                gv[i][0] = buf_load_f4(vr, gr[i].y + sub16);
-                gv[i][1] = buf_load_f4(vr, gr[i].w + sub16);
+                gv[i][0] = buf_load_ch4<TV>(vr, gr[i].y + sub16);
+                gv[i][1] = buf_load_ch4<TV>(vr, gr[i].w + sub16);
             }
         }
         if (it == 0) windows_landed();
@@ -799,8 +823,8 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
                 for (int i = 0; i < 4; ++i) r[i] = rec_g[2 * (tg + i)];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    v[i][0] = buf_load_f4(vr, r[i].y + sub16);
-                    v[i][1] = buf_load_f4(vr, r[i].w + sub16);
+                    v[i][0] = buf_load_ch4<TV>(vr, r[i].y + sub16);
+                    v[i][1] = buf_load_ch4<TV>(vr, r[i].w + sub16);
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -815,8 +839,8 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
                 for (int i = 0; i < 2; ++i) r[i] = rec_g[2 * (tg + i)];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    v[i][0] = buf_load_f4(vr, r[i].y + sub16);
-                    v[i][1] = buf_load_f4(vr, r[i].w + sub16);
+                    v[i][0] = buf_load_ch4<TV>(vr, r[i].y + sub16);
+                    v[i][1] = buf_load_ch4<TV>(vr, r[i].w + sub16);
                 }
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
@@ -826,7 +850,7 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
             }
             for (; tg < T0; ++tg) {
                 const u32x4 r = rec_g[2 * tg];
-                const f32x4 v0 = buf_load_f4(vr, r.y + sub16), v1 = buf_load_f4(vr, r.w + sub16);
+                const f32x4 v0 = buf_load_ch4<TV>(vr, r.y + sub16), v1 = buf_load_ch4<TV>(vr, r.w + sub16);
                 acc += __uint_as_float(r.x) * v0;
                 acc += __uint_as_float(r.z) * v1;
             }
@@ -862,7 +886,8 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
 // margins[l]: window side on level l = region side + 2 * margin + 1.
 inline bool make_win_plan(WinPlan &pl, const int64_t *shapes_host, int N, int S, int M, int D, int L, int Lq, int P,
                           long value_bytes, int rlogx, int rlogy, int lwin0, const int *margins, int threads,
-                          size_t &lds) {
+                          size_t &lds, int elem_bytes = 4) {
+    const int gplog = elem_bytes == 4 ? 3 : 4, gp = 1 << gplog;      // pixels per 1-KiB fill group
     if (!shapes_host || D != 32 || L < 1 || L > kWinMaxL || Lq != S || L * P > 16) return false;
     if (rlogy < L - 1) rlogy = L - 1;
     if (rlogx < rlogy) rlogx = rlogy;
@@ -901,8 +926,8 @@ inline bool make_win_plan(WinPlan &pl, const int64_t *shapes_host, int N, int S,
                     if (((x * magic) >> 16) != x / ww) return false;
             }
             pl.wmagic[l] = magic;
-            q += H * W; rows += side_x * side_y; px += (ww * wh + 7) & ~7;     // windows start on 8-pixel groups
-            if ((ww * wh + 7) / 8 > pl.wgroups_max) pl.wgroups_max = (ww * wh + 7) / 8;
+            q += H * W; rows += side_x * side_y; px += (ww * wh + gp - 1) & ~(gp - 1);     // windows start on group boundaries
+            if ((ww * wh + gp - 1) / gp > pl.wgroups_max) pl.wgroups_max = (ww * wh + gp - 1) / gp;
             const int ry = (int)((H + side_y - 1) / side_y), rx = (int)((W + side_x - 1) / side_x);
             RY = ry > RY ? ry : RY;
             RX = rx > RX ? rx : RX;
@@ -914,7 +939,7 @@ inline bool make_win_plan(WinPlan &pl, const int64_t *shapes_host, int N, int S,
     }
     if (q != S) return false;      // the host shapes do not describe this value tensor
     // 24-bit multiplies in the step loop: (query, head) rows, projection-row offsets' factors and row strides in range
-    if ((long)N * Lq * M >= (1L << 24) || (long)M * 128 >= (1L << 23) || L * P > 16) return false;
+    if ((long)N * Lq * M >= (1L << 24) || (long)M * 32 * elem_bytes >= (1L << 23) || L * P > 16) return false;
     for (int l = L; l <= kWinMaxL; ++l) { pl.row0[l] = rows; pl.wbase[l] = px; }
     pl.rows = rows; pl.steps = (rows + 3) / 4; pl.RY = RY; pl.RX = RX;
     pl.RYf = (int)(shapes_host[0] >> rlogy); pl.RXf = (int)(shapes_host[1] >> rlogx);
@@ -926,7 +951,8 @@ inline bool make_win_plan(WinPlan &pl, const int64_t *shapes_host, int N, int S,
             pl.ratw[a][c] = (float)((double)pl.W[c] / (double)pl.W[a]);
             pl.rath[a][c] = (float)((double)pl.H[c] / (double)pl.H[a]);
         }
-    pl.groups = lwin0 < L ? px / 8 + 1 : 0;
+    pl.groups = lwin0 < L ? px / gp + 1 : 0;
+    pl.gplog = gplog;
     const long nb = (long)N * RY * RX * M;
     if (nb > (1L << 30)) return false;
     pl.n_blocks = (int)nb;

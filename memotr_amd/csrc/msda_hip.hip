@@ -111,6 +111,8 @@ std::atomic<int> opt_bwd_rows{1};         // 0: few-query D = 32 calls keep the 
 std::atomic<int> opt_fwd_head_major{0};    // gather forward: head-major task walk (one head per XCD)
 std::atomic<int> opt_fwd_win_rlog{0};       // windowed forward: log2 of the region height on level 0 (0: auto)
 std::atomic<int> opt_fwd_win_rlogx{0};      // log2 of the region width (at least the height; 0: as the height)
+std::atomic<int> opt_fwd_win_bf16{0};       // 1: bf16 rows take the windowed forward too (built and measured in round 6: 51.0 vs 49.2 us
+                                            // for the gather kernel, fp32 windows 45.6 -- profiles/r06_bf16_fwd_probe.txt; default: the gather)
 std::atomic<int> opt_fwd_win_auto{1};       // 0: never pick the windowed forward on its own
 std::atomic<int> opt_fwd_win_block{0};      // threads per workgroup (128 / 256 / 384 / 512; 0: auto)
 std::atomic<int> opt_fwd_win_l0{1};         // first level served from an LDS window
@@ -517,8 +519,10 @@ int forward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart, 
     if (variant == 0) {
         // self-attention over the pyramid (one query per pixel): coarse levels from per-head LDS windows; every
         // other D = 32 call: direct gather with 4 points (16 rows) in flight -- best of the sweeps in profiles/
-        const bool pyramid = can32 && sizeof(TV) == 4 && shapes_host != nullptr && Lq == S && L <= kWinMaxL &&
-                             L * P <= 16 && opt_fwd_win_auto.load() != 0;
+        // (bf16 rows, round 6: the same kernel on 64-byte rows exists -- "fwd_win_bf16" 1 or "fwd_variant" 12 -- and is
+        //  slower than the gather kernel: halving the LDS bytes bought nothing, the widening costs VALU)
+        const bool pyramid = can32 && (sizeof(TV) == 4 || opt_fwd_win_bf16.load() != 0) && shapes_host != nullptr && Lq == S &&
+                             L <= kWinMaxL && L * P <= 16 && opt_fwd_win_auto.load() != 0;
         variant = pyramid ? 12 : (can32 ? 3 : 1);
         if (pyramid) {      // msda_select.h: windows while the points stay near their queries, else the head-major gather
             slot = sel_acquire(0, M, L, P, (int)sizeof(TV), stream);
@@ -557,7 +561,7 @@ int forward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart, 
     }
     if constexpr (kD32Type) {
         const PointSrc src = make_src(loc, attn, fa, M, L, P);
-        if constexpr (sizeof(TV) == 4) {
+        {
             if (variant == 12) {
                 WinPlan wp;
                 size_t lds = 0;
@@ -574,32 +578,37 @@ int forward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart, 
                 if (threads != 512 && threads != 384 && threads != 128 && threads != 256) threads = auto_shape ? 512 : 256;
                 if (rlogy == 0) rlogy = auto_shape ? 4 : 3;
                 if (rlogx == 0) rlogx = rlogy;
+                constexpr int kMaskGroups = sizeof(TV) == 4 ? 8 : 4;      // fill groups a wavefront's lanes cover per level
                 bool planned = make_win_plan(wp, shapes_host, N, S, M, D, L, Lq, P, value_bytes, rlogx, rlogy,
-                                             opt_fwd_win_l0.load(), margins, threads, lds) &&
-                               !(src.mask != nullptr && wp.wgroups_max > 8 * (threads / 64));
+                                             opt_fwd_win_l0.load(), margins, threads, lds, (int)sizeof(TV)) &&
+                               !(src.mask != nullptr && wp.wgroups_max > kMaskGroups * (threads / 64));
                 if (!planned && auto_shape) {
                     threads = 256;
                     planned = make_win_plan(wp, shapes_host, N, S, M, D, L, Lq, P, value_bytes, 3, 3,
-                                            opt_fwd_win_l0.load(), margins, threads, lds) &&
-                              !(src.mask != nullptr && wp.wgroups_max > 8 * (threads / 64));
+                                            opt_fwd_win_l0.load(), margins, threads, lds, (int)sizeof(TV)) &&
+                              !(src.mask != nullptr && wp.wgroups_max > kMaskGroups * (threads / 64));
                 }
+                // (bf16 rows: the default shape only -- 512 threads, no early loads, no profiling build; else the gather)
+                if (sizeof(TV) == 2 && (threads != 512 || opt_fwd_win_ablate.load() != 0 || opt_fwd_win_trace_lo.load() != 0 ||
+                                        opt_fwd_win_trace_hi.load() != 0))
+                    planned = false;
                 if (planned) {
                     const int grid = (wp.n_blocks + 7) & ~7;
 #define MSDA_LAUNCH_WIN(FU, WPS, NE, NAME)                                                                           \
     do {                                                                                                             \
-        rc = allow_big_lds(msda_fwd_d32_win<FU, WPS, NE>, lds);                                                      \
+        rc = allow_big_lds(msda_fwd_d32_win<TV, FU, WPS, NE>, lds);                                                  \
         if (rc) return rc;                                                                                           \
         g_kernel = NAME;                                                                                             \
-        hipLaunchKernelGGL((msda_fwd_d32_win<FU, WPS, NE>), dim3(grid), dim3(threads), lds, stream,                  \
-                           (const float *)value, lstart, src, (float *)out, wp);                                     \
+        hipLaunchKernelGGL((msda_fwd_d32_win<TV, FU, WPS, NE>), dim3(grid), dim3(threads), lds, stream,              \
+                           value, lstart, src, out, wp);                                                             \
     } while (0)
 #define MSDA_LAUNCH_WIN_T(FU, WPS, NE, NAME)                                                                         \
     do {                                                                                                             \
-        rc = allow_big_lds(msda_fwd_d32_win<FU, WPS, NE, true>, lds);                                                \
+        rc = allow_big_lds(msda_fwd_d32_win<TV, FU, WPS, NE, true>, lds);                                            \
         if (rc) return rc;                                                                                           \
         g_kernel = NAME;                                                                                             \
-        hipLaunchKernelGGL((msda_fwd_d32_win<FU, WPS, NE, true>), dim3(grid), dim3(threads), lds, stream,            \
-                           (const float *)value, lstart, src, (float *)out, wp);                                     \
+        hipLaunchKernelGGL((msda_fwd_d32_win<TV, FU, WPS, NE, true>), dim3(grid), dim3(threads), lds, stream,        \
+                           value, lstart, src, out, wp);                                                             \
     } while (0)
                     wp.ablate = opt_fwd_win_ablate.load();
                     wp.trace = reinterpret_cast<unsigned long long *>(((unsigned long long)opt_fwd_win_trace_hi.load() << 31) |
@@ -633,19 +642,24 @@ int forward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart, 
                     // (the profiling instantiation -- timeline stamps, ablation bits -- exists for the default shape only)
                     if ((wp.trace || wp.ablate) && (wps == 3 || early == 2))
                         return fail(MSDA_EINVAL, "fwd_win_trace / fwd_win_ablate: profiling build of the default launch shape only");
-                    if (wps == 3) {
-                        if (fused) MSDA_LAUNCH_WIN(true, 3, 4, "msda_fwd_d32_win<fused,w3,e4>");
-                        else MSDA_LAUNCH_WIN(false, 3, 4, "msda_fwd_d32_win<w3,e4>");
-                    } else if (early == 2) {
-                        if (fused) MSDA_LAUNCH_WIN(true, 4, 2, "msda_fwd_d32_win<fused,w4,e2>");
-                        else MSDA_LAUNCH_WIN(false, 4, 2, "msda_fwd_d32_win<w4,e2>");
+                    if constexpr (sizeof(TV) == 2) {       // bf16 rows: the default shape only (512 threads, no early loads)
+                        if (fused) MSDA_LAUNCH_WIN(true, 4, 0, "msda_fwd_d32_win<bf16,fused,w4>");
+                        else MSDA_LAUNCH_WIN(false, 4, 0, "msda_fwd_d32_win<bf16,w4>");
                     } else {
-                        if (fused) {
-                            if (wp.trace || wp.ablate) MSDA_LAUNCH_WIN_T(true, 4, 0, "msda_fwd_d32_win<fused,w4>");
-                            else MSDA_LAUNCH_WIN(true, 4, 0, "msda_fwd_d32_win<fused,w4>");
+                    if (wps == 3) {
+                            if (fused) MSDA_LAUNCH_WIN(true, 3, 4, "msda_fwd_d32_win<fused,w3,e4>");
+                            else MSDA_LAUNCH_WIN(false, 3, 4, "msda_fwd_d32_win<w3,e4>");
+                        } else if (early == 2) {
+                            if (fused) MSDA_LAUNCH_WIN(true, 4, 2, "msda_fwd_d32_win<fused,w4,e2>");
+                            else MSDA_LAUNCH_WIN(false, 4, 2, "msda_fwd_d32_win<w4,e2>");
                         } else {
-                            if (wp.trace || wp.ablate) MSDA_LAUNCH_WIN_T(false, 4, 0, "msda_fwd_d32_win<w4>");
-                            else MSDA_LAUNCH_WIN(false, 4, 0, "msda_fwd_d32_win<w4>");
+                            if (fused) {
+                                if (wp.trace || wp.ablate) MSDA_LAUNCH_WIN_T(true, 4, 0, "msda_fwd_d32_win<fused,w4>");
+                                else MSDA_LAUNCH_WIN(true, 4, 0, "msda_fwd_d32_win<fused,w4>");
+                            } else {
+                                if (wp.trace || wp.ablate) MSDA_LAUNCH_WIN_T(false, 4, 0, "msda_fwd_d32_win<w4>");
+                                else MSDA_LAUNCH_WIN(false, 4, 0, "msda_fwd_d32_win<w4>");
+                            }
                         }
                     }
 #undef MSDA_LAUNCH_WIN
@@ -1433,6 +1447,7 @@ static std::atomic<int> *find_opt(const char *key) {
     if (!strcmp(key, "fwd_win_rlog")) return &opt_fwd_win_rlog;
     if (!strcmp(key, "fwd_win_rlogx")) return &opt_fwd_win_rlogx;
     if (!strcmp(key, "fwd_win_auto")) return &opt_fwd_win_auto;
+    if (!strcmp(key, "fwd_win_bf16")) return &opt_fwd_win_bf16;
     if (!strcmp(key, "fwd_head_major")) return &opt_fwd_head_major;
     if (!strcmp(key, "fwd_win_block")) return &opt_fwd_win_block;
     if (!strcmp(key, "fwd_win_l0")) return &opt_fwd_win_l0;

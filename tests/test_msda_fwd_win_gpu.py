@@ -246,3 +246,58 @@ def test_win_fused_forward_against_the_plain_forward_on_the_exposed_points(msda,
     plain_g = msda.ms_deform_attn_forward(d["value"], d["shapes"], d["level_start"], loc, attn, 64)
     hip_lib.set_option("fwd_variant", 0)
     assert torch.equal(fused_g, plain_g), float((fused_g - plain_g).abs().max())
+
+
+# ----------------------------------------------------------------------------- bf16 rows (round 6, BASELINE config 5)
+@pytest.mark.parametrize("pyr", list(PYRAMIDS))
+@pytest.mark.parametrize("dist", ["encoder_like", "uniform"])
+def test_win_forward_bf16_rows_full_size(msda, hip_lib, pyr, dist):
+    """bf16 `value` / `out` (msda_*_bf16, no reference counterpart), fp32 locations, weights and accumulation, through the
+    windowed kernel on 64-byte rows: against the fp32 oracle on the bf16-rounded `value` (the output is rounded to bf16
+    once: 2^-8 relative), margins / off-window points included (uniform locations: most points leave their windows);
+    run-to-run identical; and the gather kernel -- the DEFAULT for bf16 rows: the windowed kernel on 64-byte rows measured
+    51.0 against 49.2 us, profiles/r06_bf16_fwd_probe.txt -- agrees to bf16 rounding."""
+    from memotr_amd.MultiScaleDeformableAttention import tag_host_shapes
+    from memotr_amd.synth import make_inputs
+    h, w = PYRAMIDS[pyr]
+    x = make_inputs(height=h, width=w, dist=dist, device="cuda", seed=17)
+    tag_host_shapes(x["shapes"], x["shapes_list"])
+    vb = x["value"].bfloat16()
+    args = (vb, x["shapes"], x["level_start"], x["loc"], x["attn"], 64)
+    out = msda.ms_deform_attn_forward(*args)
+    assert hip_lib.last_kernel() == "msda_fwd_d32_win<bf16,w4>", hip_lib.last_kernel()
+    c = _cpu(x)
+    c["value"] = vb.float().cpu().numpy()
+    want = _oracle_fwd(c)
+    np.testing.assert_allclose(out.float().cpu().numpy(), want, rtol=1e-2, atol=1e-2)
+    assert torch.equal(out, msda.ms_deform_attn_forward(*args))
+    hip_lib.set_option("fwd_variant", 0)          # the default for bf16 rows: the gather kernel (the windows lose to it)
+    ref = msda.ms_deform_attn_forward(*args)
+    assert "gather<4,bf16>" in hip_lib.last_kernel(), hip_lib.last_kernel()
+    hip_lib.set_option("fwd_win_bf16", 1)         # ... unless asked
+    msda.ms_deform_attn_forward(*args)
+    hip_lib.set_option("fwd_win_bf16", 0)
+    assert "win<bf16" in hip_lib.last_kernel() or dist == "uniform", hip_lib.last_kernel()
+    assert float((out.float() - ref.float()).abs().max()) <= 2.0 ** -6 * max(1.0, float(ref.float().abs().max()))
+
+
+@pytest.mark.parametrize("case", FUSED_PYRAMIDS, ids=lambda c: f"seed{c[0]}")
+def test_win_fused_forward_bf16_rows_odd_pyramids(msda, hip_lib, case):
+    """The fused entry on bf16 rows over the odd / non-halving / two-level pyramids (partial regions, windows clipped to
+    small levels, the padding mask): against the pinned checker on bf16-rounded `value`; and the plain kernel fed the
+    exposed points returns the same bits."""
+    from memotr_amd.MultiScaleDeformableAttention import tag_host_shapes
+    seed, N, M, P, shapes, ref_dim = case
+    c = make_case(seed, N, M, 32, len(shapes), P, shapes, ref_dim=ref_dim, pyramid=True, off_px=2.0)
+    c["value"] = c["value"].bfloat16().float()
+    want = expected(c)["out"]
+    d = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in c.items()}
+    tag_host_shapes(d["shapes"], c["shapes_list"])
+    vb = d["value"].bfloat16()
+    out = msda.ms_deform_attn_fused_forward(vb, d["shapes"], d["level_start"], d["proj"], d["ref"], d["mask"], M, P)
+    assert "win<bf16,fused" in hip_lib.last_kernel() or "gather" in hip_lib.last_kernel(), hip_lib.last_kernel()
+    np.testing.assert_allclose(out.float().cpu().numpy(), want, rtol=1e-2, atol=1e-2)
+    if d["mask"] is None:
+        loc, attn = msda.fused_points(d["shapes"], d["proj"], d["ref"], M, P)
+        plain = msda.ms_deform_attn_forward(vb, d["shapes"], d["level_start"], loc, attn, 64)
+        assert torch.equal(out, plain)
