@@ -6,7 +6,7 @@
 # gfx950 note of MI355X_MICROARCH.md.  Both files are stamped with the kernel label bench.py prints and the hash of the
 # kernel sources, so a number taken on other kernels is recognised as stale.
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=$PWD/gpurun_out/traffic_tmp; rm -rf "$OUT"; mkdir -p "$OUT" gpurun_out/profiles
 export TMPDIR=/tmp
 for DIR in fwd bwd; do
@@ -46,8 +46,8 @@ for d, out_name, key in (("fwd", "traffic.json", "msda_fwd_encoder_bytes_per_lau
     lines.append(f"  whole call: 2 x FETCH {2*fe*1024/1e6:.1f} MB + WRITE {wr*1024/1e6:.1f} MB = {total/1e6:.1f} MB")
     json.dump({key: total, "kernel_label": label, "source_sha16": source_hash(), "fetch_size_KiB": fe, "write_size_KiB": wr,
                "kernels": {k: v for k, v in per.items()},
-               "note": f"tools/traffic_probe.sh {tag}: every msda kernel of the call summed (the fused backward = counting-sort "
-                       "kernel + attention-weight and Jacobian side kernels); separate --pmc passes, FETCH_SIZE doubled (gfx950)"},
+               "note": f"tools/traffic_probe.sh {tag}: every msda kernel of the call summed (round 6: the fused backward given the "
+                       "forward's output is ONE counting-sort kernel + the zeroing launch); separate --pmc passes, FETCH_SIZE doubled (gfx950)"},
               open(os.path.join("gpurun_out", "profiles", out_name), "w"), indent=1)
 open(os.path.join("gpurun_out", "profiles", f"{tag}_traffic_probe.txt"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
