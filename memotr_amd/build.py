@@ -12,7 +12,7 @@ HDR = os.path.join(os.path.dirname(_HERE), "include", "msda_hip.h")
 # the operator's kernels, one header per family, all included by msda_hip.hip
 KERNEL_HEADERS = tuple(os.path.join(_HERE, "csrc", n) for n in (
     "msda_common.h", "msda_select.h", "msda_generic.h", "msda_fwd_gather.h", "msda_fwd_win.h", "msda_tile.h",
-    "msda_bwd_tile_lv.h", "msda_bwd_bins.h", "msda_bwd_rows.h", "msda_fused_side.h"))
+    "msda_bwd_tile_lv.h", "msda_bwd_bins.h", "msda_bwd_rows.h", "msda_bwd_sorted.h", "msda_fused_side.h"))
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libmsda_hip.so")
 CLIP_SRC = os.path.join(_HERE, "csrc", "clip_ops.hip")

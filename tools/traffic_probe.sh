@@ -27,7 +27,8 @@ for d, out_name, key in (("fwd", "traffic.json", "msda_fwd_encoder_bytes_per_lau
         vals = collections.defaultdict(list)
         for f in glob.glob(f"{root}/{d}_{c}/**/*counter_collection.csv", recursive=True):
             for r in csv.DictReader(open(f)):
-                if r["Counter_Name"] == c and "msda" in r["Kernel_Name"]:
+                # (the backward probe runs the forward once first -- the backward gets its output: not part of the call)
+                if r["Counter_Name"] == c and "msda" in r["Kernel_Name"] and not (d == "bwd" and "msda_fwd" in r["Kernel_Name"]):
                     m = re.search(r"msda_\w+(<[^>]*>)?", r["Kernel_Name"])
                     vals[m.group(0) if m else r["Kernel_Name"][:60]].append(float(r["Counter_Value"]))
         for k, v in vals.items():
