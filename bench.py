@@ -683,7 +683,8 @@ def main():
     respect_cpu_quota(processes=int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     # ... and from two CPUs next to the GPU's PCIe root, a different pair per local rank (memotr_amd/utils/host.py: +2 % on
     # the train step of a two-socket box)
-    pinned = pin_near_gpu(torch.cuda.current_device(), int(os.environ.get("LOCAL_RANK", "0")))
+    # (multi-rank: four, so that RCCL's proxy thread -- it polls -- does not share a core with the launch threads)
+    pinned = pin_near_gpu(torch.cuda.current_device(), int(os.environ.get("LOCAL_RANK", "0")), n_cpus=2 if world == 1 else 4)
     if args.workload == "msda":
         result = run_msda(args, rank, world)
     elif args.workload == "infer":
