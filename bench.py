@@ -355,7 +355,9 @@ def host_cpu_info():
 def cpu_baseline_msda(args, enc_shape_kwargs, dec_shape_kwargs):
     """Reference CPU fallback formulation on the host cores; bounded sample, scaled to frames/s."""
     from memotr_amd.synth import make_inputs
+    from memotr_amd.utils.host import unpin
     from oracle import msda_oracle as oracle
+    unpin()          # (the GPU legs ran from two CPUs next to the device; the host baseline gets every core the container may use)
     cpu_model, cpu_total = host_cpu_info()
 
     def one(kw):

@@ -49,6 +49,23 @@ def respect_cpu_quota(reserve: float = 0.5, processes: int = 1) -> int:
     return torch.get_num_threads()
 
 
+_AFFINITY_BEFORE_PIN = None      # what pin_near_gpu narrowed (unpin() restores it)
+
+
+def unpin():
+    """Give every thread of the process the affinity mask it had before ``pin_near_gpu`` (a CPU-side measurement -- the
+    bench's host baseline -- wants all the cores the container may use)."""
+    global _AFFINITY_BEFORE_PIN
+    if _AFFINITY_BEFORE_PIN is None:
+        return
+    for tid in os.listdir("/proc/self/task"):
+        try:
+            os.sched_setaffinity(int(tid), _AFFINITY_BEFORE_PIN)
+        except OSError:
+            pass
+    _AFFINITY_BEFORE_PIN = None
+
+
 def _parse_cpulist(text: str):
     cpus = []
     for part in text.strip().split(","):
@@ -85,6 +102,8 @@ def pin_near_gpu(device_index: int = 0, local_rank: int = 0, n_cpus: int = 2):
             return None
         start = (local_rank * n_cpus) % (len(local) - n_cpus + 1)
         chosen = local[start:start + n_cpus]
+        global _AFFINITY_BEFORE_PIN
+        _AFFINITY_BEFORE_PIN = set(allowed)
         # every thread that exists already (the HIP runtime's, torch's pool: the device had to be initialised to be asked
         # where it sits) and, through inheritance, every later one
         for tid in os.listdir("/proc/self/task"):
