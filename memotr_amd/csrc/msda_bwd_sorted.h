@@ -12,16 +12,18 @@
 // Here the scatter becomes a SORT followed by a GATHER, like msda_bwd_d32_bins does inside one window -- but over the
 // whole tensor, through a workspace, so that nothing depends on where the points land:
 //
-//   count   one lane per (query, point) of one head: sampling arithmetic, the four corners' destination pixels; the
-//           destination rows of a (batch, head) are cut into BUCKETS of 64 consecutive pixels; a workgroup (one head, a
-//           chunk of queries) histograms its corners per bucket in LDS, stores the histogram (its own row of a count
+//   dots    (msda_bwd_sort_dots) per (batch, head, chunk of queries): grad_loc / grad_attn of the chunk -- the row phase of
+//           msda_bwd_d32_bins without a region -- and, on the side, the chunk's COUNT: one lane per (query, point) does
+//           the sampling arithmetic; the destination rows of a (batch, head) are cut into BUCKETS of 64 consecutive
+//           pixels, the chunk histograms its corners per bucket in LDS, stores the histogram (its own row of a count
 //           matrix) and adds it to the bucket totals (one fire-and-forget integer atomic per non-empty bucket);
 //   scan    per (batch, head): bucket totals -> bucket starts (exclusive prefix; every (batch, head) owns a fixed
 //           segment of the record array, so no prefix crosses workgroups), and the gather's WORK LIST: a bucket with
 //           more records than one workgroup sorts in LDS is cut into equal slices;
-//   emit    the count kernel again, now writing: a workgroup reserves its share of every bucket with ONE returning
-//           atomic per bucket (its own count from the matrix), then every corner takes an LDS ticket and stores an
-//           8-byte record {query << 6 | pixel inside the bucket, w_corner * attn} -- 91 MB for the encoder call;
+//   emit    the item arithmetic again, now writing: a workgroup reserves its share of every bucket with ONE returning
+//           atomic per bucket (its chunks' counts from the matrix), then every corner pair takes two LDS tickets and
+//           leaves as one 16-byte store of two 8-byte records {query << 6 | pixel inside the bucket, w_corner * attn}
+//           -- 91 MB for the encoder call;
 //   gather  a workgroup per work item: counting sort of the slice's records by destination pixel in LDS (64 counters,
 //           integer tickets), then four lanes x eight channels per destination row walk the row's list:
 //           acc += w * grad_out[query, head, :] (16-byte loads, one head per XCD so that its 2.9 MB grad_out slab stays
@@ -29,10 +31,11 @@
 //   reduce  the rows of sliced buckets (coarse pyramid levels, where thousands of points share a pixel): their slices'
 //           partial rows, kept in the scratch, added in slice order.  No float atomic anywhere in the call.
 //
-// grad_loc / grad_attn come from msda_bwd_d32_dots below (the row phase of msda_bwd_d32_bins without a region; the fused
-// call: into the columns of grad_proj, the side kernels of msda_fused_side.h finish the Jacobians) -- or, when gradients
-// of the reference points are wanted, from msda_bwd_d32_rows instantiated without its atomics.  Non-finite gradients
-// propagate through fp32 arithmetic like the reference's atomicAdd.
+// The fused call: grad_loc / grad_attn go into the columns of grad_proj; for the encoder's rows (L * P = 16, 2-d reference
+// points) the dots and emit kernels form the softmax weights themselves and the dots kernel applies the softmax Jacobian,
+// otherwise the side kernels of msda_fused_side.h materialise the weights and finish the Jacobians; when gradients of the
+// reference points are wanted msda_bwd_d32_rows runs without its atomics.  Non-finite gradients propagate through fp32
+// arithmetic like the reference's atomicAdd.
 #pragma once
 
 constexpr int kSortBPLog = 6, kSortBP = 1 << kSortBPLog;      // destination pixels per bucket
