@@ -247,7 +247,10 @@ def clip_forward_backward(model: nn.Module, criterion, batch: dict, device, use_
                 encode_chunk(starts.index(frame_idx) + 1)     # queued before the host blocks on this frame's costs
             previous, new, unmatched = criterion.finish_frame(pending)
         if frame_idx < clip_len - 1:
-            tracks = core.postprocess_single_frame(previous, new, unmatched)
+            # (batched-encode path: the frame's slot for the updater's hipGraphs, models/updater_graphs.py)
+            tracks = core.postprocess_single_frame(previous, new, unmatched,
+                                                   **({} if chunks is None else {"frame_slot": frame_idx,
+                                                                                 "clip_key": clip_key}))
     # (no log values here: each is a device->host read, i.e. a stream synchronisation in front of the backward)
     loss_dict, _ = criterion.get_mean_by_n_gts(with_log=os.environ.get("MEMOTR_LOSS_LOG_SYNC", "0") == "1")
     loss = criterion.get_sum_loss_dict(loss_dict=loss_dict)

@@ -530,39 +530,44 @@ class _SelfAttention(torch.autograd.Function):
 
 class _Attention3(torch.autograd.Function):
     """The same kernels for separately projected q, k, v (B, L, E) -- the query updater's memory attention, whose
-    queries and keys come from different inputs."""
+    queries and keys come from different inputs.  ``key_mask`` (B, L) bool, True = ignore that key (the padded slots of
+    the captured update, models/updater_graphs.py), or None."""
 
     @staticmethod
-    def forward(ctx, q_p, k_p, v_p, n_heads):
+    def forward(ctx, q_p, k_p, v_p, key_mask, n_heads):
         B, L, E = q_p.shape
         out = torch.empty((B, L, E), dtype=torch.float32, device=q_p.device)
         lse = torch.empty((B, n_heads, L), dtype=torch.float32, device=q_p.device)
         scale = 1.0 / (E // n_heads) ** 0.5
+        mk = None if key_mask is None else key_mask.data_ptr()
         L_ = _lib()
         L_.check(L_.lib.clipops_mha_fwd_f32(q_p.data_ptr(), k_p.data_ptr(), v_p.data_ptr(), L * E, E, L * E, E, L * E, E,
-                                            None, B, n_heads, L, scale, out.data_ptr(), lse.data_ptr(), _stream(q_p)),
+                                            mk, B, n_heads, L, scale, out.data_ptr(), lse.data_ptr(), _stream(q_p)),
                  "clipops_mha_fwd_f32")
-        ctx.save_for_backward(q_p, k_p, v_p, out, lse)
+        ctx.save_for_backward(q_p, k_p, v_p, key_mask, out, lse)
         ctx.n_heads, ctx.scale = n_heads, scale
         return out
 
     @staticmethod
     def backward(ctx, g):
-        q_p, k_p, v_p, out, lse = ctx.saved_tensors
+        q_p, k_p, v_p, key_mask, out, lse = ctx.saved_tensors
         B, L, E = q_p.shape
         g = g.contiguous()
         g_q, g_k, g_v = torch.empty_like(q_p), torch.empty_like(k_p), torch.empty_like(v_p)
+        mk = None if key_mask is None else key_mask.data_ptr()
         L_ = _lib()
         L_.check(L_.lib.clipops_mha_bwd_f32(q_p.data_ptr(), k_p.data_ptr(), v_p.data_ptr(), L * E, E, L * E, E, L * E, E,
-                                            None, out.data_ptr(), lse.data_ptr(), g.data_ptr(), B, ctx.n_heads, L,
+                                            mk, out.data_ptr(), lse.data_ptr(), g.data_ptr(), B, ctx.n_heads, L,
                                             ctx.scale, g_q.data_ptr(), L * E, E, g_k.data_ptr(), L * E, E,
                                             g_v.data_ptr(), L * E, E, _stream(q_p)), "clipops_mha_bwd_f32")
-        return g_q, g_k, g_v, None
+        return g_q, g_k, g_v, None, None
 
 
-def attention(q_p: torch.Tensor, k_p: torch.Tensor, v_p: torch.Tensor, n_heads: int) -> torch.Tensor:
-    """softmax(q k^T / sqrt(d)) v per head for projected (B, L, E) inputs of one common length; (B, L, E) out."""
-    return _Attention3.apply(q_p.contiguous(), k_p.contiguous(), v_p.contiguous(), int(n_heads))
+def attention(q_p: torch.Tensor, k_p: torch.Tensor, v_p: torch.Tensor, n_heads: int, key_padding_mask=None) -> torch.Tensor:
+    """softmax(q k^T / sqrt(d)) v per head for projected (B, L, E) inputs of one common length; (B, L, E) out.
+    ``key_padding_mask`` (B, L) bool: True = that key takes no part."""
+    mask = None if key_padding_mask is None else key_padding_mask.contiguous()
+    return _Attention3.apply(q_p.contiguous(), k_p.contiguous(), v_p.contiguous(), mask, int(n_heads))
 
 
 def attention_supported(q_p: torch.Tensor, k_p: torch.Tensor, n_heads: int) -> bool:

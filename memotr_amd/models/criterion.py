@@ -265,9 +265,21 @@ class ClipCriterion:
             streams[device] = torch.cuda.Stream(device=device)
         return streams[device]
 
-    @_fp32_island
     def finish_frame(self, state: dict):
-        """Host side (assignment problems) and the device work that depends on it; see process_single_frame."""
+        """Host side (assignment problems) and the device work that depends on it; see process_single_frame.
+        = ``finish_tracks`` (what the next frame needs) + ``finish_losses`` (what only the backward needs).  Round 6
+        measured issuing the losses of frame t under the decoder of frame t + 1 (tools/small_trace.py had shown the
+        forward between two decoder graphs to be bound by the host): 124.7 vs 125.1 ms per step, nothing -- the host is
+        the bottleneck on both sides of the wait, so moving launches across it moves no time.  The halves stay separate
+        entry points; the training loop calls them back to back."""
+        out = self.finish_tracks(state)
+        self.finish_losses(state)
+        return out
+
+    @_fp32_island
+    def finish_tracks(self, state: dict):
+        """The assignment problems on the host, the index upload, and the track sets the next frame needs: returns
+        (tracked, new, unmatched).  Leaves in ``state`` what ``finish_losses`` reads."""
         model_outputs, tracked_instances, frame_idx = state["model_outputs"], state["tracked_instances"], state["frame_idx"]
         early, logits_all, boxes_all, n_gt_list = state["early"], state["logits_all"], state["boxes_all"], state["n_gt_list"]
         nd, dev, B, n_layers = self.n_det_queries, self.device, len(tracked_instances), len(state["layers"])
@@ -299,12 +311,10 @@ class ClipCriterion:
                 if li == 0:
                     main_q.append((qi, gj))
 
-        # ---- back on the device: new tracks, losses, unmatched detections ----
+        # ---- back on the device: new tracks, unmatched detections, IoU of the carried tracks ----
         new_tracks, unmatched = [], []
-        loss_label = torch.zeros((n_layers,), device=dev)
-        loss_l1 = torch.zeros((n_layers,), device=dev)
-        loss_giou = torch.zeros((n_layers,), device=dev)
         n_det_out = len(model_outputs["det_query_embed"])
+        per_clip = []                                   # what finish_losses reads, per clip of the batch
         for b in range(B):
             tr, gt = tracked_instances[b], gts[b]
             n_tr = len(tr)
@@ -327,41 +337,7 @@ class ClipCriterion:
             nt.logits = rows_of(model_outputs["pred_logits"], b, q_idx)
             nt.iou = torch.zeros((n_main,), dtype=torch.float, device=dev)
             nt = nt.to(dev)
-
-            # classification targets of every layer: matched detect queries + (late layers) the carried tracks
-            n_q = nd + n_tr                                                        # real (unpadded) queries of clip b
-            labels = torch.full((n_layers, n_q), self.num_classes, dtype=torch.int64, device=dev)
-            labels[lay_i, q_i] = gt.labels[g_i]
-            late = self._constant(("late", tuple(early)), [not e for e in early], torch.bool, dev)
-            if n_tr > 0:
-                has = tr.matched_idx >= 0
-                tr_lab = torch.where(has, gt.labels[tr.matched_idx.clamp(min=0)] if len(gt) > 0
-                                     else torch.full_like(tr.matched_idx, self.num_classes),
-                                     torch.full_like(tr.matched_idx, self.num_classes))
-                labels[:, nd:] = torch.where(late[:, None], tr_lab[None, :], labels[:, nd:])
-            use_kernels = clip_ops.fused(logits_all, boxes_all, gt.boxes)
-            if use_kernels:
-                loss_label = loss_label + clip_ops.focal_loss_per_layer(logits_all[:, b, :n_q], labels)
-            else:
-                one_hot = F.one_hot(labels, self.num_classes + 1)[..., :-1].to(logits_all.dtype)
-                loss_label = loss_label + sigmoid_focal_loss_per_layer(logits_all[:, b, :n_q], one_hot)
-
-            # box losses: detect pairs of every layer + tracked pairs of the late layers
-            pair_loss = clip_ops.pair_box_loss if use_kernels else clip_ops.pair_box_loss_reference
-            if n_tr > 0 and len(gt) > 0:
-                # every (layer, track) pair, weight 1 where the layer carries tracks and the track owns a ground truth
-                lay_t = self._constant(("lay_t", n_layers, n_tr), [li for li in range(n_layers) for _ in range(n_tr)],
-                                       torch.long, dev)
-                q_t = self._constant(("q_t", n_layers, n_tr, nd), [nd + j for _ in range(n_layers) for j in range(n_tr)],
-                                     torch.long, dev)
-                w_pair = (has[None, :] & late[:, None]).to(boxes_all.dtype).reshape(-1)
-                g_t = tr.matched_idx.clamp(min=0).repeat(n_layers)
-                l1_t, gi_t = pair_loss(boxes_all, lay_t, q_t, b, gt.boxes, g_t, w_pair)
-                loss_l1 = loss_l1 + l1_t.view(n_layers, n_tr).sum(1)
-                loss_giou = loss_giou + gi_t.view(n_layers, n_tr).sum(1)
-            l1_pair, gi_pair = pair_loss(boxes_all, lay_i, q_i, b, gt.boxes, g_i)
-            loss_l1 = loss_l1.index_add(0, lay_i, l1_pair)
-            loss_giou = loss_giou.index_add(0, lay_i, gi_pair)
+            per_clip.append({"idx": (lay_i, q_i, g_i), "n_tr": n_tr, "matched_idx": tr.matched_idx if n_tr > 0 else None})
 
             # detections nobody claimed (host knows the matched detect queries of the last layer)
             taken = set(int(q) for q in main_q[b][0])
@@ -383,13 +359,64 @@ class ClipCriterion:
             # IoU of every track with the ground truth it owns (kept where it owns none)
             tracked_instances[b] = tr = tr.to(dev)
             if len(gt) > 0:
-                iou_of = clip_ops.pair_iou if use_kernels else clip_ops.pair_iou_reference
+                iou_of = clip_ops.pair_iou if clip_ops.fused(logits_all, boxes_all, gt.boxes) else clip_ops.pair_iou_reference
                 if n_main > 0:
                     nt.iou = iou_of(nt.boxes, gt.boxes, nt.matched_idx)
                 if n_tr > 0:
                     has = tr.matched_idx >= 0
                     tr.iou = torch.where(has, iou_of(tr.boxes, gt.boxes, tr.matched_idx.clamp(min=0)), tr.iou)
             new_tracks.append(nt)
+        self.n_gts.append(sum(n_gt_list))
+        state["per_clip"] = per_clip
+        return tracked_instances, new_tracks, unmatched
+
+    @_fp32_island
+    def finish_losses(self, state: dict):
+        """Focal / L1 / GIoU losses of every decoder layer for the frame of ``state`` (after ``finish_tracks``), added
+        to the clip's running sums.  Frames must come in order (the sums are accumulated in frame order)."""
+        frame_idx, early, logits_all, boxes_all = state["frame_idx"], state["early"], state["logits_all"], state["boxes_all"]
+        nd, dev, n_layers = self.n_det_queries, self.device, len(state["layers"])
+        gts = self.gt_trackinstances_list[frame_idx]
+        loss_label = torch.zeros((n_layers,), device=dev)
+        loss_l1 = torch.zeros((n_layers,), device=dev)
+        loss_giou = torch.zeros((n_layers,), device=dev)
+        for b, clip in enumerate(state.pop("per_clip")):
+            gt, n_tr, matched_idx = gts[b], clip["n_tr"], clip["matched_idx"]
+            lay_i, q_i, g_i = clip["idx"]
+            # classification targets of every layer: matched detect queries + (late layers) the carried tracks
+            n_q = nd + n_tr                                                        # real (unpadded) queries of clip b
+            labels = torch.full((n_layers, n_q), self.num_classes, dtype=torch.int64, device=dev)
+            labels[lay_i, q_i] = gt.labels[g_i]
+            late = self._constant(("late", tuple(early)), [not e for e in early], torch.bool, dev)
+            if n_tr > 0:
+                has = matched_idx >= 0
+                tr_lab = torch.where(has, gt.labels[matched_idx.clamp(min=0)] if len(gt) > 0
+                                     else torch.full_like(matched_idx, self.num_classes),
+                                     torch.full_like(matched_idx, self.num_classes))
+                labels[:, nd:] = torch.where(late[:, None], tr_lab[None, :], labels[:, nd:])
+            use_kernels = clip_ops.fused(logits_all, boxes_all, gt.boxes)
+            if use_kernels:
+                loss_label = loss_label + clip_ops.focal_loss_per_layer(logits_all[:, b, :n_q], labels)
+            else:
+                one_hot = F.one_hot(labels, self.num_classes + 1)[..., :-1].to(logits_all.dtype)
+                loss_label = loss_label + sigmoid_focal_loss_per_layer(logits_all[:, b, :n_q], one_hot)
+
+            # box losses: detect pairs of every layer + tracked pairs of the late layers
+            pair_loss = clip_ops.pair_box_loss if use_kernels else clip_ops.pair_box_loss_reference
+            if n_tr > 0 and len(gt) > 0:
+                # every (layer, track) pair, weight 1 where the layer carries tracks and the track owns a ground truth
+                lay_t = self._constant(("lay_t", n_layers, n_tr), [li for li in range(n_layers) for _ in range(n_tr)],
+                                       torch.long, dev)
+                q_t = self._constant(("q_t", n_layers, n_tr, nd), [nd + j for _ in range(n_layers) for j in range(n_tr)],
+                                     torch.long, dev)
+                w_pair = (has[None, :] & late[:, None]).to(boxes_all.dtype).reshape(-1)
+                g_t = matched_idx.clamp(min=0).repeat(n_layers)
+                l1_t, gi_t = pair_loss(boxes_all, lay_t, q_t, b, gt.boxes, g_t, w_pair)
+                loss_l1 = loss_l1 + l1_t.view(n_layers, n_tr).sum(1)
+                loss_giou = loss_giou + gi_t.view(n_layers, n_tr).sum(1)
+            l1_pair, gi_pair = pair_loss(boxes_all, lay_i, q_i, b, gt.boxes, g_i)
+            loss_l1 = loss_l1.index_add(0, lay_i, l1_pair)
+            loss_giou = loss_giou.index_add(0, lay_i, gi_pair)
 
         fw = self.frame_weights[frame_idx]
         per_layer = torch.stack((loss_l1, loss_giou, loss_label))               # rows in the order of _LOSS_KEYS
@@ -397,14 +424,12 @@ class ClipCriterion:
         self.log[f"frame{frame_idx}_box_l1_loss"] = log[0, 0]
         self.log[f"frame{frame_idx}_box_giou_loss"] = log[1, 0]
         self.log[f"frame{frame_idx}_label_focal_loss"] = log[2, 0]
-        self.n_gts.append(sum(n_gt_list))
         # column 0: the last decoder layer (x frame weight); column 1: the auxiliary layers (x their weights)
         cols = [[fw] + [0.0] * (n_layers - 1)]
         if self._acc.shape[1] == 2:
             cols.append([0.0] + [w * fw for w in self.aux_weights[:n_layers - 1]])
         weights = self._constant(("loss_w", n_layers, fw, self._acc.shape[1]), cols, per_layer.dtype, dev)
         self._acc = self._acc + per_layer @ weights.t()
-        return tracked_instances, new_tracks, unmatched
 
     def update_tracked_instances(self, model_outputs: dict, tracked_instances: List[TrackInstances]):
         """Refresh the carried tracks from their query slots.  Padded slots (other clips of the batch carrying

@@ -280,12 +280,16 @@ class MeMOTR(nn.Module):
         return mask
 
     def postprocess_single_frame(self, previous_tracks: List[TrackInstances], new_tracks: List[TrackInstances],
-                                 unmatched_dets: Optional[List[TrackInstances]], no_augment: bool = False):
-        """Query updating between frames (a float32 island under autocast, like ``decode_frame``)."""
+                                 unmatched_dets: Optional[List[TrackInstances]], no_augment: bool = False,
+                                 frame_slot: int = None, clip_key=None):
+        """Query updating between frames (a float32 island under autocast, like ``decode_frame``).  ``frame_slot`` /
+        ``clip_key``: see ``QueryUpdater.forward`` (the training loop's hipGraph slot of this frame)."""
         if torch.is_autocast_enabled() and os.environ.get("MEMOTR_AUTOCAST_DECODER", "0") != "1":
             with torch.autocast(device_type="cuda", enabled=False):
-                return self.query_updater(previous_tracks, new_tracks, unmatched_dets, no_augment)
-        return self.query_updater(previous_tracks, new_tracks, unmatched_dets, no_augment)
+                return self.query_updater(previous_tracks, new_tracks, unmatched_dets, no_augment,
+                                          frame_slot=frame_slot, clip_key=clip_key)
+        return self.query_updater(previous_tracks, new_tracks, unmatched_dets, no_augment, frame_slot=frame_slot,
+                                  clip_key=clip_key)
 
 
 DATASET_NUM_CLASSES = {"DanceTrack": 1, "SportsMOT": 1, "MOT17": 1, "MOT17_SPLIT": 1, "BDD100K": 8}

@@ -59,46 +59,77 @@ class QueryUpdater(nn.Module):
                 nn.init.xavier_uniform_(p)
 
     def forward(self, previous_tracks: List[TrackInstances], new_tracks: List[TrackInstances],
-                unmatched_dets: Optional[List[TrackInstances]], no_augment: bool = False):
+                unmatched_dets: Optional[List[TrackInstances]], no_augment: bool = False, frame_slot: int = None,
+                clip_key=None):
+        """``frame_slot`` (the frame's index inside its clip) and ``clip_key`` (any object, one per clip) come from the
+        training loop: with them the embedding update replays from the hipGraph pair of that slot
+        (models/updater_graphs.py); without them -- and whenever a capture is not possible -- it runs kernel by kernel."""
         tracks = self.select_active_tracks(previous_tracks, new_tracks, unmatched_dets, no_augment=no_augment)
-        return self.update_tracks_embedding(tracks)
+        return self.update_tracks_embedding(tracks, frame_slot=frame_slot, clip_key=clip_key)
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state.pop("_updater_graphs", None)         # captured hipGraphs are per-process objects
+        return state
+
+    def graphs(self):
+        g = self.__dict__.get("_updater_graphs")
+        if g is None:
+            from .updater_graphs import UpdaterGraphs
+            g = self.__dict__["_updater_graphs"] = UpdaterGraphs(self)
+        return g
 
     # ------------------------------------------------------------------ embedding update
-    def update_tracks_embedding(self, tracks: List[TrackInstances]):
+    FIELDS = ("logits", "boxes", "ref_pts", "output_embed", "long_memory", "last_output", "query_embed")
+
+    def update_fields(self, logits, boxes, ref_pts, out_embed, long_memory_in, last_output, query_embed, key_mask=None):
+        """The update of reference models/query_updater.py:96-158 as a function of the track fields (n rows each):
+        returns the new (ref_pts, long_memory, last_output, query_embed).  ``key_mask`` (1, n) bool marks rows that are
+        padding (the captured form runs on a padded row count): their keys take no part in the memory attention, and
+        nothing else mixes rows."""
         C = self.hidden_dim
         lam = self.long_memory_lambda
-        for t in tracks:
-            scores = torch.max(logits_to_scores(t.logits), dim=1).values
-            is_pos = scores > self.update_threshold
-            pos_col = is_pos.reshape(-1, 1)
-            # (masked assignments of the reference are written as selects: no boolean-index synchronisation)
-            t.ref_pts = torch.where(pos_col, inverse_sigmoid(t.boxes.detach()), t.ref_pts)
+        scores = torch.max(logits_to_scores(logits), dim=1).values
+        is_pos = scores > self.update_threshold
+        pos_col = is_pos.reshape(-1, 1)
+        # (masked assignments of the reference are written as selects: no boolean-index synchronisation)
+        ref_pts = torch.where(pos_col, inverse_sigmoid(boxes.detach()), ref_pts)
 
-            query_pos = self.query_pos_head(pos_to_pos_embed(t.ref_pts.sigmoid(), num_pos_feats=C // 2))
-            out_embed = t.output_embed
-            long_memory = t.long_memory.detach()
+        query_pos = self.query_pos_head(pos_to_pos_embed(ref_pts.sigmoid(), num_pos_feats=C // 2))
+        long_memory = long_memory_in.detach()
 
-            confidence = self.confidence_weight_net(out_embed)
-            short_memory = self.short_memory_fusion(torch.cat((confidence * out_embed, t.last_output), dim=-1))
+        confidence = self.confidence_weight_net(out_embed)
+        short_memory = self.short_memory_fusion(torch.cat((confidence * out_embed, last_output), dim=-1))
 
-            q = (short_memory + query_pos)[None]
-            k = (long_memory + query_pos)[None]
-            attn = memory_attention(self.memory_attn, q, k, out_embed[None])[0]
-            tgt = self.memory_ffn(add_layer_norm(out_embed, self.memory_dropout(attn), self.memory_norm))
-            query_feat = self.query_feat_ffn(add_layer_norm(long_memory, self.query_feat_dropout(tgt),
-                                                            self.query_feat_norm))
+        q = (short_memory + query_pos)[None]
+        k = (long_memory + query_pos)[None]
+        attn = memory_attention(self.memory_attn, q, k, out_embed[None], key_padding_mask=key_mask)[0]
+        tgt = self.memory_ffn(add_layer_norm(out_embed, self.memory_dropout(attn), self.memory_norm))
+        query_feat = self.query_feat_ffn(add_layer_norm(long_memory, self.query_feat_dropout(tgt),
+                                                        self.query_feat_norm))
 
-            new_long = (1 - lam) * long_memory + lam * out_embed
-            t.long_memory = t.long_memory * ~pos_col + new_long * pos_col
-            t.last_output = t.last_output * ~pos_col + out_embed * pos_col
+        new_long = (1 - lam) * long_memory + lam * out_embed
+        new_long_memory = long_memory_in * ~pos_col + new_long * pos_col
+        new_last_output = last_output * ~pos_col + out_embed * pos_col
 
-            if self.use_dab:
-                t.query_embed = torch.where(pos_col, query_feat, t.query_embed)
-            else:
-                refreshed = self.norm_pos(t.query_embed[:, :C]
-                                          + self.linear_pos2(self.activation(self.linear_pos1(out_embed))))
-                t.query_embed = torch.cat((torch.where(pos_col, refreshed, t.query_embed[:, :C]),
-                                           torch.where(pos_col, query_feat, t.query_embed[:, C:])), dim=-1)
+        if self.use_dab:
+            new_query = torch.where(pos_col, query_feat, query_embed)
+        else:
+            refreshed = self.norm_pos(query_embed[:, :C]
+                                      + self.linear_pos2(self.activation(self.linear_pos1(out_embed))))
+            new_query = torch.cat((torch.where(pos_col, refreshed, query_embed[:, :C]),
+                                   torch.where(pos_col, query_feat, query_embed[:, C:])), dim=-1)
+        return ref_pts, new_long_memory, new_last_output, new_query
+
+    def update_tracks_embedding(self, tracks: List[TrackInstances], frame_slot: int = None, clip_key=None):
+        for b, t in enumerate(tracks):
+            fields = tuple(getattr(t, f) for f in self.FIELDS)
+            new = None
+            if frame_slot is not None and self.graphs().usable(fields):
+                new = self.graphs().run((frame_slot, b), fields, clip_key)
+            if new is None:
+                new = self.update_fields(*fields)
+            t.ref_pts, t.long_memory, t.last_output, t.query_embed = new
         return tracks
 
     # ------------------------------------------------------------------ track selection

@@ -58,6 +58,47 @@ class _PackedInProj(torch.autograd.Function):
         return g_in_qk, g_in_v, gw, gb
 
 
+class _PackedInProj3(torch.autograd.Function):
+    """(q W_q^T + b_q, k W_k^T + b_k, v W_v^T + b_v) from the packed parameters for three different inputs (the query
+    updater's memory attention).  One node for the same reason as ``_PackedInProj``: three row slices of the packed
+    weight and bias in the graph cost a zero-fill, a strided copy and an add into the parameter's buffer EACH in the
+    backward (18 small kernels per call); here the three launches write the row slices of one gradient buffer."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, w, b):
+        from ..functions import clip_ops
+        E = w.shape[1]
+        xs = tuple(t.reshape(-1, E) for t in (q, k, v))
+        outs = []
+        for i, x2 in enumerate(xs):
+            wi, bi = w[i * E:(i + 1) * E], b[i * E:(i + 1) * E]
+            y = clip_ops.linear_fwd(x2, wi, bi, False) if clip_ops.linear_fwd_usable(x2, wi, bi) else torch.addmm(bi, x2, wi.t())
+            outs.append(y.view(*(q, k, v)[i].shape[:-1], E))
+        ctx.save_for_backward(*xs, w)
+        ctx.shapes = (q.shape, k.shape, v.shape)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        from ..functions import clip_ops
+        *xs, w = ctx.saved_tensors
+        E = w.shape[1]
+        gw, gb = torch.empty_like(w), torch.empty((3 * E,), dtype=w.dtype, device=w.device)
+        g_in = []
+        for i, (g, x2) in enumerate(zip(grads, xs)):
+            g2 = g.reshape(-1, E)
+            wi, rows = w[i * E:(i + 1) * E], slice(i * E, (i + 1) * E)
+            if clip_ops.linear_bwd_usable(g2, x2, wi):
+                gx = clip_ops.linear_bwd(g2, None, x2, wi, ctx.needs_input_grad[i], True, True, gw_out=gw[rows],
+                                         gb_out=gb[rows])[0]
+            else:
+                torch.mm(g2.t(), x2, out=gw[rows])
+                clip_ops.colsum(g2.contiguous(), out=gb[rows])
+                gx = g2 @ wi if ctx.needs_input_grad[i] else None
+            g_in.append(None if gx is None else gx.view(ctx.shapes[i]))
+        return (*g_in, gw, gb)
+
+
 def self_attention(mha: nn.MultiheadAttention, qk: torch.Tensor, v: torch.Tensor,
                    key_padding_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``mha(qk, qk, v, key_padding_mask=..., need_weights=False)[0]`` for a batch-first module with packed
@@ -112,11 +153,13 @@ def self_attention(mha: nn.MultiheadAttention, qk: torch.Tensor, v: torch.Tensor
     return row_linear(out, mha.out_proj.weight, mha.out_proj.bias)
 
 
-def memory_attention(mha: nn.MultiheadAttention, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+def memory_attention(mha: nn.MultiheadAttention, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
+                     key_padding_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``mha(q, k, v, need_weights=False)[0]`` for batch-first (B, L, E) inputs of one length with three different
     sources (the query updater: short memory + pos, long memory + pos, output embedding; reference
     models/query_updater.py:123-125).  On CUDA fp32 with head_dim 32 the attention itself runs in the hand-written
-    kernels; anything else goes through the module."""
+    kernels; anything else goes through the module.  ``key_padding_mask`` (B, L) bool, True = ignore that key: the
+    padded slots of the captured update (models/updater_graphs.py); the reference call has none."""
     from ..functions import clip_ops
     from .linear import row_linear
     E, H = mha.embed_dim, mha.num_heads
@@ -127,12 +170,16 @@ def memory_attention(mha: nn.MultiheadAttention, q: torch.Tensor, k: torch.Tenso
           and q.dim() == 3 and q.shape == k.shape == v.shape and q.is_cuda and q32.dtype == torch.float32
           and clip_ops.attention_supported(q32, k32, H) and v.is_cuda)
     if not ok:
-        return mha(q, k, v, need_weights=False)[0]
+        return mha(q, k, v, key_padding_mask=key_padding_mask, need_weights=False)[0]
     w, b = mha.in_proj_weight, mha.in_proj_bias
-    q_p = row_linear(q, w[:E], b[:E])
-    k_p = row_linear(k, w[E:2 * E], b[E:2 * E])
-    v_p = row_linear(v, w[2 * E:], b[2 * E:])
+    if (not island and torch.is_grad_enabled() and w.requires_grad and q.dtype == w.dtype == v.dtype == k.dtype
+            and w.is_contiguous() and b.is_contiguous()):
+        q_p, k_p, v_p = _PackedInProj3.apply(q, k, v, w, b)
+    else:
+        q_p = row_linear(q, w[:E], b[:E])
+        k_p = row_linear(k, w[E:2 * E], b[E:2 * E])
+        v_p = row_linear(v, w[2 * E:], b[2 * E:])
     if island:
         q_p, k_p, v_p = q_p.float(), k_p.float(), v_p.float()
-    out = clip_ops.attention(q_p, k_p, v_p, H)
+    out = clip_ops.attention(q_p, k_p, v_p, H, key_padding_mask)
     return row_linear(out, mha.out_proj.weight, mha.out_proj.bias)

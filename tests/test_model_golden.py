@@ -216,7 +216,7 @@ def test_train_step_matches_reference(monkeypatch, chunks):
                          "boxes": t(g[f"gt{i}_boxes"])} for i in range(T)]]}
 
     seen = {}
-    orig = criterion.finish_frame       # both loop orders end a frame here (process_single_frame = finish(begin))
+    orig = criterion.finish_tracks      # both loop orders hand a frame's tracks on here (finish_frame = finish_tracks + finish_losses)
 
     def spy(state):
         res = orig(state)
@@ -225,7 +225,7 @@ def test_train_step_matches_reference(monkeypatch, chunks):
                                     for group in res]
         return res
 
-    criterion.finish_frame = spy
+    criterion.finish_tracks = spy
     # engine.clip_forward_backward: reference order / per-frame encode ahead / all frames in one batched encode / 1+2
     model.encode_chunks = chunks
     loss, loss_dict = clip_forward_backward(model, criterion, batch, torch.device("cpu"), use_dab=True)

@@ -300,13 +300,14 @@ def test_fused_bias_relu_epilogue_is_bit_identical():
 
 
 # ----------------------------------------------------------------------------- decoder hipGraphs
-def _d32_clip_step(monkeypatch, graphs: bool, clip_len=3, seed=0, require=None, **cfg_over):
-    """One clip train step of a D = 32 model (specialised kernels) with the decoder graphs on or off; returns
-    (loss, {param: grad}, decoder graph cache)."""
+def _d32_clip_step(monkeypatch, graphs: bool, clip_len=3, seed=0, require=None, updater_graphs=None, **cfg_over):
+    """One clip train step of a D = 32 model (specialised kernels) with the decoder graphs on or off (and the query
+    updater's with them, unless ``updater_graphs`` says otherwise); returns (loss, {param: grad}, decoder graph cache)."""
     from memotr_amd.engine import clip_forward_backward, make_synthetic_clip, clip_to_device
     from memotr_amd.models.criterion import build as build_criterion
     import memotr_amd.modules.ms_deform_attn as mod
     monkeypatch.setenv("MEMOTR_DECODER_GRAPHS", "1" if graphs else "0")
+    monkeypatch.setenv("MEMOTR_UPDATER_GRAPHS", "1" if (graphs if updater_graphs is None else updater_graphs) else "0")
     monkeypatch.setenv("MEMOTR_REQUIRE_GRAPHS", "1" if (graphs if require is None else require) else "0")
     torch.manual_seed(seed)
     model = build_memotr_cuda(None, hidden=256, ffn=256, NUM_ENC_LAYERS=1, NUM_DEC_LAYERS=2, **cfg_over).train()
@@ -324,7 +325,73 @@ def _d32_clip_step(monkeypatch, graphs: bool, clip_len=3, seed=0, require=None, 
                            torch.device("cuda"))
     loss, _ = clip_forward_backward(model, criterion, batch, torch.device("cuda"))
     grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
-    return float(loss), grads, model.transformer.decoder.graphs()
+    cache = model.transformer.decoder.graphs()
+    cache.updater = model.query_updater.graphs()
+    return float(loss), grads, cache
+
+
+def test_updater_graphs_are_captured_and_match_the_eager_update(monkeypatch):
+    """The query updater's embedding update replayed from its hipGraph pair (models/updater_graphs.py; rows padded to
+    the bucket, padded keys masked out of the memory attention) against the same update kernel by kernel, decoder
+    graphs on in both runs: one capture per frame that hands tracks on (T - 1), same loss, same parameter gradients."""
+    T = 4
+    loss_g, grads_g, cache = _d32_clip_step(monkeypatch, True, clip_len=T)
+    up = cache.updater
+    assert up.captures == T - 1 and up.replays == T - 1 and up.eager == 0 and not up.failed
+    loss_e, grads_e, cache_e = _d32_clip_step(monkeypatch, True, clip_len=T, updater_graphs=False)
+    assert cache_e.updater.captures == 0 and cache_e.updater.replays == 0
+    assert abs(loss_g - loss_e) <= 2e-4 * abs(loss_e), (loss_g, loss_e)
+    assert grads_g.keys() == grads_e.keys()
+    for n in grads_e:
+        denom = float(grads_e[n].norm()) + 1e-6
+        assert float((grads_g[n] - grads_e[n]).norm()) / denom < 2e-2, n
+    for n in grads_e:       # the updater's own parameters: nothing order-dependent between the two runs but the decoder
+        if n.startswith("query_updater."):
+            denom = float(grads_e[n].norm()) + 1e-6
+            assert float((grads_g[n] - grads_e[n]).norm()) / denom < 5e-3, n
+
+
+def test_updater_graph_on_a_padded_track_set_equals_the_eager_update():
+    """``UpdaterGraphs.run`` directly: 5 tracks in a bucket of 16 (11 padded rows, masked as keys), outputs and the
+    gradients of every input field and every parameter against ``update_fields`` on the 5 rows; a second replay with
+    another live count reuses the capture."""
+    from memotr_amd.models.query_updater import build as build_qu
+    torch.manual_seed(5)
+    cfg = small_config()
+    cfg.update(HIDDEN_DIM=256, FFN_DIM=512)
+    qu = build_qu(cfg).cuda().train()
+    C = 256
+
+    def fields(n, seed):
+        g = torch.Generator().manual_seed(seed)
+        widths = (1, 4, 4, C, C, C, C)
+        out = [torch.randn(n, w, generator=g).cuda() for w in widths]
+        out[1] = out[1].sigmoid()                                   # boxes in (0, 1)
+        for i in (3, 4, 5, 6):
+            out[i].requires_grad_(True)
+        return out
+
+    cache = qu.graphs()
+    for n, seed in ((5, 0), (9, 1)):
+        fe, fg = fields(n, seed), fields(n, seed)
+        assert cache.usable(fg)
+        out_g = cache.run((0, 0), fg, clip_key=object())
+        out_e = qu.update_fields(*fe)
+        w = [torch.randn_like(o) for o in out_e]
+        for p in qu.parameters():
+            p.grad = None
+        sum((o * wi).sum() for o, wi in zip(out_e, w)).backward()
+        pe = {k: p.grad.clone() for k, p in qu.named_parameters()}
+        for p in qu.parameters():
+            p.grad = None
+        sum((o * wi).sum() for o, wi in zip(out_g, w)).backward()
+        for a, b in zip(out_g, out_e):
+            torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5)
+        for i in (3, 4, 5, 6):
+            torch.testing.assert_close(fg[i].grad, fe[i].grad, rtol=1e-4, atol=1e-5)
+        for k, p in qu.named_parameters():
+            torch.testing.assert_close(p.grad, pe[k], rtol=1e-4, atol=2e-5, msg=k)
+    assert cache.captures == 1 and cache.replays == 2
 
 
 def test_decoder_graphs_are_captured_and_match_the_eager_loop(monkeypatch):

@@ -60,7 +60,8 @@ phase(model, "encode_frame", "memotr.encode_frame (own ops)")
 phase(model.transformer, "encode", "transformer.encode (own ops)")
 phase(model.transformer, "decode", "transformer.decode (own ops)")
 phase(criterion, "begin_frame", "criterion.begin_frame")
-phase(criterion, "finish_frame", "criterion.finish_frame")
+phase(criterion, "finish_tracks", "criterion.finish_tracks")
+phase(criterion, "finish_losses", "criterion.finish_losses")
 phase(criterion, "get_mean_by_n_gts", "criterion.get_mean_by_n_gts")
 phase(criterion, "get_sum_loss_dict", "criterion.get_sum_loss_dict")
 phase(model, "postprocess_single_frame", "memotr.postprocess_single_frame (own ops)")
