@@ -236,6 +236,22 @@ int msda_fused_backward_out_bf16(const uint16_t *value, const int64_t *shapes_de
                                  int zero_grad_value, const int64_t *shapes_host,
                                  void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- `value` as a slice of a wider tensor (round 6, ABI 7) ----
+ * The reference operator takes a contiguous (N, S, M, D) `value` (ms_deform_attn_cuda.cu:30, AT_ASSERTM contiguous): six
+ * decoder layers that attend to the same memory each project it on their own (reference
+ * models/deformable_decoder.py:303-310 -> ms_deform_attn.py:104: six (S x 256) x (256 x 256) GEMMs per frame, forward;
+ * twelve and five full-size gradient additions backward).  One GEMM with the six weights stacked does the same work in
+ * one launch each way -- if every layer can read ITS 256 columns of the (S x 1536) product in place:
+ *   msda_next_value_pixel_stride(e)  the NEXT forward / backward call of the calling thread (any entry point above)
+ *                        addresses pixel s of batch b at value + (b * S + s) * e (+ m * D + c) instead of
+ *                        (b * S + s) * M * D; in a backward call `grad_value` has the same layout (the slice of the wide
+ *                        gradient tensor that belongs to this layer) and `zero_grad_value` must be 0: the caller zeroes
+ *                        the wide tensor once.  e >= M * D, e * sizeof(element) a multiple of 16; 0 or M * D: contiguous.
+ *                        D = 32 float32 / bfloat16 calls only (the direct-gather forward, the row backward: the kernels the
+ *                        decoder's calls take anyway); anything else returns MSDA_ENOTSUP and the caller passes a
+ *                        contiguous copy.  The setting is consumed by that one call, successful or not. */
+int msda_next_value_pixel_stride(long elements);
+
 /* ---- kernel selection (round 4, records reworked in round 5 = ABI 5, per-site poll = ABI 6; memotr_amd/csrc/msda_select.h) ----
  * The cost of the reference kernels does not depend on where the sampling points land
  * (ms_deform_im2col_cuda.cuh:237-403); the windowed kernels here are fast for points near their query and slow

@@ -227,6 +227,20 @@ def _fused_dims(value, spatial_shapes, level_start_index, proj, ref, pad_mask, n
     return N, S, M, D, L, Lq, P
 
 
+def value_pixel_stride(value):
+    """How a (N, S, M, D) ``value`` reaches the kernels: 0 -- contiguous; e > 0 -- in place with e elements between
+    pixels (rows that are a slice of a wider projection: include/msda_hip.h, msda_next_value_pixel_stride); None -- neither,
+    the caller makes a contiguous copy."""
+    if value.is_contiguous():
+        return 0
+    N, S, M, D = value.shape
+    st = value.stride()
+    if (D == 32 and st[3] == 1 and st[2] == D and st[1] >= M * D and (N == 1 or st[0] == S * st[1])
+            and (st[1] * value.element_size()) % 16 == 0 and value.data_ptr() % 16 == 0):
+        return int(st[1])
+    return None
+
+
 def _fused_suffix(value):
     suf = {torch.float32: "f32", torch.bfloat16: "bf16"}.get(value.dtype)
     if suf is None:
@@ -243,8 +257,15 @@ def ms_deform_attn_fused_forward(value, spatial_shapes, level_start_index, proj,
                                  n_heads, n_points):
     """-> output (N, Lq, M*D) from the raw query projection [offsets | logits], the reference points and the
     padding mask of ``value`` (softmax, location arithmetic and mask fill in-kernel)."""
-    named = [("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
+    vstride = value_pixel_stride(value) if value.dim() == 4 else 0
+    if vstride is None:
+        value, vstride = value.contiguous(), 0
+    named = [("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
              ("proj", proj), ("reference_points", reference_points)]
+    if not vstride:
+        named.insert(0, ("value", value))
+    elif not value.is_cuda:
+        raise RuntimeError("Not implemented on the CPU")
     if pad_mask is not None:
         named.append(("padding_mask", pad_mask))
     _check_inputs(named)
@@ -255,7 +276,9 @@ def ms_deform_attn_fused_forward(value, spatial_shapes, level_start_index, proj,
         output = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
         if output.numel() == 0:
             return output
-        keep, hptr = _host_ptr(spatial_shapes, D == 32 and Lq == S and L <= 4)
+        keep, hptr = _host_ptr(spatial_shapes, D == 32 and Lq == S and L <= 4 and not vstride)
+        if vstride:
+            _lib.lib.msda_next_value_pixel_stride(vstride)
         rc = getattr(_lib.lib, f"msda_fused_forward_{suf}")(
             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), proj.data_ptr(),
             proj.shape[2], reference_points.data_ptr(), reference_points.shape[3],
@@ -269,12 +292,25 @@ def ms_deform_attn_fused_forward(value, spatial_shapes, level_start_index, proj,
 
 
 def ms_deform_attn_fused_backward(value, spatial_shapes, level_start_index, proj, reference_points, pad_mask,
-                                  grad_output, n_heads, n_points, need_ref_grad=False, fwd_output=None):
+                                  grad_output, n_heads, n_points, need_ref_grad=False, fwd_output=None,
+                                  grad_value_out=None):
     """-> [grad_value, grad_proj, grad_reference_points | None].  ``fwd_output``: the tensor the fused forward of the same
     call returned, when the caller still holds it (an autograd function does): the encoder's backward is then one kernel
-    (include/msda_hip.h, msda_fused_backward_out_*)."""
-    named = [("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
+    (include/msda_hip.h, msda_fused_backward_out_*).  ``grad_value_out``: for a ``value`` that is a slice of a wider
+    tensor (``value_pixel_stride`` > 0) the float32 slice of the wide gradient tensor that belongs to it -- same shape and
+    strides, already zeroed by the caller; the gradient is accumulated there and that tensor is returned."""
+    vstride = value_pixel_stride(value) if value.dim() == 4 else 0
+    if vstride and (grad_value_out is None or grad_value_out.dtype != torch.float32 or not grad_value_out.is_cuda
+                    or grad_value_out.shape != value.shape or grad_value_out.stride() != value.stride()):
+        vstride = None
+    if vstride is None or (not vstride and grad_value_out is not None):
+        value, vstride, grad_value_out = value.contiguous(), 0, None
+    named = [("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
              ("proj", proj), ("reference_points", reference_points), ("grad_output", grad_output)]
+    if not vstride:
+        named.insert(0, ("value", value))
+    elif not value.is_cuda:
+        raise RuntimeError("Not implemented on the CPU")
     if pad_mask is not None:
         named.append(("padding_mask", pad_mask))
     _check_inputs(named)
@@ -285,7 +321,10 @@ def ms_deform_attn_fused_backward(value, spatial_shapes, level_start_index, proj
         raise RuntimeError("grad_output must match the forward output (N, Lq, M*D) and value's dtype")
     with torch.cuda.device(value.device):
         # (zeroed by the library, `zero_grad_value`, next to whatever else its chosen kernels want cleared)
-        grad_value = (torch.empty if grad_output.numel() else torch.zeros)(value.shape, dtype=torch.float32, device=value.device)
+        if vstride:
+            grad_value = grad_value_out
+        else:
+            grad_value = (torch.empty if grad_output.numel() else torch.zeros)(value.shape, dtype=torch.float32, device=value.device)
         used = 3 * M * L * P
         grad_proj = (torch.empty_like(proj) if proj.shape[2] == used else torch.zeros_like(proj))
         ref_part = None
@@ -294,7 +333,7 @@ def ms_deform_attn_fused_backward(value, spatial_shapes, level_start_index, proj
         if grad_output.numel() == 0:
             gref = ref_part.sum(2) if ref_part is not None else None
             return [grad_value.to(value.dtype), grad_proj, gref]
-        keep, hptr = _host_ptr(spatial_shapes, D == 32 and Lq == S and L <= 4 and not need_ref_grad)
+        keep, hptr = _host_ptr(spatial_shapes, D == 32 and Lq == S and L <= 4 and not need_ref_grad and not vstride)
         # scratch: the three-kernel form of the region-tiled backward (the prologue materialised once per row) and, for
         # sampling points far from their queries, the records of the sort + gather form of grad_value
         stream = _stream(value.device)
@@ -303,18 +342,20 @@ def ms_deform_attn_fused_backward(value, spatial_shapes, level_start_index, proj
         if fwd_output is not None and not (fwd_output.is_contiguous() and fwd_output.dtype == value.dtype
                                            and fwd_output.numel() == grad_output.numel()):
             fwd_output = None
+        if vstride:
+            _lib.lib.msda_next_value_pixel_stride(vstride)
         rc = getattr(_lib.lib, f"msda_fused_backward_out_{suf}")(
             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), proj.data_ptr(),
             proj.shape[2], reference_points.data_ptr(), reference_points.shape[3],
             pad_mask.data_ptr() if pad_mask is not None else None, grad_output.data_ptr(),
             fwd_output.data_ptr() if fwd_output is not None else None, N, S, M, D, L, Lq, P,
-            grad_value.data_ptr(), grad_proj.data_ptr(), ref_part.data_ptr() if ref_part is not None else None, 1,
-            hptr, ws.data_ptr() if ws is not None else None, ws_bytes, stream)
+            grad_value.data_ptr(), grad_proj.data_ptr(), ref_part.data_ptr() if ref_part is not None else None,
+            0 if vstride else 1, hptr, ws.data_ptr() if ws is not None else None, ws_bytes, stream)
         del keep, ws
     if rc != 0:
         _raise(rc, "ms_deform_attn_fused_backward")
     LAST_KERNEL["backward"] = _lib.last_kernel()
-    if grad_value.dtype != value.dtype:
+    if grad_value.dtype != value.dtype and not vstride:       # (a strided call's gradient stays in the caller's fp32 bank)
         grad_value = grad_value.to(value.dtype)
     return [grad_value, grad_proj, ref_part.sum(2) if ref_part is not None else None]
 

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MEMOTR_MSDA_LIB") or os.path.join(_HERE, "lib", "libmsda_hip.so")   # (override: A/B builds)
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 c_int = ctypes.c_int
 c_void_p = ctypes.c_void_p
@@ -57,6 +57,7 @@ SYMBOLS = {
     "msda_selector_next": ([c_int] * 4, c_int),
     "msda_selector_poll": ([ctypes.POINTER(ctypes.c_uint64)], c_int),
     "msda_selector_poll_sites": ([ctypes.POINTER(ctypes.c_uint64), c_int, c_int, ctypes.POINTER(ctypes.c_uint64)], c_int),
+    "msda_next_value_pixel_stride": ([ctypes.c_long], c_int),
     "msda_selector_reset": ([], c_int),
     "msda_set_option": ([ctypes.c_char_p, c_int], c_int),
     "msda_get_option": ([ctypes.c_char_p, ctypes.POINTER(c_int)], c_int),

@@ -58,7 +58,9 @@ __global__ __launch_bounds__(256) void msda_bwd_d32_rows(
     const PointSrc fs, const TV *__restrict__ grad_out, int N, int S, int M, int L, int Lq, int P,
     float *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_attn,
     float *__restrict__ grad_proj, float *__restrict__ grad_ref_part, unsigned value_bytes, unsigned gv_bytes,
-    unsigned *__restrict__ zero = nullptr, unsigned zero_n = 0u) {
+    unsigned *__restrict__ zero = nullptr, unsigned zero_n = 0u, unsigned pix_elems = 0u) {
+    // pix_elems: elements between two pixels of `value` AND of `grad_value` (0: M * D, contiguous tensors); larger when
+    // both are slices of a wider projection and of its gradient (msda_next_value_pixel_stride)
     constexpr unsigned D = 32;
     if (!ATOMICS && zero != nullptr)
         for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < zero_n; i += gridDim.x * blockDim.x) zero[i] = 0u;
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(256) void msda_bwd_d32_rows(
     const int LP = L * P;
     const int slot = threadIdx.x >> 5, c = threadIdx.x & 31;
     const unsigned n_rows = (unsigned)N * (unsigned)Lq * (unsigned)M;
-    const unsigned row_elems = (unsigned)M * D;
+    const unsigned row_elems = pix_elems ? pix_elems : (unsigned)M * D;
     const __amdgpu_buffer_rsrc_t vr = make_rsrc(value, value_bytes);
     const __amdgpu_buffer_rsrc_t gr = make_rsrc(grad_value, gv_bytes);
     u32x4 (*rec)[2] = s_rec[slot];
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(256) void msda_bwd_d32_rows(
                 ok3 = ok3 && !mk[ok3 ? p00 + W : 0];
                 ok4 = ok4 && !mk[ok4 ? p00 + W + 1 : 0];
             }
-            const unsigned e1 = ((b * (unsigned)S + (unsigned)(s_start[l] + h0 * W + w0)) * (unsigned)M + (unsigned)m) * D;
+            const unsigned e1 = (b * (unsigned)S + (unsigned)(s_start[l] + h0 * W + w0)) * row_elems + (unsigned)m * D;
             u32x4 off, w;
             off.x = ok1 ? e1 : kRowsOobElem;
             off.y = ok2 ? e1 + row_elems : kRowsOobElem;

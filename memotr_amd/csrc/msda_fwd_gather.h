@@ -54,8 +54,8 @@ __device__ __forceinline__ void store_row16<bf16_t>(bf16_t *dst, const float *ac
 template <typename TV, bool FUSED>
 __device__ __forceinline__ void stage_records_fwd(u32x4 *rec, const PointSrc &src, unsigned pmc, unsigned qrow, int m,
                                                   bool row_ok, int sub, int L, int P, int M, int S, int b,
-                                                  unsigned row_base, const int *s_H, const int *s_W,
-                                                  const int *s_start) {
+                                                  unsigned row_base, unsigned pix_stride, const int *s_H,
+                                                  const int *s_W, const int *s_start) {
     constexpr int LANES = RowGeom<TV>::kLanes;
     constexpr unsigned ROWB = RowGeom<TV>::kRowBytes;
     const int LP = L * P;
@@ -101,7 +101,6 @@ __device__ __forceinline__ void stage_records_fwd(u32x4 *rec, const PointSrc &sr
             ok10 = ok10 && !mk[ok10 ? p00 + W : 0];
             ok11 = ok11 && !mk[ok11 ? p00 + W + 1 : 0];
         }
-        const unsigned pix_stride = (unsigned)M * ROWB;
         const unsigned o00 = row_base + (unsigned)(s_start[l] + h0 * W + w0) * pix_stride;
         u32x4 off;
         off.x = ok00 ? o00 : kOobOffset;
@@ -153,7 +152,10 @@ template <int PTS, typename TV, bool FUSED>
 __global__ __launch_bounds__(256) void msda_fwd_d32_gather(
     const TV *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ lstart,
     const PointSrc src, int N, int S, int M, int L, int Lq, int P, TV *__restrict__ out, unsigned value_bytes,
-    int head_major) {
+    int head_major, unsigned pix_bytes) {
+    // pix_bytes: bytes between two pixels of `value` -- M * D * sizeof(TV) for a contiguous (N, S, M, D) tensor, more when
+    // the rows are a slice of a wider projection (msda_next_value_pixel_stride, round 6: the decoder layers' six value
+    // projections as ONE GEMM whose output each layer reads in place)
     constexpr int D = 32;
     constexpr int LANES = RowGeom<TV>::kLanes, ROWS = RowGeom<TV>::kRows, CH = RowGeom<TV>::kCh;
     __shared__ int s_H[kMaxLevels], s_W[kMaxLevels], s_start[kMaxLevels];
@@ -193,8 +195,8 @@ __global__ __launch_bounds__(256) void msda_fwd_d32_gather(
         const unsigned qrow = pmc / (unsigned)M;
         const int m = (int)(pmc - qrow * (unsigned)M);
         const int b = (int)(qrow / (unsigned)Lq);
-        const unsigned row_base = ((unsigned)b * (unsigned)S * (unsigned)M + (unsigned)m) * (D * (unsigned)sizeof(TV));
-        stage_records_fwd<TV, FUSED>(rec, src, pmc, qrow, m, row_ok, sub, L, P, M, S, b, row_base, s_H, s_W, s_start);
+        const unsigned row_base = (unsigned)b * (unsigned)S * pix_bytes + (unsigned)m * (D * (unsigned)sizeof(TV));
+        stage_records_fwd<TV, FUSED>(rec, src, pmc, qrow, m, row_ok, sub, L, P, M, S, b, row_base, pix_bytes, s_H, s_W, s_start);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         float acc[CH];

@@ -283,6 +283,14 @@ unsigned long long *g_sel_pool_host[64] = {nullptr}, *g_sel_pool_host_dev[64] = 
 bool g_sel_pool_failed[64] = {false};
 unsigned long long g_sel_clock = 0, g_sel_tick = 0;
 thread_local unsigned long long g_site = 0;
+// msda_next_value_pixel_stride: elements between two pixels of `value` (and of `grad_value`) for the NEXT forward /
+// backward call of this thread (0: contiguous, M * D).  Read once -- by that call, whatever its outcome -- and cleared.
+thread_local long g_value_stride = 0;
+inline long take_value_stride() {
+    const long v = g_value_stride;
+    g_value_stride = 0;
+    return v;
+}
 thread_local int g_sel_level = 0;           // level of this thread's last selected call (msda_selector_last)
 thread_local float g_sel_frac = -1.f, g_sel_inner = -1.f;
 
@@ -502,6 +510,7 @@ template <typename TV, typename TC>
 int forward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart, const TC *loc, const TC *attn,
                  const FusedArgs &fa, int N, int S, int M, int D, int L, int Lq, int P, TV *out,
                  const int64_t *shapes_host, hipStream_t stream) {
+    const long vstride = take_value_stride();
     const bool fused = fa.proj != nullptr;
     int rc = fused ? check_dims(value, shapes, lstart, fa.proj, fa.ref, out, N, S, M, D, L, Lq, P)
                    : check_dims(value, shapes, lstart, loc, attn, out, N, S, M, D, L, Lq, P);
@@ -509,10 +518,19 @@ int forward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart, 
     if (fused && (rc = check_fused(fa, M, L, P))) return rc;
     if ((long)N * Lq == 0) { g_err[0] = 0; return MSDA_OK; }
     int variant = opt_fwd_variant.load();
-    const long value_elems = (long)N * S * M * D;
-    const long value_bytes = value_elems * (long)sizeof(TV);
     constexpr bool kD32Type = sizeof(TC) == 4 && (sizeof(TV) == 4 || sizeof(TV) == 2);
+    // `value` as a slice of a wider tensor (msda_next_value_pixel_stride): the gather kernel only -- the call sites that
+    // use it are the decoder's (a few hundred queries), which take that kernel anyway
+    const bool strided = vstride != 0 && vstride != (long)M * D;
+    const long value_elems = strided ? (long)N * S * vstride : (long)N * S * M * D;
+    const long value_bytes = value_elems * (long)sizeof(TV);
     const bool can32 = kD32Type && d32_ok(D, L, value_elems);
+    if (strided) {
+        if (vstride < (long)M * D || (vstride * (long)sizeof(TV)) % 16 != 0)
+            return fail(MSDA_EINVAL, "value pixel stride: at least M * D elements, rows 16-byte aligned");
+        if (!can32) return fail(MSDA_ENOTSUP, "value pixel stride: D = 32 float32 / bfloat16 calls only");
+        variant = 3;
+    }
     SelSlot *slot = nullptr;
     int sel = 0;
     bool sel_head_major = false;
@@ -687,7 +705,8 @@ int forward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart, 
     do {                                                                                                             \
         g_kernel = NAME;                                                                                             \
         hipLaunchKernelGGL((msda_fwd_d32_gather<PTS, TV, FU>), dim3(grid), dim3(use_block), lds, stream, value,      \
-                           shapes, lstart, src, N, S, M, L, Lq, P, out, (unsigned)value_bytes, head_major);          \
+                           shapes, lstart, src, N, S, M, L, Lq, P, out, (unsigned)value_bytes, head_major,          \
+                           (unsigned)((strided ? vstride : (long)M * D) * (long)sizeof(TV)));                         \
     } while (0)
         // (four points = 16 corner rows in flight per lane: the best of the round-1 sweep, profiles/r01_kbench_fwd_sweep.txt;
         //  the 1- and 2-point instantiations went in round 5 -- variants 2, 3, 4 all mean this kernel)
@@ -705,6 +724,7 @@ int backward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart,
                   TG *grad_value, TC *grad_loc, TC *grad_attn, float *grad_proj, float *grad_ref_part,
                   int zero_grad_value, const int64_t *shapes_host, hipStream_t stream, float *workspace = nullptr,
                   size_t workspace_bytes = 0, const TV *fwd_out = nullptr) {
+    const long vstride = take_value_stride();
     const bool fused = fa.proj != nullptr;
     // `fwd_out` (round 6): the forward's output of the same call, when the caller still holds it.  sum_j a_j ga_j of the
     // softmax Jacobian IS <grad_out_row, out_row>, so with it the counting-sort backward needs no side kernel
@@ -733,12 +753,23 @@ int backward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart,
                            reinterpret_cast<unsigned *>(grad_value), n1, extra, extra_n);
         return check_launch("msda_zero_words_kernel");
     };
+    // `value` and `grad_value` as slices of wider tensors (msda_next_value_pixel_stride): the rows kernel only, and the
+    // caller owns the zeroing of the whole gradient tensor
+    const bool strided = vstride != 0 && vstride != (long)M * D;
+    if (strided && zero_grad_value) return fail(MSDA_EINVAL, "value pixel stride: grad_value is the caller's to zero");
     if ((long)N * Lq == 0) return zero_launch(nullptr, 0u);
     int variant = opt_bwd_variant.load();
-    const long value_elems = (long)N * S * M * D;
+    const long value_elems = strided ? (long)N * S * vstride : (long)N * S * M * D;
     const long value_bytes = value_elems * (long)sizeof(TV);
     constexpr bool kD32Type = sizeof(TC) == 4 && sizeof(TG) == 4 && (sizeof(TV) == 4 || sizeof(TV) == 2);
-    const bool can_tile = kD32Type && d32_ok(D, L, value_elems) && shapes_host && Lq == S && L <= kTileMaxL &&
+    if (strided) {
+        if (vstride < (long)M * D || (vstride * (long)sizeof(TV)) % 16 != 0)
+            return fail(MSDA_EINVAL, "value pixel stride: at least M * D elements, rows 16-byte aligned");
+        if (!(kD32Type && d32_ok(D, L, value_elems) && L * P <= kRowsMaxLP && (long)N * Lq * M < (1L << 31)))
+            return fail(MSDA_ENOTSUP, "value pixel stride: D = 32 float32 / bfloat16 calls of at most 64 points only");
+        variant = 3;        // (any value the pyramid / sorted branches do not claim: straight to the rows kernel)
+    }
+    const bool can_tile = !strided && kD32Type && d32_ok(D, L, value_elems) && shapes_host && Lq == S && L <= kTileMaxL &&
                           grad_ref_part == nullptr;
     // Measured on MI355X (profiles/): per-contribution global float atomics cap the backward at ~1.1 ms
     // for the encoder call (L2 atomic throughput; the row-per-block kernel's 32-consecutive-lane pattern
@@ -1027,8 +1058,8 @@ int backward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart,
         // few-query calls at D = 32 (the decoder's cross-attention): 32 lanes per row, grad_value atomics in whole
         // 128-byte rows, four points in flight (msda_bwd_rows.h)
         const int requested = opt_bwd_variant.load();      // 1 = the generic kernel, explicitly
-        if (d32_ok(D, L, value_elems) && L * P <= kRowsMaxLP && opt_bwd_rows.load() != 0 && n_rows < (1L << 31) &&
-            requested != 1) {
+        if (d32_ok(D, L, value_elems) && L * P <= kRowsMaxLP && (opt_bwd_rows.load() != 0 || strided) && n_rows < (1L << 31) &&
+            (requested != 1 || strided)) {
             const PointSrc src = make_src(loc, attn, fa, M, L, P);
             // a row is a chain of dependent round trips (stage -> loads -> atomics -> reductions): small calls get one
             // wavefront (two rows) per workgroup so that every CU holds several chains
@@ -1042,12 +1073,14 @@ int backward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart,
                 g_kernel = b16 ? "msda_bwd_d32_rows<bf16,fused>" : "msda_bwd_d32_rows<fused>";
                 hipLaunchKernelGGL((msda_bwd_d32_rows<TV, true>), dim3(grid), dim3(threads), 0, stream, value, shapes, lstart,
                                    src, grad_out, N, S, M, L, Lq, P, (float *)grad_value, (float *)nullptr,
-                                   (float *)nullptr, grad_proj, grad_ref_part, (unsigned)value_bytes, gv_bytes);
+                                   (float *)nullptr, grad_proj, grad_ref_part, (unsigned)value_bytes, gv_bytes,
+                                   (unsigned *)nullptr, 0u, (unsigned)(strided ? vstride : 0));
             } else {
                 g_kernel = b16 ? "msda_bwd_d32_rows<bf16>" : "msda_bwd_d32_rows";
                 hipLaunchKernelGGL((msda_bwd_d32_rows<TV, false>), dim3(grid), dim3(threads), 0, stream, value, shapes, lstart,
                                    src, grad_out, N, S, M, L, Lq, P, (float *)grad_value, (float *)grad_loc,
-                                   (float *)grad_attn, (float *)nullptr, (float *)nullptr, (unsigned)value_bytes, gv_bytes);
+                                   (float *)grad_attn, (float *)nullptr, (float *)nullptr, (unsigned)value_bytes, gv_bytes,
+                                   (unsigned *)nullptr, 0u, (unsigned)(strided ? vstride : 0));
             }
             return check_launch(g_kernel);
         }
@@ -1076,9 +1109,15 @@ int backward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart,
 
 extern "C" {
 
-int msda_abi_version(void) { return 6; }
+int msda_abi_version(void) { return 7; }
 
 void msda_set_call_site(uint64_t site) { g_site = site; }
+
+int msda_next_value_pixel_stride(long elements) {
+    if (elements < 0) return fail(MSDA_EINVAL, "msda_next_value_pixel_stride: negative stride");
+    g_value_stride = elements;
+    return MSDA_OK;
+}
 
 int msda_selector_last(int *level, float *off_share, float *inner_share) {
     if (level) *level = g_sel_level;

@@ -1,1 +1,2 @@
-from .ms_deform_attn_func import MSDeformAttnFunction, MSDeformAttnFusedFunction  # noqa: F401
+from .ms_deform_attn_func import (BankSlices, MSDeformAttnFunction, MSDeformAttnFusedFunction,  # noqa: F401
+                                  ValueBank)

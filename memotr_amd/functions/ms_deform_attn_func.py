@@ -55,9 +55,10 @@ class MSDeformAttnFusedFunction(Function):
 
     @staticmethod
     def forward(ctx, value, value_spatial_shapes, value_level_start_index, proj, reference_points, padding_mask,
-                n_heads, n_points, zero_rows=None):
+                n_heads, n_points, zero_rows=None, bank=None):
         ctx.n_heads, ctx.n_points = int(n_heads), int(n_points)
         ctx.zero_rows = zero_rows
+        ctx.bank = bank          # (ValueBank, index): ``value`` is slice ``index`` of a wider projection (below)
         ctx.site = MSDA.get_call_site()
         ctx.shapes_host = getattr(value_spatial_shapes, "_msda_host", None)
         output = MSDA.ms_deform_attn_fused_forward(value, value_spatial_shapes, value_level_start_index, proj,
@@ -76,10 +77,56 @@ class MSDeformAttnFusedFunction(Function):
         if ctx.shapes_host is not None and getattr(shapes, "_msda_host", None) is None:
             shapes._msda_host = (ctx.shapes_host[0], shapes._version)
         MSDA.set_call_site(ctx.site)
+        gv_out = None
+        if ctx.bank is not None and MSDA.value_pixel_stride(value):
+            gv_out = ctx.bank[0].grad_slice(value, ctx.bank[1])
         grad_value, grad_proj, grad_ref = MSDA.ms_deform_attn_fused_backward(
             value, shapes, level_start, proj, reference_points, padding_mask, grad_output.contiguous(), ctx.n_heads,
-            ctx.n_points, need_ref_grad=ctx.needs_input_grad[4], fwd_output=output)
+            ctx.n_points, need_ref_grad=ctx.needs_input_grad[4], fwd_output=output, grad_value_out=gv_out)
         MSDA.set_call_site(0)
         if ctx.zero_rows is not None and ctx.zero_rows.numel():
             grad_value.view(-1, grad_value.shape[-2] * grad_value.shape[-1]).index_fill_(0, ctx.zero_rows, 0)
-        return grad_value, None, None, grad_proj, grad_ref, None, None, None, None
+        return grad_value, None, None, grad_proj, grad_ref, None, None, None, None, None
+
+
+class ValueBank:
+    """The gradient side of ONE projection shared by G attention modules (``BankSlices``): the first backward among
+    them makes the zeroed float32 (N, S, G, M, D) tensor, every module's operator accumulates into its own slice, and
+    ``BankSlices.backward`` hands the whole tensor on -- no per-module gradient tensors, no additions."""
+
+    def __init__(self, groups: int):
+        self.groups = int(groups)
+        self.grad = None
+
+    def grad_slice(self, value, index: int):
+        N, S, M, D = value.shape
+        if self.grad is None:
+            self.grad = torch.zeros((N, S, self.groups, M, D), dtype=torch.float32, device=value.device)
+        return self.grad[:, :, index]
+
+
+class BankSlices(Function):
+    """``value_all`` (N, S, G, M, D) -> its G slices (N, S, M, D) as views (rows of a wider projection, read in place by
+    the kernels: include/msda_hip.h, msda_next_value_pixel_stride).  Backward: when every incoming gradient is the
+    matching slice of the bank's tensor, that tensor IS the gradient; otherwise the slices are stacked."""
+
+    @staticmethod
+    def forward(ctx, value_all, bank):
+        ctx.bank = bank
+        ctx.dtype = value_all.dtype
+        return tuple(value_all.unbind(2))
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *grads):
+        bank = ctx.bank
+        whole, bank.grad = bank.grad, None
+        if whole is not None and len(grads) == whole.shape[2] and all(
+                g is not None and g.dtype == whole.dtype and g.shape == whole[:, :, i].shape
+                and g.data_ptr() == whole[:, :, i].data_ptr() and g.stride() == whole[:, :, i].stride()
+                for i, g in enumerate(grads)):
+            return whole.to(ctx.dtype), None
+        like = next((g for g in grads if g is not None), None)
+        if like is None:
+            return None, None
+        return torch.stack([torch.zeros_like(like) if g is None else g.to(like.dtype) for g in grads], dim=2).to(ctx.dtype), None

@@ -63,6 +63,9 @@ class DecoderLoop(nn.Module):
 
     def forward(self, output, reference_points, src, ratios4, query_mask, src_padding_mask):
         outs, refs, layer_inputs, boxes = [], [], [], []
+        from ..modules.ms_deform_attn import project_values
+        # the six value projections of `src` as one GEMM, each layer reading its columns in place
+        values = project_values([layer.cross_attn for layer in self.layers], src, src_padding_mask)
         for lid, layer in enumerate(self.layers):
             layer_inputs.append(output)
             ref_in = reference_points[:, :, None] * ratios4
@@ -70,7 +73,8 @@ class DecoderLoop(nn.Module):
             raw_pos = self.ref_point_head(anchor)
             query_pos = raw_pos if lid == 0 else self.query_scale(output) * raw_pos
             merge = lid >= self.merge_from
-            output = layer(output, query_pos, ref_in, src, self._shapes, self._lsi, query_mask, src_padding_mask, merge)
+            output = layer(output, query_pos, ref_in, src, self._shapes, self._lsi, query_mask, src_padding_mask, merge,
+                           None if values is None else values[lid])
             new_ref = refine_boxes(self.bbox_embed[lid](output), reference_points)
             boxes.append(new_ref)
             if merge:
@@ -117,9 +121,19 @@ def _thread_local_capture(census=None):
 
             torch.cuda.CUDAGraph = _KeepGraph
         torch.cuda.graph = _Graph
+        # No cyclic garbage collection while a capture is open: a collection that happens to run then may finalise a
+        # hipGraph of an EARLIER capture (a refused one, an evicted cache entry still held by a reference cycle or a
+        # traceback), and releasing its memory pool under an open capture aborts the process (seen in round 6: the
+        # query updater's capture right after a refused decoder capture).  Garbage is collected before, outside.
+        import gc
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
         try:
             yield
         finally:
+            if gc_was_on:
+                gc.enable()
             torch.cuda.graph = orig
             torch.cuda.CUDAGraph = orig_graph_cls
 

@@ -7,6 +7,7 @@ import torch.nn as nn
 from torch.utils.checkpoint import checkpoint
 
 from ..modules import MSDeformAttn
+from ..modules.ms_deform_attn import project_values
 from ..functions.clip_ops import add_layer_norm
 from ..modules.attention import self_attention
 from ..modules.linear import row_linear
@@ -111,6 +112,10 @@ class DeformableDecoder(nn.Module):
         outs, refs, layer_inputs, boxes = [], [], [], []
         ref_backup = None
         ratios4 = torch.cat([src_valid_ratios, src_valid_ratios], -1)[:, None]      # same for every layer
+        # the layers' value projections of `src` as one GEMM (modules/ms_deform_attn.py: project_values); None: each
+        # layer projects for itself (CPU, autocast, other head sizes; checkpointed layers recompute on their own)
+        values = None if self.use_checkpoint else project_values([layer.cross_attn for layer in self.layers], src,
+                                                                 src_padding_mask)
         for lid, layer in enumerate(self.layers):
             if lid == 0 and not self.use_dab:        # Deformable-DETR variant: 2-d references
                 ref_backup = reference_points.clone()
@@ -131,7 +136,7 @@ class DeformableDecoder(nn.Module):
                                     query_mask, src_padding_mask, merge, use_reentrant=False)
             else:
                 output = layer(output, query_pos, ref_in, src, src_spatial_shapes, src_level_start_index, query_mask,
-                               src_padding_mask, merge)
+                               src_padding_mask, merge, None if values is None else values[lid])
             if self.bbox_embed is not None:
                 delta = self.bbox_embed[lid](output)
                 if reference_points.shape[-1] == 4:
@@ -214,7 +219,7 @@ class DeformableDecoderLayer(nn.Module):
         return add_layer_norm(tgt, self.dropout4(row_linear(hidden, self.linear2.weight, self.linear2.bias)), self.norm3)
 
     def forward(self, tgt, query_pos, reference_points, src, src_spatial_shapes, level_start_index, query_mask,
-                src_padding_mask=None, merge_det_track=False):
+                src_padding_mask=None, merge_det_track=False, value=None):
         nd = self.n_det_queries
         track_tgt = None
         if not merge_det_track:   # early layers see the detect queries only
@@ -226,7 +231,7 @@ class DeformableDecoderLayer(nn.Module):
             tgt = self.forward_track_attn(tgt, query_pos, query_mask)
         tgt = self.forward_self_attn(tgt, query_pos, query_mask)
         cross = self.cross_attn(self.with_pos_embed(tgt, query_pos), reference_points, src, src_spatial_shapes,
-                                level_start_index, src_padding_mask)
+                                level_start_index, src_padding_mask, value)
         tgt = add_layer_norm(tgt, self.dropout1(cross), self.norm1)
         tgt = self.forward_ffn(tgt)
         if track_tgt is not None:

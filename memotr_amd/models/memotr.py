@@ -104,6 +104,7 @@ class MeMOTR(nn.Module):
         state = self.__dict__.copy()
         state.pop("_encode_graphs", None)          # captured hipGraphs are per-process objects
         state.pop("_infer_graphs", None)
+        state.pop("_cls_stack", None)              # per-clip cache of the class heads' stacked parameters
         return state
 
     def infer_graphs(self):
@@ -158,6 +159,20 @@ class MeMOTR(nn.Module):
             masks.append(mask)
         return self.transformer.encode(srcs=srcs, masks=masks, pos_embeds=pos, geometry=getattr(frame, "sizes", None))
 
+    def _class_head_stack(self, clip_key):
+        """The class heads' weights (n, C, K) and biases (n, 1, K) as two stacks.  With a ``clip_key`` (the training
+        loop's per-clip object) the stacks are made once per clip and shared by its frames: the frames' gradients then
+        meet in one add per frame and the stack's backward (twelve slices handed to the parameters) runs once per
+        clip, not once per frame."""
+        cache = self.__dict__.get("_cls_stack")
+        if clip_key is not None and cache is not None and cache[0] is clip_key and cache[3] == torch.is_grad_enabled():
+            return cache[1], cache[2]
+        w = torch.stack([m.weight for m in self.class_embed]).transpose(1, 2)
+        b = torch.stack([m.bias for m in self.class_embed])[:, None, :]
+        if clip_key is not None:
+            self.__dict__["_cls_stack"] = (clip_key, w, b, torch.is_grad_enabled())
+        return w, b
+
     def decode_frame(self, encoded: dict, tracks: List[TrackInstances]) -> dict:
         """Query assembly -> decoder -> heads over an ``encode_frame`` result.
 
@@ -188,8 +203,7 @@ class MeMOTR(nn.Module):
         n_lvl, B_, Nq_, C_ = outputs.shape
         batched_heads = reuse and all(isinstance(m, nn.Linear) for m in self.class_embed)
         if batched_heads:      # the per-layer class heads as ONE batched product (6 x {GEMM, bias} forward, 18 kernels backward)
-            w = torch.stack([m.weight for m in self.class_embed]).transpose(1, 2)          # (n, C, K)
-            b = torch.stack([m.bias for m in self.class_embed])[:, None, :]                 # (n, 1, K)
+            w, b = self._class_head_stack(encoded.get("clip_key"))                          # (n, C, K), (n, 1, K)
             classes = torch.baddbmm(b, outputs.reshape(n_lvl, B_ * Nq_, C_), w).view(n_lvl, B_, Nq_, -1)
         for lvl in range(outputs.shape[0]):
             if not batched_heads:

@@ -19,7 +19,7 @@ from torch import nn
 from torch.nn.init import constant_, xavier_uniform_
 
 from .. import MultiScaleDeformableAttention as MSDA
-from ..functions import MSDeformAttnFunction, MSDeformAttnFusedFunction
+from ..functions import BankSlices, MSDeformAttnFunction, MSDeformAttnFusedFunction, ValueBank
 from .linear import long_linear
 
 # Fused prologue (softmax + location arithmetic + mask fill inside the HIP kernels).  On by default
@@ -87,6 +87,57 @@ class _ZeroRows(torch.autograd.Function):
         return g.reshape(-1, g.shape[-1]).index_fill(0, ctx.rows, 0).view(g.shape), None, None
 
 
+class ProjectedValue:
+    """What ``project_values`` hands one module: its (N, S, M, D) slice of the shared projection, the bank that collects
+    the slices' gradients, the slice's index, and the padding mask the kernels still have to apply (None when the
+    padded rows were zeroed where the projection wrote them)."""
+    __slots__ = ("value", "bank", "index", "mask")
+
+    def __init__(self, value, bank, index, mask):
+        self.value, self.bank, self.index, self.mask = value, bank, index, mask
+
+
+BATCHED_VALUE_PROJ = os.environ.get("MEMOTR_BATCHED_VALUE_PROJ", "1") != "0"
+
+
+def project_values(modules, input_flatten: torch.Tensor, input_padding_mask=None):
+    """The value projections of several modules that attend to the SAME memory -- the six decoder layers of a frame,
+    reference models/deformable_decoder.py:303-310 -> ms_deform_attn.py:104 -- as one GEMM with the weights stacked:
+    (S x C) x (C x G C) instead of G products forward, one (S x G C) x (G C x C) product instead of G products and G - 1
+    full-size additions for the memory's gradient, one weight-gradient product instead of G.  Each module reads its C
+    columns of the product in place (include/msda_hip.h, msda_next_value_pixel_stride) and accumulates its share of the
+    gradient into a slice of one tensor (``ValueBank``).  Returns a list of ``ProjectedValue`` (pass one as ``value=`` to
+    each module's forward) or None when the calls do not qualify -- the modules then project for themselves."""
+    mods = list(modules)
+    if not mods or not BATCHED_VALUE_PROJ or not FUSED_PROLOGUE or len(mods) < 2:
+        return None
+    m0 = mods[0]
+    M, L, P, C = m0.n_heads, m0.n_levels, m0.n_points, m0.d_model
+    x = input_flatten
+    if not (x.is_cuda and x.dim() == 3 and x.dtype == torch.float32 and not torch.is_autocast_enabled() and C // M == 32
+            and MSDA.fused_supported(x.dtype, C // M, L, P)
+            and all(isinstance(m, MSDeformAttn) and not m.sigmoid_attn and (m.n_heads, m.n_levels, m.n_points, m.d_model)
+                    == (M, L, P, C) and m.value_proj.weight.dtype == torch.float32 for m in mods)):
+        return None
+    N, S, _ = x.shape
+    G = len(mods)
+    if (G * C * 4) % 16 != 0 or N * S * G * C >= (1 << 29):
+        return None
+    mask = input_padding_mask
+    rows = getattr(mask, MASKED_ROWS_ATTR, None) if mask is not None else None
+    zero = None
+    if rows is not None:        # (as in MSDeformAttn.forward: the padded rows zeroed where the projection writes them)
+        mask = None
+        if rows.numel():
+            zero = lambda y: _ZeroRows.apply(y, rows, None)      # noqa: E731
+    w = torch.cat([m.value_proj.weight for m in mods], 0)
+    b = torch.cat([m.value_proj.bias for m in mods], 0)
+    value_all = long_linear(x, w, b, activation=zero)                           # (N, S, G * C)
+    bank = ValueBank(G)
+    slices = BankSlices.apply(value_all.view(N, S, G, M, C // M), bank)
+    return [ProjectedValue(v, bank, i, mask) for i, v in enumerate(slices)]
+
+
 class MSDeformAttn(nn.Module):
     def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4, sigmoid_attn=False, visualize=False):
         super().__init__()
@@ -125,6 +176,26 @@ class MSDeformAttn(nn.Module):
         constant_(self.value_proj.bias.data, 0.0)
         xavier_uniform_(self.output_proj.weight.data)
         constant_(self.output_proj.bias.data, 0.0)
+
+    def _forward_projected(self, query, reference_points, pv: "ProjectedValue", input_spatial_shapes,
+                           input_level_start_index):
+        """The fused branch of ``forward`` on a slice of a shared value projection (``project_values`` checked the
+        conditions of that branch)."""
+        M, P = self.n_heads, self.n_points
+        site = self.__dict__.get("_msda_site")
+        if site is None:
+            site = self.__dict__["_msda_site"] = MSDA.new_call_site()
+        MSDA.set_call_site(site)
+        w, b = self._fused_query_projection()
+        proj = long_linear(query, w, b)
+        if reference_points.shape[-1] not in (2, 4):
+            raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead.".format(
+                reference_points.shape[-1]))
+        out = MSDeformAttnFusedFunction.apply(pv.value, input_spatial_shapes, input_level_start_index, proj.contiguous(),
+                                              reference_points.contiguous(),
+                                              None if pv.mask is None else pv.mask.contiguous(), M, P, None,
+                                              (pv.bank, pv.index))
+        return long_linear(out, self.output_proj.weight, self.output_proj.bias)
 
     def _fused_query_projection(self):
         """Stacked (offsets; attention-logits) weight and bias for the single query GEMM.  The module runs once per
@@ -183,15 +254,20 @@ class MSDeformAttn(nn.Module):
         return new
 
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
-                input_padding_mask=None):
+                input_padding_mask=None, value: "ProjectedValue" = None):
         """
         query (N, Lq, C); reference_points (N, Lq, L, 2|4) in [0,1] incl. padding; input_flatten (N, S, C);
         input_spatial_shapes (L, 2) int64 (H, W); input_level_start_index (L,); input_padding_mask (N, S) bool.
+        ``value`` (optional, no reference counterpart): this module's share of ``project_values`` -- the value
+        projection has then been done together with the other modules'.
         Returns (N, Lq, C).
         """
         N, Lq, _ = query.shape
         S = input_flatten.shape[1]
         M, L, P = self.n_heads, self.n_levels, self.n_points
+        if value is not None:
+            return self._forward_projected(query, reference_points, value, input_spatial_shapes,
+                                           input_level_start_index)
         if input_flatten.is_cuda:
             # one kernel-selection record per module: the learnt offsets differ from layer to layer
             site = self.__dict__.get("_msda_site")
