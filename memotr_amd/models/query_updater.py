@@ -20,6 +20,9 @@ from .mlp import MLP
 from .utils import logits_to_scores, pos_to_pos_embed
 
 
+PACKED_TRACKS = __import__("os").environ.get("MEMOTR_PACKED_TRACKS", "1") != "0"
+
+
 class QueryUpdater(nn.Module):
     def __init__(self, hidden_dim: int, ffn_dim: int, tp_drop_ratio: float, fp_insert_ratio: float, dropout: float,
                  use_checkpoint: bool, use_dab: bool, update_threshold: float, long_memory_lambda: float,
@@ -126,7 +129,11 @@ class QueryUpdater(nn.Module):
             fields = tuple(getattr(t, f) for f in self.FIELDS)
             new = None
             if frame_slot is not None and self.graphs().usable(fields):
-                new = self.graphs().run((frame_slot, b), fields, clip_key)
+                packed = t._packed_base()           # the fields as adjacent columns of one tensor, in FIELDS' order?
+                if packed is not None and tuple(packed[1][:len(self.FIELDS)]) != tuple(self.FIELDS):
+                    packed = None
+                new = self.graphs().run((frame_slot, b), fields, clip_key,
+                                        packed=None if packed is None else packed[0])
             if new is None:
                 new = self.update_fields(*fields)
             t.ref_pts, t.long_memory, t.last_output, t.query_embed = new
@@ -168,7 +175,10 @@ class QueryUpdater(nn.Module):
             self._seed_memories(new_tracks[b])
             self._seed_memories(unmatched_dets[b])
             if self.tp_drop_ratio == 0.0 and self.fp_insert_ratio == 0.0:
-                active = cat(previous_tracks[b], new_tracks[b], unmatched_dets[b])
+                # (float fields packed into one tensor: the selection below and the embedding update then move all of
+                #  them with one gather / read them in place -- structures/track_instances.py: cat_packed)
+                active = (TrackInstances.cat_packed if PACKED_TRACKS else cat)(previous_tracks[b], new_tracks[b],
+                                                                               unmatched_dets[b])
                 scores = torch.max(logits_to_scores(active.logits), dim=1).values
                 active = active[(scores > self.update_threshold) | (active.ids >= 0)]
                 active.ids = torch.where(active.iou < 0.5, torch.full_like(active.ids, -1), active.ids)

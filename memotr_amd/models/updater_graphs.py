@@ -64,9 +64,10 @@ class UpdaterGraphs(GraphCache):
                 and any(f.requires_grad for f in fields) and len(fields[0]) > 0
                 and not (u.training and u.dropout > 0) and clip_ops.fused(fields[3]))
 
-    def run(self, slot, fields, clip_key=None):
+    def run(self, slot, fields, clip_key=None, packed=None):
         """The update of the track set ``fields`` (the tensors of ``QueryUpdater.FIELDS``) through the graph of ``slot``
-        (captured on first use).  Returns the four new fields, or None if the capture failed."""
+        (captured on first use).  Returns the four new fields, or None if the capture failed.  ``packed``: a tensor whose
+        leading columns ARE the fields, in order (``TrackInstances.cat_packed``): no concatenation then."""
         n = fields[0].shape[0]
         rows = (n + BUCKET - 1) // BUCKET * BUCKET
         widths = tuple(f.shape[1] for f in fields)
@@ -75,7 +76,10 @@ class UpdaterGraphs(GraphCache):
         if entry is None:
             return None
         fn, params, mask_for = entry
-        packed = torch.cat(fields, dim=1)                          # one launch; its backward hands out views
+        if packed is not None and packed.shape[0] == n and packed.shape[1] >= sum(widths):
+            packed = packed[:, :sum(widths)]
+        else:
+            packed = torch.cat(fields, dim=1)                      # one launch; its backward hands out views
         if rows > n:
             packed = F.pad(packed, (0, 0, 0, rows - n))
         self.replays += 1

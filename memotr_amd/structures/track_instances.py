@@ -61,7 +61,7 @@ class TrackInstances:
     def to(self, device) -> "TrackInstances":
         res = self._blank_like()
         for k, v in vars(self).items():
-            setattr(res, k, v.to(device) if hasattr(v, "to") else v)
+            setattr(res, k, v.to(device) if hasattr(v, "to") else v)     # (_packed: kept, checked by identity when used)
         return res
 
     def __len__(self) -> int:
@@ -81,7 +81,16 @@ class TrackInstances:
         # differentiates through a sort-based accumulate (~7 kernels per field that carries a gradient)
         rows = torch.is_tensor(item) and item.dim() == 1 and item.dtype in (torch.int64, torch.int32)
         res = self._blank_like()
+        packed = self._packed_base() if rows else None
+        if packed is not None:
+            # the float fields are column views of one tensor (cat_packed): ONE gather for all of them, and one
+            # index_add instead of one per field on the way back
+            base, names, widths = packed
+            idx = item if item.device == base.device else item.to(base.device)
+            res._set_packed(base.index_select(0, idx), names, widths)
         for k, v in vars(self).items():
+            if k.startswith("_") or (packed is not None and k in packed[1]):
+                continue
             if hasattr(v, "__getitem__") and v.shape[0] != 0:
                 if rows and torch.is_tensor(v):
                     # index_select wants the index on the field's device (advanced indexing did not: the query
@@ -114,6 +123,58 @@ class TrackInstances:
         for k, v in vars(tracked1).items():
             if type(v) is torch.Tensor:
                 setattr(res, k, torch.cat((v, getattr(tracked2, k)) + tuple(getattr(t, k) for t in more)))
+        return res
+
+    # ------------------------------------------------------------------ float fields as columns of one tensor
+    PACKED_FLOAT = ("logits", "boxes", "ref_pts", "output_embed", "long_memory", "last_output", "query_embed", "iou")
+
+    def _set_packed(self, base: torch.Tensor, names, widths):
+        views = base.split(list(widths), dim=1)
+        for name, v in zip(names, views):
+            setattr(self, name, v.squeeze(1) if name == "iou" else v)
+        self._packed = (base, tuple(names), tuple(widths), tuple(getattr(self, n) for n in names))
+
+    def _packed_base(self):
+        """(base, names, widths) while every packed field still IS the view made by ``_set_packed`` (assigning a field
+        replaces the attribute, which ends the arrangement for good), else None."""
+        p = self.__dict__.get("_packed")
+        if p is None:
+            return None
+        base, names, widths, views = p
+        if all(getattr(self, n) is v for n, v in zip(names, views)):
+            return base, names, widths
+        del self.__dict__["_packed"]
+        return None
+
+    @staticmethod
+    def cat_packed(*parts: "TrackInstances") -> "TrackInstances":
+        """``cat_tracked_instances`` with the float fields of ``PACKED_FLOAT`` gathered into ONE (n, W) tensor whose
+        column views become the fields: a following ``[index]`` then costs one gather (and one index_add backward)
+        for all eight instead of one each, and the query updater's captured update reads the packed rows as they are
+        (models/updater_graphs.py).  Same values as the per-field concatenation; falls back to it when the parts do
+        not carry those fields as float32 rows on one device."""
+        names = TrackInstances.PACKED_FLOAT
+        live = [t for t in parts if len(t) > 0]
+
+        def packable(t):
+            n = len(t)
+            dev = t.query_embed.device
+            return all(torch.is_tensor(getattr(t, k)) and getattr(t, k).dtype == torch.float32
+                       and getattr(t, k).shape[0] == n and getattr(t, k).device == dev
+                       and getattr(t, k).dim() == (1 if k == "iou" else 2) for k in names)
+
+        if not live or not all(packable(t) for t in live) or len({t.query_embed.device for t in live}) != 1:
+            return TrackInstances.cat_tracked_instances(*parts) if len(parts) > 1 else parts[0]
+        widths = [1 if k == "iou" else getattr(live[0], k).shape[1] for k in names]
+        if any([1 if k == "iou" else getattr(t, k).shape[1] for k in names] != widths for t in live):
+            return TrackInstances.cat_tracked_instances(*parts) if len(parts) > 1 else parts[0]
+        blocks = [torch.cat([getattr(t, k)[:, None] if k == "iou" else getattr(t, k) for k in names], dim=1) for t in live]
+        base = blocks[0] if len(blocks) == 1 else torch.cat(blocks, dim=0)
+        res = TrackInstances(frame_height=parts[0].frame_height, frame_width=parts[0].frame_width)
+        for k, v in vars(parts[0]).items():
+            if type(v) is torch.Tensor and k not in names:
+                setattr(res, k, torch.cat(tuple(getattr(t, k) for t in parts)))
+        res._set_packed(base, names, widths)
         return res
 
     @staticmethod

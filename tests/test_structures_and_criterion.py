@@ -36,6 +36,48 @@ def test_track_instances_reference_quirks():
     assert init[0].frame_height == pytest.approx(0.8) and init[1].frame_width == pytest.approx(0.5)
 
 
+def test_cat_packed_equals_the_per_field_concatenation():
+    """``TrackInstances.cat_packed``: same fields as ``cat_tracked_instances`` (values, shapes, gradients), the float
+    fields as column views of one tensor; ``[index]`` keeps them packed with one gather; assigning a field ends the
+    arrangement for that container; parts that cannot be packed take the per-field path."""
+    from memotr_amd.structures.track_instances import TrackInstances
+
+    def make(n, seed, C=16, K=1):
+        g = torch.Generator().manual_seed(seed)
+        t = TrackInstances(hidden_dim=C, num_classes=K, use_dab=True)
+        t.ref_pts, t.boxes = torch.rand(n, 4, generator=g), torch.rand(n, 4, generator=g)
+        t.query_embed = torch.randn(n, C, generator=g, requires_grad=True)
+        t.output_embed = torch.randn(n, C, generator=g, requires_grad=True)
+        t.last_output, t.long_memory = torch.randn(n, C, generator=g), torch.randn(n, C, generator=g)
+        t.logits, t.iou = torch.randn(n, K, generator=g), torch.rand(n, generator=g)
+        t.ids, t.matched_idx = torch.arange(n) + 10 * seed, torch.arange(n)
+        return t
+
+    a, b, c = make(3, 1), make(0, 2), make(5, 3)
+    ref = TrackInstances.cat_tracked_instances(a, b, c)
+    got = TrackInstances.cat_packed(a, b, c)
+    assert got._packed_base() is not None and len(got) == len(ref) == 8
+    for k in ("ref_pts", "boxes", "query_embed", "output_embed", "last_output", "long_memory", "logits", "iou", "ids",
+              "matched_idx", "labels", "scores"):
+        assert getattr(got, k).shape == getattr(ref, k).shape, k
+        assert torch.equal(getattr(got, k), getattr(ref, k)), k
+    idx = torch.tensor([7, 0, 4])
+    sel_ref, sel = ref[idx], got[idx]
+    assert sel._packed_base() is not None and sel._packed_base()[0].shape[0] == 3
+    for k in ("query_embed", "output_embed", "iou", "logits", "ids"):
+        assert torch.equal(getattr(sel, k), getattr(sel_ref, k)), k
+    assert torch.equal(got[torch.tensor([True] * 3 + [False] * 5)].ids, a.ids)          # boolean masks too
+    (sel.query_embed.sum() * 2 + sel.output_embed.square().sum()).backward()
+    ga, gc = a.query_embed.grad.clone(), c.output_embed.grad.clone()
+    a.query_embed.grad = c.output_embed.grad = a.output_embed.grad = c.query_embed.grad = None
+    (sel_ref.query_embed.sum() * 2 + sel_ref.output_embed.square().sum()).backward()
+    assert torch.equal(ga, a.query_embed.grad) and torch.allclose(gc, c.output_embed.grad)
+    sel.ref_pts = torch.zeros(3, 4)                      # a field assigned: no longer one tensor
+    assert sel._packed_base() is None and sel[torch.tensor([1])].ref_pts.shape == (1, 4)
+    c.iou = torch.zeros(5, dtype=torch.float64)          # not packable -> the per-field concatenation
+    assert TrackInstances.cat_packed(a, c)._packed_base() is None
+
+
 def fake_outputs(n_det, n_tr, hidden, n_layers=2, K=1, seed=0):
     g = torch.Generator().manual_seed(seed)
     nq = n_det + n_tr
