@@ -101,7 +101,9 @@ class ValueBank:
     def grad_slice(self, value, index: int):
         N, S, M, D = value.shape
         if self.grad is None:
-            self.grad = torch.zeros((N, S, self.groups, M, D), dtype=torch.float32, device=value.device)
+            # (fill_, not torch.zeros: under capture torch.zeros of more than a few thousand elements becomes a MEMSET
+            #  node, tools/zeros_probe.py -- the captured regions hold none, models/decoder_graphs.py)
+            self.grad = torch.empty((N, S, self.groups, M, D), dtype=torch.float32, device=value.device).fill_(0.0)
         return self.grad[:, :, index]
 
 
