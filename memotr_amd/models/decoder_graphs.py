@@ -226,6 +226,47 @@ def enabled() -> bool:
     return os.environ.get("MEMOTR_DECODER_GRAPHS", "1") != "0"
 
 
+def paired_query_projections(root: nn.Module, named):
+    """Order the parameters of ``root`` for the flat argument of a capture so that, for every deformable-attention module,
+    ``sampling_offsets.weight`` is directly followed by ``attention_weights.weight`` and the two biases likewise: the
+    stacked (offsets; logits) projection the module feeds its one query GEMM with is then a VIEW of the flat tensor, not a
+    concatenation made by every replay (two kernels per layer and frame; the concatenation's gradient was slices anyway).
+    Returns (names, parameters, [(name of sampling_offsets.weight, offset, rows_w, cols, offset_b, rows_b), ...])."""
+    from ..modules.ms_deform_attn import MSDeformAttn
+    by_name = dict(named)
+    pairs = {}
+    for mod_name, m in root.named_modules():
+        if isinstance(m, MSDeformAttn):
+            pre = mod_name + "." if mod_name else ""
+            keys = [pre + k for k in ("sampling_offsets.weight", "attention_weights.weight", "sampling_offsets.bias",
+                                      "attention_weights.bias")]
+            if all(k in by_name for k in keys) and by_name[keys[0]].dtype == by_name[keys[1]].dtype:
+                pairs[keys[0]] = keys
+    taken = {k for keys in pairs.values() for k in keys}
+    order = [n for n, _ in named if n not in taken]
+    for keys in pairs.values():
+        order += keys
+    names = tuple(order)
+    params = tuple(by_name[n] for n in names)
+    offsets, pos = {}, 0
+    for n, p in zip(names, params):
+        offsets[n] = pos
+        pos += p.numel()
+    fused = []
+    for first, keys in pairs.items():
+        w0, w1, b0, b1 = (by_name[k] for k in keys)
+        fused.append((first, offsets[keys[0]], w0.shape[0] + w1.shape[0], w0.shape[1], offsets[keys[2]],
+                      b0.shape[0] + b1.shape[0]))
+    return names, params, fused
+
+
+def attach_fused_projections(sub: dict, flat: torch.Tensor, fused) -> None:
+    """Tag each module's ``sampling_offsets.weight`` stand-in with the views of ``flat`` that ARE its stacked weight and bias
+    (``MSDeformAttn._fused_query_projection`` picks them up)."""
+    for first, off_w, rows, cols, off_b, rows_b in fused:
+        sub[first]._msda_fused_qproj = (flat.narrow(0, off_w, rows * cols).view(rows, cols), flat.narrow(0, off_b, rows_b))
+
+
 class DecoderGraphs(GraphCache):
     """Cache of captured decoder steps, owned by a ``DeformableDecoder``."""
 
@@ -299,18 +340,21 @@ class DecoderGraphs(GraphCache):
         hipStreamEndCapture faults.  Inside the graph the flat tensor is split into the parameter shapes (views);
         the split's backward is one concatenation."""
         loop = DecoderLoop(self.decoder, shapes, lsi)
-        names, params = zip(*loop.named_parameters())
-        if len(names) != sum(1 for _ in loop.named_parameters(remove_duplicate=False)):
+        named = list(loop.named_parameters())
+        if len(named) != sum(1 for _ in loop.named_parameters(remove_duplicate=False)):
             self.failed = True      # a module shared between layers (no box refinement clones): see DecoderLoop
             return None
+        names, params, fused = paired_query_projections(loop, named)
         sizes = [p.numel() for p in params]
         views = [p.shape for p in params]
         n_user = len(args)
 
         def run(*flat_in):
-            pieces = flat_in[n_user].split(sizes)
-            return torch.func.functional_call(loop, {n: w.view(s) for n, w, s in zip(names, pieces, views)},
-                                              tuple(flat_in[:n_user]))
+            flat_p = flat_in[n_user]
+            pieces = flat_p.split(sizes)
+            sub = {n: w.view(s) for n, w, s in zip(names, pieces, views)}
+            attach_fused_projections(sub, flat_p, fused)
+            return torch.func.functional_call(loop, sub, tuple(flat_in[:n_user]))
 
         with torch.no_grad():
             flat = torch.cat([p.reshape(-1) for p in params])
@@ -322,6 +366,6 @@ class DecoderGraphs(GraphCache):
             return self.capture_failed(exc)
         # functional_call must have put every nn.Parameter back (see DecoderLoop)
         assert all(isinstance(p, nn.Parameter) for p in loop.parameters()) and \
-            [id(p) for p in loop.parameters()] == [id(p) for p in params], "decoder parameters were replaced"
+            sorted(id(p) for p in loop.parameters()) == sorted(id(p) for p in params), "decoder parameters were replaced"
         self.captures += 1
         return fn, params

@@ -203,6 +203,11 @@ class MSDeformAttn(nn.Module):
         concatenations are made once per step: the cached tensors (and the autograd edge to the four parameters)
         are reused until a parameter changes or a backward pass has flowed through them."""
         so, aw = self.sampling_offsets, self.attention_weights
+        pre = getattr(so.weight, "_msda_fused_qproj", None)
+        if pre is not None:
+            # a capture whose flat parameter argument holds the two weights (and the two biases) next to each other
+            # (models/decoder_graphs.py: paired_query_projections): the stack is a view, nothing to concatenate
+            return pre
         if so.weight.is_cuda and torch.cuda.is_current_stream_capturing():
             # inside a hipGraph capture the concatenation must be part of the graph (a cached tensor would freeze the
             # weights of the first capture into every replay)
