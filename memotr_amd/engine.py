@@ -123,6 +123,10 @@ def encode_chunks(core, clip_len: int):
 
 
 DEFAULT_ENCODE_CHUNKS = "all"
+# Frame t's losses are issued under frame t + 1's decoder: the next frame needs a frame's TRACKS (criterion.finish_tracks),
+# not its losses, and the host would otherwise sit in the wait for that decoder (0.45-0.5 ms per frame, tools/
+# replay_cost_probe.py: clip forward on the host 46.1 -> 45.2 ms).  MEMOTR_DEFER_LOSSES=0: both halves back to back.
+DEFER_LOSSES = os.environ.get("MEMOTR_DEFER_LOSSES", "1") != "0"
 
 _ENCODE_STREAMS = {}
 
@@ -222,6 +226,7 @@ def clip_forward_backward(model: nn.Module, criterion, batch: dict, device, use_
         encode_chunk(0)
     if tracks is None:
         tracks = set_up()
+    owed = None                                     # criterion state of the frame whose losses are still to be issued
     for frame_idx in range(clip_len):
         if lazy and frame_idx in starts and frame_idx > 0:   # just in time: encoded right before its first decode
             encode_chunk(starts.index(frame_idx))
@@ -245,12 +250,20 @@ def clip_forward_backward(model: nn.Module, criterion, batch: dict, device, use_
             pending = criterion.begin_frame(model_outputs=res, tracked_instances=tracks, frame_idx=frame_idx)
             if not lazy and frame_idx in starts and starts.index(frame_idx) + 1 < len(chunks):
                 encode_chunk(starts.index(frame_idx) + 1)     # queued before the host blocks on this frame's costs
-            previous, new, unmatched = criterion.finish_frame(pending)
+            if DEFER_LOSSES:
+                if owed is not None:
+                    criterion.finish_losses(owed)         # the previous frame's, while the GPU runs this frame's decoder
+                previous, new, unmatched = criterion.finish_tracks(pending)
+                owed = pending
+            else:
+                previous, new, unmatched = criterion.finish_frame(pending)
         if frame_idx < clip_len - 1:
             # (batched-encode path: the frame's slot for the updater's hipGraphs, models/updater_graphs.py)
             tracks = core.postprocess_single_frame(previous, new, unmatched,
                                                    **({} if chunks is None else {"frame_slot": frame_idx,
                                                                                  "clip_key": clip_key}))
+    if owed is not None:
+        criterion.finish_losses(owed)
     # (no log values here: each is a device->host read, i.e. a stream synchronisation in front of the backward)
     loss_dict, _ = criterion.get_mean_by_n_gts(with_log=os.environ.get("MEMOTR_LOSS_LOG_SYNC", "0") == "1")
     loss = criterion.get_sum_loss_dict(loss_dict=loss_dict)

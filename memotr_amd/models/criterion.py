@@ -267,11 +267,10 @@ class ClipCriterion:
 
     def finish_frame(self, state: dict):
         """Host side (assignment problems) and the device work that depends on it; see process_single_frame.
-        = ``finish_tracks`` (what the next frame needs) + ``finish_losses`` (what only the backward needs).  Round 6
-        measured issuing the losses of frame t under the decoder of frame t + 1 (tools/small_trace.py had shown the
-        forward between two decoder graphs to be bound by the host): 124.7 vs 125.1 ms per step, nothing -- the host is
-        the bottleneck on both sides of the wait, so moving launches across it moves no time.  The halves stay separate
-        entry points; the training loop calls them back to back."""
+        = ``finish_tracks`` (what the next frame needs) + ``finish_losses`` (what only the backward needs).  The training
+        loop issues the losses of frame t while the GPU runs the decoder of frame t + 1 (engine.DEFER_LOSSES): the wait
+        for that decoder -- 0.45-0.5 ms per frame -- is then spent launching instead (clip forward on the host 46.1 ->
+        45.2 ms, tools/replay_cost_probe.py; the whole-step A/B could not resolve it: 124.7 vs 125.1 ms)."""
         out = self.finish_tracks(state)
         self.finish_losses(state)
         return out
