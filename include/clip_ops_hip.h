@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define CLIPOPS_ABI_VERSION 9
+#define CLIPOPS_ABI_VERSION 10
 
 int clipops_abi_version(void);
 const char *clipops_last_error(void);
@@ -51,6 +51,23 @@ int clipops_pair_box_loss_bwd_f32(const float *boxes, const int64_t *lay, const 
  * iou[i] = IoU(xyxy(boxes[i]), xyxy(tgt_boxes[gidx[i]]))  (gidx == NULL: row i); boxes (n,4) cxcywh contiguous. */
 int clipops_pair_iou_f32(const float *boxes, const float *tgt_boxes, const int64_t *gidx, int n, float *iou,
                          void *stream);
+
+/* ---- per-frame bookkeeping of the criterion (round 6, ABI 10) ----
+ * Which ground truth a carried track owns, and which ground truths nobody owns (reference models/criterion.py:166-182:
+ * the `gt_ids_to_idx` dict -- the LAST ground truth wins when a frame repeats an id -- and the `unmatched` list):
+ *   matched_idx[i] = max { j : gt_ids[j] == track_ids[i] }  or -1;   gt_free[j] = 1.0 if no track carries gt_ids[j] else 0.0
+ * (float: it travels to the host in front of the cost tensor).  Replaces seven torch launches (compare / arange / product
+ * / amax / subtract / any / not) by one. */
+int clipops_track_ownership_i64(const int64_t *track_ids, int n_tracks, const int64_t *gt_ids, int n_gt,
+                                int64_t *matched_idx, float *gt_free, void *stream);
+/* Classification targets of every decoder layer for the focal loss (reference models/criterion.py:300-330):
+ *   labels (n_layers, n_det + n_tracks) = K (background);  columns n_det.. of the layers with late[l] != 0 = the label of the
+ *   ground truth the track owns (matched_idx, -1: background);  then labels[lay[p], q[p]] = gt_labels[g[p]] for the n_pairs
+ *   matched (layer, detect query, ground truth) triples.  Replaces eleven torch launches (fill / gather / index_put /
+ *   compare / clamp / gather / two fills / two selects / slice copy) by one. */
+int clipops_focal_labels_i64(const int64_t *lay, const int64_t *q, const int64_t *g, int n_pairs,
+                             const int64_t *gt_labels, int n_gt, const int64_t *matched_idx, int n_tracks,
+                             const uint8_t *late, int n_layers, int n_det, int K, int64_t *labels, void *stream);
 
 /* Sigmoid focal loss of stacked layers (reference models/criterion.py:442-467, RetinaNet form): per layer l
  *   loss[l] = sum_q mean_k  a_t * ce * (1 - p_t)^gamma,   target one-hot of labels[l,q] (label == K: background).

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libclip_ops_hip.so")
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 c_int, c_long, c_float, c_void_p = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_void_p
 
@@ -26,6 +26,9 @@ SYMBOLS = {
     "clipops_pair_box_loss_fwd_f32": (_PAIR + [c_void_p, c_void_p, c_void_p], c_int),
     "clipops_pair_box_loss_bwd_f32": (_PAIR + [c_void_p, c_void_p, c_void_p, c_void_p], c_int),
     "clipops_pair_iou_f32": ([c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p], c_int),
+    "clipops_track_ownership_i64": ([c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p], c_int),
+    "clipops_focal_labels_i64": ([c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
+                                  c_int, c_int, c_void_p, c_void_p], c_int),
     "clipops_focal_fwd_f32": (_FOCAL + [c_void_p, c_void_p], c_int),
     "clipops_focal_bwd_f32": (_FOCAL + [c_void_p, c_void_p, c_void_p], c_int),
     "clipops_colsum_f32": ([c_void_p, c_long, c_int, c_void_p, c_void_p], c_int),

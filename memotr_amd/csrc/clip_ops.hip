@@ -1069,6 +1069,52 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float *__restrict
 
 }  // namespace
 
+// ---- per-frame bookkeeping of the criterion (round 6, ABI 10): index arithmetic on a few hundred elements that took
+//      7 and 11 torch launches per frame -- the forward between two decoder graphs is bound by the host's launch rate ----
+// one workgroup: thread i < n_tr finds the LAST ground truth carrying track i's id, thread j < n_gt whether any track
+// carries ground truth j's id
+__global__ __launch_bounds__(256) void track_ownership_kernel(const int64_t *__restrict__ tr_ids, int n_tr,
+                                                              const int64_t *__restrict__ gt_ids, int n_gt,
+                                                              int64_t *__restrict__ matched, float *__restrict__ free_out) {
+    for (int i = threadIdx.x; i < n_tr; i += blockDim.x) {
+        const int64_t id = tr_ids[i];
+        int64_t m = -1;
+        for (int j = 0; j < n_gt; ++j)
+            if (gt_ids[j] == id) m = j;
+        matched[i] = m;
+    }
+    for (int j = threadIdx.x; j < n_gt; j += blockDim.x) {
+        const int64_t id = gt_ids[j];
+        bool owned = false;
+        for (int i = 0; i < n_tr; ++i) owned = owned || tr_ids[i] == id;
+        free_out[j] = owned ? 0.f : 1.f;
+    }
+}
+
+// one workgroup: background everywhere, the carried tracks' labels in the late layers, then the matched pairs
+__global__ __launch_bounds__(256) void focal_labels_kernel(const int64_t *__restrict__ lay, const int64_t *__restrict__ q,
+                                                           const int64_t *__restrict__ g, int n_pairs,
+                                                           const int64_t *__restrict__ gt_labels, int n_gt,
+                                                           const int64_t *__restrict__ matched, int n_tr,
+                                                           const unsigned char *__restrict__ late, int n_layers, int nd,
+                                                           int K, int64_t *__restrict__ labels) {
+    const int nq = nd + n_tr;
+    for (int e = threadIdx.x; e < n_layers * nq; e += blockDim.x) {
+        const int l = e / nq, c = e - l * nq;
+        int64_t v = K;
+        if (c >= nd && late[l]) {
+            const int64_t m = matched[c - nd];
+            if (m >= 0 && m < n_gt) v = gt_labels[m];
+        }
+        labels[e] = v;
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < n_pairs; p += blockDim.x) {
+        const int64_t l = lay[p], c = q[p], t = g[p];
+        if (l >= 0 && l < n_layers && c >= 0 && c < nq && t >= 0 && t < n_gt) labels[l * nq + c] = gt_labels[t];
+    }
+}
+
 extern "C" {
 
 int clipops_abi_version(void) { return CLIPOPS_ABI_VERSION; }
@@ -1110,6 +1156,30 @@ int clipops_pair_box_loss_bwd_f32(const float *boxes, const int64_t *lay, const 
     hipLaunchKernelGGL(pair_box_loss_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, boxes, lay,
                        qidx, row_mul, row_add, tgt_boxes, gidx, weight, n, grad_l1, grad_giou, grad_boxes);
     return check_launch("pair_box_loss_bwd_kernel");
+}
+
+int clipops_track_ownership_i64(const int64_t *track_ids, int n_tracks, const int64_t *gt_ids, int n_gt,
+                                int64_t *matched_idx, float *gt_free, void *stream) {
+    if (n_tracks < 0 || n_gt < 0) return fail(1, "clipops_track_ownership_i64: negative count");
+    if (n_tracks + n_gt == 0) { g_err[0] = 0; return 0; }
+    if ((n_tracks > 0 && (!track_ids || !matched_idx)) || (n_gt > 0 && (!gt_ids || !gt_free)))
+        return fail(1, "clipops_track_ownership_i64: null pointer");
+    hipLaunchKernelGGL(track_ownership_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, track_ids, n_tracks, gt_ids,
+                       n_gt, matched_idx, gt_free);
+    return check_launch("track_ownership_kernel");
+}
+
+int clipops_focal_labels_i64(const int64_t *lay, const int64_t *q, const int64_t *g, int n_pairs,
+                             const int64_t *gt_labels, int n_gt, const int64_t *matched_idx, int n_tracks,
+                             const uint8_t *late, int n_layers, int n_det, int K, int64_t *labels, void *stream) {
+    if (n_pairs < 0 || n_gt < 0 || n_tracks < 0 || n_layers < 0 || n_det < 0) return fail(1, "clipops_focal_labels_i64: negative count");
+    if ((long)n_layers * (n_det + n_tracks) == 0) { g_err[0] = 0; return 0; }
+    if (!labels || !late || (n_pairs > 0 && (!lay || !q || !g || !gt_labels)) || (n_tracks > 0 && !matched_idx) ||
+        (n_gt > 0 && !gt_labels))
+        return fail(1, "clipops_focal_labels_i64: null pointer");
+    hipLaunchKernelGGL(focal_labels_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, lay, q, g, n_pairs, gt_labels, n_gt,
+                       matched_idx, n_tracks, late, n_layers, n_det, K, labels);
+    return check_launch("focal_labels_kernel");
 }
 
 int clipops_pair_iou_f32(const float *boxes, const float *tgt_boxes, const int64_t *gidx, int n, float *iou,

@@ -93,11 +93,11 @@ def encode_chunks(core, clip_len: int):
     (MEMOTR_CHECKPOINT_REFERENCE_ORDER=1 restores the reference's frame order)."""
     if getattr(core, "use_checkpoint", False) and os.environ.get("MEMOTR_CHECKPOINT_REFERENCE_ORDER", "0") == "1":
         return None, False
-    spec = getattr(core, "encode_chunks", None)
-    if spec is None:
-        spec = os.environ.get("MEMOTR_ENCODE_CHUNKS", DEFAULT_ENCODE_CHUNKS)
+    spec = _chunk_spec(core)
     lazy = False
     if isinstance(spec, str):
+        if spec.startswith("enc:"):                  # (see backbone_batched)
+            spec = spec[4:]
         if spec.startswith("lazy:"):
             lazy, spec = True, spec[5:]
         if spec.strip() == "auto":                   # two groups, ~60 % of the clip first, each encoded just in time
@@ -120,6 +120,20 @@ def encode_chunks(core, clip_len: int):
         out.append(min(spec[-1], left))
         left -= out[-1]
     return out, lazy
+
+
+def _chunk_spec(core):
+    spec = getattr(core, "encode_chunks", None)
+    return os.environ.get("MEMOTR_ENCODE_CHUNKS", DEFAULT_ENCODE_CHUNKS) if spec is None else spec
+
+
+def backbone_batched(core) -> bool:
+    """"enc:<groups>": the groups apply to the transformer encoder only -- backbone + feature projections of the whole clip
+    run as ONE batch first (``model(stage="features")``; the convolutions lose the most at small batches), and each
+    group's encoder is queued one group ahead of its first decode, so the GPU has a group's encoder to run while the
+    host is in a frame's launch-bound chain (assignment, track bookkeeping, query updater, the next decoder's launch)."""
+    spec = _chunk_spec(core)
+    return isinstance(spec, str) and spec.startswith("enc:")
 
 
 DEFAULT_ENCODE_CHUNKS = "all"
@@ -177,12 +191,15 @@ def clip_forward_backward(model: nn.Module, criterion, batch: dict, device, use_
     encoded = {}                                   # frame index -> encode result of that frame
     clip_key = object()                            # identifies this clip's autograd graph to per-clip caches
 
-    side = encode_stream(device) if chunks is not None and len(chunks) > 1 else None
+    split = chunks is not None and backbone_batched(core) and not getattr(core, "use_checkpoint", False)
+    feats = None                                   # split: the clip's backbone features, encoders per group
+    side = encode_stream(device) if chunks is not None and len(chunks) > 1 and not split else None
     if side is not None:
         lazy = False                               # later groups are queued one group ahead, on the side stream
     on_side = set()                                # frames whose encode result was produced on the side stream
 
     def encode_chunk(ci):
+        nonlocal feats
         lo, n = starts[ci], chunks[ci]
         if side is not None and ci > 0:
             main = torch.cuda.current_stream()
@@ -197,6 +214,12 @@ def clip_forward_backward(model: nn.Module, criterion, batch: dict, device, use_
                 if torch.is_tensor(v) and v.is_cuda:
                     v.record_stream(main)
             on_side.update(range(lo, lo + n))
+        elif split:
+            if feats is None:
+                feats = model(frame=frames(0, clip_len), stage="features")
+            enc = model(frame=(feats, lo * n_clips, (lo + n) * n_clips), stage="encode_features")
+            if lo + n >= clip_len:
+                feats = None
         else:
             batch_frames = frames(lo, lo + n)
             batch_frames.encode_slot = ci           # which of the clip's encode calls this is (models/encode_graphs.py)

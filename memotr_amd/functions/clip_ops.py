@@ -53,12 +53,17 @@ def _strides3(t: torch.Tensor):
 # matching cost (models/matcher.py of the reference, :83-121)
 # --------------------------------------------------------------------------------------------------------------
 def match_cost(logits: torch.Tensor, boxes: torch.Tensor, gt_labels: torch.Tensor, gt_boxes: torch.Tensor,
-               w_class: float, w_bbox: float, w_giou: float) -> torch.Tensor:
+               w_class: float, w_bbox: float, w_giou: float, out: torch.Tensor = None) -> torch.Tensor:
     """(n_layers, Q, K) logits and (n_layers, Q, 4) cxcywh boxes (views allowed) against (T,) labels / (T, 4) boxes
-    -> (n_layers, Q, T) cost."""
+    -> (n_layers, Q, T) cost.  ``out``: a contiguous float32 destination of n_layers * Q * T elements (any shape: the
+    tail of the buffer that travels to the host)."""
     n_layers, Q, K = logits.shape
     T = gt_labels.shape[0]
-    cost = torch.empty((n_layers, Q, T), dtype=torch.float32, device=logits.device)
+    if out is not None:
+        assert out.is_contiguous() and out.dtype == torch.float32 and out.numel() == n_layers * Q * T
+        cost = out.view(n_layers, Q, T)
+    else:
+        cost = torch.empty((n_layers, Q, T), dtype=torch.float32, device=logits.device)
     lsl, lsq = _strides3(logits)
     bsl, bsq = _strides3(boxes)
     gt_labels, gt_boxes = gt_labels.contiguous(), gt_boxes.contiguous()
@@ -67,6 +72,57 @@ def match_cost(logits: torch.Tensor, boxes: torch.Tensor, gt_labels: torch.Tenso
                                          gt_boxes.data_ptr(), n_layers, Q, K, T, float(w_class), float(w_bbox),
                                          float(w_giou), cost.data_ptr(), _stream(logits)), "clipops_match_cost_f32")
     return cost
+
+
+# --------------------------------------------------------------------------------------------------------------
+# per-frame bookkeeping (include/clip_ops_hip.h, ABI 10): ownership of the ground truths, focal-loss targets
+# --------------------------------------------------------------------------------------------------------------
+def track_ownership(track_ids: torch.Tensor, gt_ids: torch.Tensor, free_out: torch.Tensor = None):
+    """-> (matched_idx (n_tracks,) int64: index of the LAST ground truth carrying the track's id or -1,
+    free (n_gt,) float32: 1 where no track carries the ground truth's id).  ``free_out``: where to write ``free``."""
+    n_tr, n_gt = track_ids.shape[0], gt_ids.shape[0]
+    matched = torch.empty((n_tr,), dtype=torch.int64, device=gt_ids.device)
+    free = free_out if free_out is not None else torch.empty((n_gt,), dtype=torch.float32, device=gt_ids.device)
+    assert free.is_contiguous() and free.dtype == torch.float32 and free.numel() == n_gt
+    track_ids, gt_ids = track_ids.contiguous(), gt_ids.contiguous()
+    L = _lib()
+    L.check(L.lib.clipops_track_ownership_i64(track_ids.data_ptr(), n_tr, gt_ids.data_ptr(), n_gt, matched.data_ptr(),
+                                              free.data_ptr(), _stream(gt_ids)), "clipops_track_ownership_i64")
+    return matched, free
+
+
+def track_ownership_reference(track_ids, gt_ids):
+    n_gt = gt_ids.shape[0]
+    eq = track_ids[:, None] == gt_ids[None, :]
+    order = torch.arange(1, n_gt + 1, device=eq.device)
+    return (eq * order).amax(1) - 1 if n_gt > 0 else torch.full_like(track_ids, -1), (~eq.any(0)).to(torch.float32)
+
+
+def focal_labels(lay: torch.Tensor, q: torch.Tensor, g: torch.Tensor, gt_labels: torch.Tensor, matched_idx,
+                 late: torch.Tensor, n_det: int, n_tracks: int, num_classes: int) -> torch.Tensor:
+    """(n_layers, n_det + n_tracks) int64 focal-loss targets: background, the carried tracks' labels in the layers with
+    ``late`` set, the matched (layer, query, ground truth) triples -- ``focal_labels_reference`` in one launch."""
+    n_layers = late.shape[0]
+    labels = torch.empty((n_layers, n_det + n_tracks), dtype=torch.int64, device=late.device)
+    lay, q, g, gt_labels = lay.contiguous(), q.contiguous(), g.contiguous(), gt_labels.contiguous()
+    L = _lib()
+    L.check(L.lib.clipops_focal_labels_i64(lay.data_ptr(), q.data_ptr(), g.data_ptr(), lay.shape[0], gt_labels.data_ptr(),
+                                           gt_labels.shape[0], None if matched_idx is None else matched_idx.contiguous().data_ptr(),
+                                           n_tracks, late.contiguous().data_ptr(), n_layers, n_det, num_classes,
+                                           labels.data_ptr(), _stream(late)), "clipops_focal_labels_i64")
+    return labels
+
+
+def focal_labels_reference(lay, q, g, gt_labels, matched_idx, late, n_det, n_tracks, num_classes):
+    n_layers = late.shape[0]
+    labels = torch.full((n_layers, n_det + n_tracks), num_classes, dtype=torch.int64, device=late.device)
+    labels[lay, q] = gt_labels[g]
+    if n_tracks > 0:
+        has = matched_idx >= 0
+        tr_lab = torch.where(has, gt_labels[matched_idx.clamp(min=0)] if gt_labels.shape[0] > 0
+                             else torch.full_like(matched_idx, num_classes), torch.full_like(matched_idx, num_classes))
+        labels[:, n_det:] = torch.where(late[:, None], tr_lab[None, :], labels[:, n_det:])
+    return labels
 
 
 # --------------------------------------------------------------------------------------------------------------

@@ -210,17 +210,24 @@ class ClipCriterion:
             tr, gt = tracked_instances[b], gts[b]
             n_gt, n_tr = len(gt), len(tr)
             n_gt_list.append(n_gt)
+            lg, bx = logits_all.detach()[:, b, :nd], boxes_all.detach()[:, b, :nd]
+            kernels = clip_ops.fused(lg, bx, gt.boxes) and n_gt > 0 and tr.ids.dtype == gt.ids.dtype == torch.int64
+            if kernels:
+                # ownership and the whole cost tensor written straight into the buffer that travels to the host:
+                # two launches (include/clip_ops_hip.h: clipops_track_ownership_i64, clipops_match_cost_f32)
+                buf = torch.empty((n_gt + n_layers * nd * n_gt,), dtype=torch.float32, device=lg.device)
+                tr.matched_idx, _ = clip_ops.track_ownership(tr.ids, gt.ids, free_out=buf[:n_gt])
+                clip_ops.match_cost(lg, bx, gt.labels, gt.boxes, self.matcher.cost_class, self.matcher.cost_bbox,
+                                    self.matcher.cost_giou, out=buf[n_gt:])
+                payload.append(buf)
+                continue
             if n_tr > 0 and n_gt > 0:
-                eq = tr.ids[:, None] == gt.ids[None, :]
                 # index of the LAST ground truth carrying the id (the reference's ``gt_ids_to_idx`` dict keeps the
                 # last one when a frame repeats an id, criterion.py:166-170), -1 when the identity is gone
-                order = torch.arange(1, n_gt + 1, device=eq.device)
-                tr.matched_idx = (eq * order).amax(1) - 1
-                free = ~eq.any(0)
+                tr.matched_idx, free = clip_ops.track_ownership_reference(tr.ids, gt.ids)
             else:
                 tr.matched_idx = torch.full((n_tr,), -1, dtype=torch.long, device=dev)
-                free = torch.ones((n_gt,), dtype=torch.bool, device=dev)
-            lg, bx = logits_all.detach()[:, b, :nd], boxes_all.detach()[:, b, :nd]
+                free = torch.ones((n_gt,), dtype=torch.float32, device=dev)
             if clip_ops.fused(lg, bx, gt.boxes):        # one kernel for the whole cost tensor
                 cost = clip_ops.match_cost(lg, bx, gt.labels, gt.boxes, self.matcher.cost_class,
                                            self.matcher.cost_bbox, self.matcher.cost_giou)
@@ -231,7 +238,7 @@ class ClipCriterion:
         if not payload:
             host = torch.zeros(0)
         else:
-            flat = torch.cat(payload)
+            flat = payload[0] if len(payload) == 1 else torch.cat(payload)
             if flat.is_cuda:
                 # copy on a side stream: the event then depends on the work queued up to here only, and the host
                 # wait in finish_frame is not held back by kernels the caller queues on the main stream meanwhile
@@ -384,15 +391,13 @@ class ClipCriterion:
             lay_i, q_i, g_i = clip["idx"]
             # classification targets of every layer: matched detect queries + (late layers) the carried tracks
             n_q = nd + n_tr                                                        # real (unpadded) queries of clip b
-            labels = torch.full((n_layers, n_q), self.num_classes, dtype=torch.int64, device=dev)
-            labels[lay_i, q_i] = gt.labels[g_i]
             late = self._constant(("late", tuple(early)), [not e for e in early], torch.bool, dev)
-            if n_tr > 0:
-                has = matched_idx >= 0
-                tr_lab = torch.where(has, gt.labels[matched_idx.clamp(min=0)] if len(gt) > 0
-                                     else torch.full_like(matched_idx, self.num_classes),
-                                     torch.full_like(matched_idx, self.num_classes))
-                labels[:, nd:] = torch.where(late[:, None], tr_lab[None, :], labels[:, nd:])
+            has = matched_idx >= 0 if n_tr > 0 else None
+            if clip_ops.fused(logits_all, boxes_all, gt.boxes) and gt.labels.dtype == torch.int64:
+                labels = clip_ops.focal_labels(lay_i, q_i, g_i, gt.labels, matched_idx, late, nd, n_tr, self.num_classes)
+            else:
+                labels = clip_ops.focal_labels_reference(lay_i, q_i, g_i, gt.labels, matched_idx, late, nd, n_tr,
+                                                         self.num_classes)
             use_kernels = clip_ops.fused(logits_all, boxes_all, gt.boxes)
             if use_kernels:
                 loss_label = loss_label + clip_ops.focal_loss_per_layer(logits_all[:, b, :n_q], labels)

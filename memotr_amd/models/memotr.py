@@ -94,6 +94,10 @@ class MeMOTR(nn.Module):
         still waits for / solves this frame's assignment: ``model(frame=f, stage="encode")`` returns the encoder
         result, ``model(tracks=t, encoded=enc)`` finishes the frame.  Both go through ``forward`` so a
         DistributedDataParallel wrapper sees every call."""
+        if stage == "features":
+            return self._encode_frame_eager(frame, features_only=True)
+        if stage == "encode_features":                 # frame = (features, lo, hi)
+            return self.encode_features(*frame)
         if encoded is None:
             encoded = self._encode_frame_eager(frame) if stage == "encode_eager" else self.encode_frame(frame)
         if stage in ("encode", "encode_eager"):
@@ -138,8 +142,9 @@ class MeMOTR(nn.Module):
                 return enc
         return self._encode_frame_eager(frame)
 
-    def _encode_frame_eager(self, frame: NestedTensor) -> dict:
-        """Backbone -> feature projections -> encoder (independent of the track queries)."""
+    def _encode_frame_eager(self, frame: NestedTensor, features_only: bool = False) -> dict:
+        """Backbone -> feature projections -> encoder (independent of the track queries).  ``features_only``: stop in
+        front of the encoder and return its inputs (``encode_features`` finishes any sub-batch of them)."""
         if self.use_checkpoint and self.checkpoint_level != 3:
             features, pos = checkpoint(self.backbone, frame, use_reentrant=False)
         else:
@@ -157,7 +162,18 @@ class MeMOTR(nn.Module):
             pos.append(self.backbone.position_embedding(level).to(src.device))
             srcs.append(src)
             masks.append(mask)
+        if features_only:
+            return {"srcs": srcs, "masks": masks, "pos": pos, "sizes": getattr(frame, "sizes", None)}
         return self.transformer.encode(srcs=srcs, masks=masks, pos_embeds=pos, geometry=getattr(frame, "sizes", None))
+
+    def encode_features(self, feats: dict, lo: int, hi: int) -> dict:
+        """The encoder over images lo..hi-1 of a ``stage="features"`` result (backbone + projections of a whole clip
+        in one batch -- the convolutions want the large batch -- the transformer encoder in smaller groups, so that a
+        training loop has GPU work queued while the host runs a frame's launch-bound decoder chain; engine.py)."""
+        sizes = feats["sizes"]
+        geometry = None if sizes is None else (sizes[0],) + tuple(sizes[1 + lo:1 + hi])
+        return self.transformer.encode(srcs=[s[lo:hi] for s in feats["srcs"]], masks=[m[lo:hi] for m in feats["masks"]],
+                                       pos_embeds=[p[lo:hi] for p in feats["pos"]], geometry=geometry)
 
     def _class_head_stack(self, clip_key):
         """The class heads' weights (n, C, K) and biases (n, 1, K) as two stacks.  With a ``clip_key`` (the training

@@ -508,3 +508,42 @@ def test_relu_mask_and_bias_gradient_partials_in_one_pass(dtype, rows, cols):
     ref = want.double().sum(0)
     assert gb.dtype == torch.float32
     assert float((gb.double() - ref).abs().max()) <= 1e-5 * rows ** 0.5 * float(want.float().abs().max())
+
+
+# ----------------------------------------------------------------------------- per-frame bookkeeping (ABI 10)
+@pytest.mark.parametrize("n_tr,n_gt", [(0, 5), (7, 5), (40, 13), (3, 300), (300, 3)])
+def test_track_ownership_matches_the_torch_formulation(n_tr, n_gt):
+    """clipops_track_ownership_i64 against the compare / amax / any chain it replaces (models/criterion.py), duplicated
+    ground-truth ids included (the LAST one owns), writing ``free`` into the head of a larger buffer."""
+    from memotr_amd.functions import clip_ops
+    g = torch.Generator().manual_seed(n_tr * 1000 + n_gt)
+    gt_ids = torch.randint(0, max(n_gt // 2, 2), (n_gt,), generator=g).cuda()            # duplicates on purpose
+    tr_ids = torch.randint(-1, max(n_gt // 2, 2) + 3, (n_tr,), generator=g).cuda()
+    buf = torch.full((n_gt + 9,), 7.0, device="cuda")
+    matched, free = clip_ops.track_ownership(tr_ids, gt_ids, free_out=buf[:n_gt])
+    if n_tr:
+        want_m, want_f = clip_ops.track_ownership_reference(tr_ids, gt_ids)
+        assert torch.equal(matched, want_m) and torch.equal(free, want_f)
+    else:
+        assert matched.numel() == 0 and bool((free == 1).all())
+    assert bool((buf[n_gt:] == 7.0).all())
+
+
+@pytest.mark.parametrize("n_tr", [0, 11])
+def test_focal_labels_match_the_torch_formulation(n_tr):
+    from memotr_amd.functions import clip_ops
+    g = torch.Generator().manual_seed(n_tr)
+    n_layers, nd, n_gt, K = 6, 300, 9, 8
+    late = torch.tensor([False, True, True, False, True, True]).cuda()
+    gt_labels = torch.randint(0, K, (n_gt,), generator=g).cuda()
+    pairs = [(l, int(q), int(t)) for l in range(n_layers)
+             for q, t in zip(torch.randperm(nd, generator=g)[:n_gt], torch.randperm(n_gt, generator=g))]
+    lay, q, t = (torch.tensor(c).cuda() for c in zip(*pairs))
+    matched = torch.randint(-1, n_gt, (n_tr,), generator=g).cuda() if n_tr else None
+    got = clip_ops.focal_labels(lay, q, t, gt_labels, matched, late, nd, n_tr, K)
+    want = clip_ops.focal_labels_reference(lay, q, t, gt_labels, matched, late, nd, n_tr, K)
+    assert got.shape == (n_layers, nd + n_tr) and torch.equal(got, want)
+    empty = torch.zeros((0,), dtype=torch.long, device="cuda")
+    got0 = clip_ops.focal_labels(empty, empty, empty, gt_labels, matched, late, nd, n_tr, K)
+    assert torch.equal(got0, clip_ops.focal_labels_reference(empty, empty, empty, gt_labels, matched, late, nd, n_tr, K))
+

@@ -196,7 +196,7 @@ def test_memotr_two_frame_inference_matches_reference(monkeypatch):
     assert len(tracks[0]) == g["f1_next_ids"].shape[0] > 0
 
 
-@pytest.mark.parametrize("chunks", ["0", "1", "all", "1,2", "lazy:2", "auto"])
+@pytest.mark.parametrize("chunks", ["0", "1", "all", "1,2", "lazy:2", "auto", "enc:1", "enc:1,2"])
 def test_train_step_matches_reference(monkeypatch, chunks):
     """the body of train_engine.py:192-238 (criterion + matcher + query updater + backward)
     on the reference's seeded 3-frame clip: per-frame track sets, every loss term, and the gradient norm of

@@ -67,7 +67,7 @@ def test_two_frame_inference_on_hip_operator_matches_reference(hip_lib):
             assert np.array_equal(tracks[0].ids.cpu().numpy(), g[f"f{i}_next_ids"])
 
 
-@pytest.mark.parametrize("chunks", ["0", "all", "auto", "auto/two-streams", "1,1,1/two-streams"])
+@pytest.mark.parametrize("chunks", ["0", "all", "auto", "auto/two-streams", "1,1,1/two-streams", "enc:1", "enc:2,1"])
 def test_train_step_on_hip_operator_matches_reference(chunks, monkeypatch):
     from memotr_amd.engine import clip_forward_backward
     from memotr_amd.models.criterion import build as build_criterion
