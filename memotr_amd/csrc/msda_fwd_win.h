@@ -277,7 +277,7 @@ __device__ __forceinline__ void win_place(WinTables &tb, const WinPlan &pl, int 
 // instantiations hold none of it (as a run-time test the stamps cost 1.1 us per launch, round 4).
 // TV: float, or bf16_t (round 6: 64-byte rows -- windows of half the bytes, 16 pixels per fill instruction, 8-byte LDS
 // reads widened in registers; locations, weights and accumulation stay fp32)
-template <typename TV, bool FUSED, int WPS, int NE, bool TRACE = false>
+template <typename TV, bool FUSED, int WPS, int NE, bool TRACE = false, int PB = 4>
 __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(const TV *__restrict__ value,
                                                            const int64_t *__restrict__ lstart, const PointSrc src,
                                                            TV *__restrict__ out, const WinPlan pl) {
@@ -715,49 +715,47 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
         __syncthreads();      // (also: the row -> query table is complete from here on, windows or not)
     };
     // the LDS-served points of the step whose records are in place
-    auto lds_points = [&](unsigned gmask, f32x4 acc) -> f32x4 {
-            int t0 = T0;
-            for (; t0 + 4 <= LP; t0 += 4) {
-                const u32x4 *rp = rec_g + 2 * t0;
-                if (((gmask >> t0) & 15u) == 0u) {
-                    u32x4 r[4];
-                    f32x4 v[4][2];
+    // (`nb`: points per batch as a type -- PB of them first (one wait for PB records, one for 2 PB rows: the 256-register
+    //  build, two wavefronts per SIMD, hides the LDS round trips by what one wavefront has in flight), then fours)
+    auto lds_batch = [&](auto nb, int t0, unsigned gmask, f32x4 acc) -> f32x4 {
+        constexpr int NB = decltype(nb)::value;
+        const u32x4 *rp = rec_g + 2 * t0;
+        u32x4 r[NB];
+        f32x4 v[NB][2];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) r[i] = rp[2 * i];
+        for (int i = 0; i < NB; ++i) r[i] = rp[2 * i];
+        if (((gmask >> t0) & ((1u << NB) - 1u)) == 0u) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        v[i][0] = win_lds_ch4<TV>(s_dyn + (r[i].y + sub16));
-                        v[i][1] = win_lds_ch4<TV>(s_dyn + (r[i].w + sub16));
-                    }
+            for (int i = 0; i < NB; ++i) {
+                v[i][0] = win_lds_ch4<TV>(s_dyn + (r[i].y + sub16));
+                v[i][1] = win_lds_ch4<TV>(s_dyn + (r[i].w + sub16));
+            }
+        } else {
+            // some row's point left its window: those lanes read `value` itself, the others their window;
+            // all rows of the batch are requested before the first is used
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        acc += __uint_as_float(r[i].x) * v[i][0];
-                        acc += __uint_as_float(r[i].z) * v[i][1];
-                    }
-                } else {
-                    // some row's point left its window: those lanes read `value` itself, the others their window;
-                    // all eight rows of the batch are requested before the first is used
-                    u32x4 r[4];
-                    f32x4 v[4][2];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) r[i] = rp[2 * i];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const bool g = (r[i].y & 1u) != 0u;
-                        v[i][0] = win_lds_ch4<TV>(s_dyn + ((g ? zero_off : r[i].y) + sub16));
-                        v[i][1] = win_lds_ch4<TV>(s_dyn + ((g ? zero_off : r[i].w) + sub16));
-                        if (g) {
-                            v[i][0] = buf_load_ch4<TV>(vr, (r[i].y & ~1u) + sub16);
-                            v[i][1] = buf_load_ch4<TV>(vr, r[i].w + sub16);
-                        }
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        acc += __uint_as_float(r[i].x) * v[i][0];
-                        acc += __uint_as_float(r[i].z) * v[i][1];
-                    }
+            for (int i = 0; i < NB; ++i) {
+                const bool g = (r[i].y & 1u) != 0u;
+                v[i][0] = win_lds_ch4<TV>(s_dyn + ((g ? zero_off : r[i].y) + sub16));
+                v[i][1] = win_lds_ch4<TV>(s_dyn + ((g ? zero_off : r[i].w) + sub16));
+                if (g) {
+                    v[i][0] = buf_load_ch4<TV>(vr, (r[i].y & ~1u) + sub16);
+                    v[i][1] = buf_load_ch4<TV>(vr, r[i].w + sub16);
                 }
             }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            acc += __uint_as_float(r[i].x) * v[i][0];
+            acc += __uint_as_float(r[i].z) * v[i][1];
+        }
+        return acc;
+    };
+    auto lds_points = [&](unsigned gmask, f32x4 acc) -> f32x4 {
+            int t0 = T0;
+            if constexpr (PB > 4)
+                for (; t0 + PB <= LP; t0 += PB) acc = lds_batch(std::integral_constant<int, PB>{}, t0, gmask, acc);
+            for (; t0 + 4 <= LP; t0 += 4) acc = lds_batch(std::integral_constant<int, 4>{}, t0, gmask, acc);
             for (; t0 < LP; ++t0) acc = win_mixed_point<TV>(rec_g[2 * t0], s_dyn, zero_off, vr, sub16, acc);
             return acc;
     };
@@ -866,9 +864,13 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
         if (stat_wg) {
             // the share's denominator: the windowed points of the rows this wavefront staged (counted once, here --
             // a second ballot per step in the staging loop cost 0.5 us per launch)
-            const int st = wave + (lane >> 2) * nw;
-            const bool mine = lane < iters * 4 && st < steps && s_rowq[st * 4 + (lane & 3)] >= 0;
-            const unsigned n_live = (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(mine)) * (unsigned)(LP - T0);
+            unsigned n_rows = 0;
+            for (int k0 = 0; k0 < iters; k0 += 16) {      // sixteen steps (x four rows) per ballot
+                const int k = k0 + (lane >> 2), st = wave + k * nw;
+                const bool mine = k < iters && st < steps && s_rowq[st * 4 + (lane & 3)] >= 0;
+                n_rows += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(mine));
+            }
+            const unsigned n_live = n_rows * (unsigned)(LP - T0);
             unsigned n_off = v_off;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) n_off += __shfl_xor(n_off, o, 64);

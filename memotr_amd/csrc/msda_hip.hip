@@ -49,6 +49,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <type_traits>
 
 #include "../../include/msda_hip.h"
 #include "msda_common.h"
@@ -119,7 +120,7 @@ std::atomic<int> opt_fwd_win_l0{1};         // first level served from an LDS wi
 std::atomic<int> opt_fwd_win_margins{0x3333};  // window margin per level, 4 bits each (level 0 in the low nibble)
 std::atomic<int> opt_fwd_win_ablate{0};     // profiling only
 std::atomic<int> opt_fwd_win_place{0};      // 1: measured window placement in every workgroup (rounds 3-4)
-std::atomic<int> opt_fwd_win_wps{0};        // 3 / 4: force the 168- / 128-register build
+std::atomic<int> opt_fwd_win_wps{0};        // 3 / 4: force the 168- / 128-register build; 2 (256 threads): the 256-register build
 std::atomic<int> opt_fwd_win_early{9};      // 0 / 2 / 4: level-0 points requested before the LDS phase (else: by register budget)
 constexpr int kWinEarlyW4 = 0;              // ... of the 128-register build (0 and 2 time the same; 0 needs 107 registers, no spill)
 std::atomic<int> opt_bwd_side_rows{1};      // slim split backward: side kernels with one lane per (query, head) row (0: one lane per point)
@@ -628,15 +629,21 @@ int forward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart, 
         hipLaunchKernelGGL((msda_fwd_d32_win<TV, FU, WPS, NE, true>), dim3(grid), dim3(threads), lds, stream,        \
                            value, lstart, src, out, wp);                                                             \
     } while (0)
+#define MSDA_LAUNCH_WIN_P(FU, WPS, NE, PB, NAME)                                                                     \
+    do {                                                                                                             \
+        rc = allow_big_lds(msda_fwd_d32_win<TV, FU, WPS, NE, false, PB>, lds);                                       \
+        if (rc) return rc;                                                                                           \
+        g_kernel = NAME;                                                                                             \
+        hipLaunchKernelGGL((msda_fwd_d32_win<TV, FU, WPS, NE, false, PB>), dim3(grid), dim3(threads), lds, stream,   \
+                           value, lstart, src, out, wp);                                                             \
+    } while (0)
                     wp.ablate = opt_fwd_win_ablate.load();
                     wp.trace = reinterpret_cast<unsigned long long *>(((unsigned long long)opt_fwd_win_trace_hi.load() << 31) |
                                                                       (unsigned long long)opt_fwd_win_trace_lo.load());
-                    // The kernel's share denominator covers 16 staged steps per wavefront (one ballot) and its publisher is
-                    // wavefront 1: workgroup shapes reachable through the options only ("fwd_win_block" 128 / 256 with
-                    // 16 x 16 regions: 22-43 steps; 64 threads) run without statistics instead of reporting an inflated
-                    // off-window share (advisor, round 5)
+                    // The kernel's publisher is wavefront 1: a 64-thread workgroup (options only) runs without statistics.
+                    // (The share's denominator counts a wavefront's staged rows sixteen steps per ballot, any step count.)
                     const int win_nw = threads / 64;
-                    const bool stats_ok = slot != nullptr && win_nw >= 2 && (wp.steps + win_nw - 1) / win_nw <= 16;
+                    const bool stats_ok = slot != nullptr && win_nw >= 2;
                     if (stats_ok) {     // (cumulative counters, fixed addresses: a captured launch counts like an eager one)
                         wp.stats = slot->dev;
                         wp.stats_host = slot->host_dev;
@@ -649,6 +656,7 @@ int forward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart, 
                     // of LDS each) -> 168 registers, all four level-0 points requested before the LDS phase; 512-thread
                     // workgroups (two per CU) or four small ones -> 128 registers, two of them
                     int wps = opt_fwd_win_wps.load();
+                    const bool wide = wps == 2 && threads <= 256 && sizeof(TV) == 4 && !wp.trace && !wp.ablate;
                     if (wps != 3 && wps != 4) wps = (threads <= 256 && lds + 640 > 40 * 1024) ? 3 : 4;
                     int early = opt_fwd_win_early.load();          // 0 / 2 / 4 points; anything else: by budget
                     if (threads > 256) {
@@ -660,6 +668,21 @@ int forward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart, 
                     // (the profiling instantiation -- timeline stamps, ablation bits -- exists for the default shape only)
                     if ((wp.trace || wp.ablate) && (wps == 3 || early == 2))
                         return fail(MSDA_EINVAL, "fwd_win_trace / fwd_win_ablate: profiling build of the default launch shape only");
+                    if constexpr (sizeof(TV) == 4) {
+                        if (wide) {     // "fwd_win_wps" 2: two wavefronts per SIMD, 256 registers, twelve LDS points per wait
+                            // (six points per wait, "p6", was built and measured too: 67.5 / 70.1 us against p12's 65.9 / 68.6
+                            //  -- profiles/r06_fwd_win_sweep_wide.txt; not kept in the library)
+                            const int e4 = opt_fwd_win_early.load() == 4;
+                            if (fused) {
+                                if (e4) MSDA_LAUNCH_WIN_P(true, 2, 4, 12, "msda_fwd_d32_win<fused,w2,e4,p12>");
+                                else MSDA_LAUNCH_WIN_P(true, 2, 0, 12, "msda_fwd_d32_win<fused,w2,p12>");
+                            } else {
+                                if (e4) MSDA_LAUNCH_WIN_P(false, 2, 4, 12, "msda_fwd_d32_win<w2,e4,p12>");
+                                else MSDA_LAUNCH_WIN_P(false, 2, 0, 12, "msda_fwd_d32_win<w2,p12>");
+                            }
+                            return check_launch(g_kernel);
+                        }
+                    }
                     if constexpr (sizeof(TV) == 2) {       // bf16 rows: the default shape only (512 threads, no early loads)
                         if (fused) MSDA_LAUNCH_WIN(true, 4, 0, "msda_fwd_d32_win<bf16,fused,w4>");
                         else MSDA_LAUNCH_WIN(false, 4, 0, "msda_fwd_d32_win<bf16,w4>");
@@ -681,6 +704,7 @@ int forward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart, 
                         }
                     }
 #undef MSDA_LAUNCH_WIN
+#undef MSDA_LAUNCH_WIN_P
 #undef MSDA_LAUNCH_WIN_T
                     return check_launch(g_kernel);
                 }

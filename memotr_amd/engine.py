@@ -234,6 +234,16 @@ def clip_forward_backward(model: nn.Module, criterion, batch: dict, device, use_
             encoded[lo + j]["frame_slot"] = lo + j
             encoded[lo + j]["clip_key"] = clip_key
 
+    # The query updater's selection of active tracks (training, no drop / insert augmentation) from flags that travel
+    # to the host with the matching costs instead of a boolean mask on the device (models/criterion.py: keep_rows);
+    # MEMOTR_KEEP_ROWS=0: the mask.
+    upd = getattr(core, "query_updater", None)
+    hint = (chunks is not None and upd is not None and core.training and getattr(upd, "tp_drop_ratio", 1.0) == 0.0
+            and getattr(upd, "fp_insert_ratio", 1.0) == 0.0 and os.environ.get("MEMOTR_KEEP_ROWS", "1") != "0")
+    criterion.keep_threshold = upd.update_threshold if hint else None
+    if upd is not None:
+        upd.__dict__["_keep_rows_ok"] = hint
+
     def set_up():
         tr = TrackInstances.init_tracks(batch=batch, hidden_dim=core.hidden_dim, num_classes=core.num_classes,
                                         device=device, use_dab=use_dab)

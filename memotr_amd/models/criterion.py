@@ -12,6 +12,7 @@ normalisation all-reduces (criterion.py:122-124) travel as one message.
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Tuple
 
 import torch
@@ -24,6 +25,7 @@ from ..utils.box_ops import box_cxcywh_to_xyxy, box_iou_union, generalized_box_i
 from ..utils.utils import distributed_world_size, is_distributed
 from .matcher import HungarianMatcher
 from .matcher import build as build_matcher
+from .utils import logits_to_scores
 
 _LOSS_KEYS = ("box_l1_loss", "box_giou_loss", "label_focal_loss")
 
@@ -205,22 +207,42 @@ class ClipCriterion:
             boxes_all = torch.stack([o["pred_bboxes"] for o in layers])   # (n_layers, B, Nq, 4)
 
         # ---- device side: ownership of ground truths + stacked cost tensors, then one transfer ----
-        payload, n_gt_list = [], []
+        payload, n_gt_list, n_flag_list = [], [], []
+        thr = getattr(self, "keep_threshold", None)
         for b in range(B):
             tr, gt = tracked_instances[b], gts[b]
             n_gt, n_tr = len(gt), len(tr)
             n_gt_list.append(n_gt)
             lg, bx = logits_all.detach()[:, b, :nd], boxes_all.detach()[:, b, :nd]
-            kernels = clip_ops.fused(lg, bx, gt.boxes) and n_gt > 0 and tr.ids.dtype == gt.ids.dtype == torch.int64
+            # what the query updater's selection of active tracks will ask of the device -- score above its threshold?
+            # identity still alive? -- answered here for every query / track / ground truth and sent along with the
+            # costs: the host then knows which rows stay active and uploads their indices with the matching's, where
+            # the boolean mask's nonzero() was a second stream synchronisation per frame (finish_tracks: keep_rows)
+            n_fl = (nd + 2 * n_tr + n_gt) if thr is not None else 0
+            n_flag_list.append(n_fl)
+            flags = None
+            if n_fl:
+                score_ok = torch.max(logits_to_scores(batch_item(model_outputs["pred_logits"], b).detach()[:nd + n_tr]),
+                                     dim=1).values > thr
+                flags = (score_ok, tr.ids >= 0, gt.ids >= 0)
+            kernels = (clip_ops.fused(lg, bx, gt.boxes) and n_gt > 0 and tr.ids.dtype == gt.ids.dtype == torch.int64
+                       and os.environ.get("MEMOTR_FUSED_BOOKKEEPING", "1") != "0")
             if kernels:
                 # ownership and the whole cost tensor written straight into the buffer that travels to the host:
                 # two launches (include/clip_ops_hip.h: clipops_track_ownership_i64, clipops_match_cost_f32)
-                buf = torch.empty((n_gt + n_layers * nd * n_gt,), dtype=torch.float32, device=lg.device)
-                tr.matched_idx, _ = clip_ops.track_ownership(tr.ids, gt.ids, free_out=buf[:n_gt])
+                buf = torch.empty((n_fl + n_gt + n_layers * nd * n_gt,), dtype=torch.float32, device=lg.device)
+                if n_fl:
+                    buf[:nd + n_tr].copy_(flags[0])
+                    if n_tr:
+                        buf[nd + n_tr:nd + 2 * n_tr].copy_(flags[1])
+                    buf[nd + 2 * n_tr:n_fl].copy_(flags[2])
+                tr.matched_idx, _ = clip_ops.track_ownership(tr.ids, gt.ids, free_out=buf[n_fl:n_fl + n_gt])
                 clip_ops.match_cost(lg, bx, gt.labels, gt.boxes, self.matcher.cost_class, self.matcher.cost_bbox,
-                                    self.matcher.cost_giou, out=buf[n_gt:])
+                                    self.matcher.cost_giou, out=buf[n_fl + n_gt:])
                 payload.append(buf)
                 continue
+            if n_fl:
+                payload += [f.to(torch.float32) for f in flags]
             if n_tr > 0 and n_gt > 0:
                 # index of the LAST ground truth carrying the id (the reference's ``gt_ids_to_idx`` dict keeps the
                 # last one when a frame repeats an id, criterion.py:166-170), -1 when the identity is gone
@@ -256,7 +278,7 @@ class ClipCriterion:
                 host = flat
         return {"model_outputs": model_outputs, "tracked_instances": tracked_instances, "frame_idx": frame_idx,
                 "layers": layers, "early": early, "logits_all": logits_all, "boxes_all": boxes_all,
-                "n_gt_list": n_gt_list, "host": host, "ready": ready, "keep": keep}
+                "n_gt_list": n_gt_list, "n_flag_list": n_flag_list, "host": host, "ready": ready, "keep": keep}
 
     def _constant(self, key, values, dtype, device):
         """Small per-configuration device constants (uploaded once, not once per frame)."""
@@ -297,9 +319,12 @@ class ClipCriterion:
         # ---- host side: the assignment problems ----
         pos = 0
         rows_layer, rows_q, rows_g = [[] for _ in range(B)], [[] for _ in range(B)], [[] for _ in range(B)]
-        main_q = []
+        main_q, flags_h = [], []
         for b in range(B):
             n_gt = n_gt_list[b]
+            n_fl = state["n_flag_list"][b]
+            flags_h.append(host[pos:pos + n_fl].bool().numpy() if n_fl else None)
+            pos += n_fl
             free_h = host[pos:pos + n_gt].bool().numpy()
             pos += n_gt
             cost_h = host[pos:pos + n_layers * nd * n_gt].view(n_layers, nd, n_gt).numpy()
@@ -325,9 +350,26 @@ class ClipCriterion:
             tr, gt = tracked_instances[b], gts[b]
             n_tr = len(tr)
             flat = lambda rows: [x for r in rows for x in r]                       # noqa: E731
-            idx = upload([flat(rows_layer[b]), flat(rows_q[b]), flat(rows_g[b])], torch.long, dev)
-            lay_i, q_i, g_i = idx[0], idx[1], idx[2]
             n_main = len(main_q[b][0])
+            # detections nobody claimed (the host knows the matched detect queries of the last layer)
+            taken = set(int(q) for q in main_q[b][0])
+            free_list = [q for q in range(n_det_out) if q not in taken]
+            # rows of (carried tracks; new tracks; unclaimed detections) the query updater keeps active: the reference's
+            # ``(scores > update_thresh) | (ids >= 0)`` (models/query_updater.py:170-176), from the flags of begin_frame
+            keep_list = None
+            if flags_h[b] is not None:
+                fl = flags_h[b]
+                sc, idf, gtf = fl[:nd + n_tr], fl[nd + n_tr:nd + 2 * n_tr], fl[nd + 2 * n_tr:]
+                keep_list = [i for i in range(n_tr) if sc[nd + i] or idf[i]]
+                keep_list += [n_tr + j for j, (q, g) in enumerate(zip(*main_q[b])) if sc[q] or gtf[g]]
+                keep_list += [n_tr + n_main + k for k, q in enumerate(free_list) if sc[q]]
+            # ONE upload for everything the host found out
+            n_pairs = sum(len(r) for r in rows_q[b])
+            up = upload(flat(rows_layer[b]) + flat(rows_q[b]) + flat(rows_g[b]) + free_list + (keep_list or []),
+                        torch.long, dev)
+            lay_i, q_i, g_i = up[:n_pairs], up[n_pairs:2 * n_pairs], up[2 * n_pairs:3 * n_pairs]
+            free_q = up[3 * n_pairs:3 * n_pairs + len(free_list)]
+            keep_rows = up[3 * n_pairs + len(free_list):] if keep_list is not None else None
             q_idx, gt_idx = q_i[:n_main], g_i[:n_main]                              # layer 0 comes first
 
             nt = TrackInstances(frame_height=tr.frame_height, frame_width=tr.frame_width, hidden_dim=tr.hidden_dim,
@@ -345,9 +387,6 @@ class ClipCriterion:
             nt = nt.to(dev)
             per_clip.append({"idx": (lay_i, q_i, g_i), "n_tr": n_tr, "matched_idx": tr.matched_idx if n_tr > 0 else None})
 
-            # detections nobody claimed (host knows the matched detect queries of the last layer)
-            taken = set(int(q) for q in main_q[b][0])
-            free_q = upload([q for q in range(n_det_out) if q not in taken], torch.long, dev)
             d = TrackInstances(hidden_dim=model_outputs["outputs"].shape[-1],
                                num_classes=model_outputs["pred_logits"].shape[-1]).to(dev)
             d.ref_pts = rows_of(model_outputs["init_ref_pts"], b, free_q)
@@ -360,6 +399,8 @@ class ClipCriterion:
             d.ids = -torch.ones((len(free_q),), dtype=torch.long, device=dev)
             d.matched_idx = -torch.ones((len(free_q),), dtype=torch.long, device=dev)
             d.iou = torch.zeros((len(free_q),), dtype=torch.float, device=dev)
+            if keep_rows is not None:
+                d._keep_rows = keep_rows            # (QueryUpdater.select_active_tracks: index instead of boolean mask)
             unmatched.append(d)
 
             # IoU of every track with the ground truth it owns (kept where it owns none)
@@ -393,7 +434,8 @@ class ClipCriterion:
             n_q = nd + n_tr                                                        # real (unpadded) queries of clip b
             late = self._constant(("late", tuple(early)), [not e for e in early], torch.bool, dev)
             has = matched_idx >= 0 if n_tr > 0 else None
-            if clip_ops.fused(logits_all, boxes_all, gt.boxes) and gt.labels.dtype == torch.int64:
+            if (clip_ops.fused(logits_all, boxes_all, gt.boxes) and gt.labels.dtype == torch.int64
+                    and os.environ.get("MEMOTR_FUSED_BOOKKEEPING", "1") != "0"):
                 labels = clip_ops.focal_labels(lay_i, q_i, g_i, gt.labels, matched_idx, late, nd, n_tr, self.num_classes)
             else:
                 labels = clip_ops.focal_labels_reference(lay_i, q_i, g_i, gt.labels, matched_idx, late, nd, n_tr,

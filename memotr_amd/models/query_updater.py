@@ -179,8 +179,15 @@ class QueryUpdater(nn.Module):
                 #  them with one gather / read them in place -- structures/track_instances.py: cat_packed)
                 active = (TrackInstances.cat_packed if PACKED_TRACKS else cat)(previous_tracks[b], new_tracks[b],
                                                                                unmatched_dets[b])
-                scores = torch.max(logits_to_scores(active.logits), dim=1).values
-                active = active[(scores > self.update_threshold) | (active.ids >= 0)]
+                keep_rows = unmatched_dets[b].__dict__.pop("_keep_rows", None)
+                if keep_rows is not None and self.__dict__.get("_keep_rows_ok", False):
+                    # the criterion already knows which rows pass (models/criterion.py: finish_tracks, from flags that
+                    # travelled to the host with the matching costs): an index, not a boolean mask -- no nonzero(), no
+                    # second stream synchronisation per frame
+                    active = active[keep_rows]
+                else:
+                    scores = torch.max(logits_to_scores(active.logits), dim=1).values
+                    active = active[(scores > self.update_threshold) | (active.ids >= 0)]
                 active.ids = torch.where(active.iou < 0.5, torch.full_like(active.ids, -1), active.ids)
             else:
                 active = cat(previous_tracks[b], new_tracks[b])

@@ -445,3 +445,51 @@ def test_no_grad_frames_follow_the_reference_loop(monkeypatch):
     assert seen == [(False, True), (False, False)]       # frame 0: frozen + no augmentation; frame 1: frozen
     assert torch.isfinite(loss) and loss.requires_grad
     assert any(p.grad is not None and float(p.grad.abs().sum()) > 0 for p in model.parameters())
+
+
+def test_active_track_rows_from_the_host_equal_the_boolean_mask(monkeypatch):
+    """engine / criterion / query updater, round 6: the rows the updater keeps active come as an index the host computed
+    from flags sent along with the matching costs (criterion.finish_tracks: keep_rows) -- the same rows, in the same
+    order, as the reference's boolean mask ``(scores > update_thresh) | (ids >= 0)`` (models/query_updater.py:170-176),
+    with detections above the threshold in the set (a low threshold, so that unclaimed detections DO stay active)."""
+    from memotr_amd.engine import clip_forward_backward
+    from memotr_amd.models.criterion import build as build_criterion
+    from memotr_amd.models.query_updater import QueryUpdater
+    patch_operator(monkeypatch)
+    g = load_model_golden("M6_train_step")
+    T = 3
+    batch = {"imgs": [[t(g[f"img{i}"]) for i in range(T)]],
+             "infos": [[{"ids": t(g[f"gt{i}_ids"]), "labels": torch.zeros(6, dtype=torch.long),
+                         "boxes": t(g[f"gt{i}_boxes"])} for i in range(T)]]}
+    results = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MEMOTR_KEEP_ROWS", mode)
+        torch.manual_seed(0)
+        model = build_memotr(g).train()
+        model.query_updater.update_threshold = 0.50915      # some, not all, unclaimed detections pass (scores: 0.5085-0.5093)
+        cfg = small_config()
+        cfg.update(MATCH_COST_CLASS=2, MATCH_COST_BBOX=5, MATCH_COST_GIOU=2, LOSS_WEIGHT_FOCAL=2, LOSS_WEIGHT_L1=5,
+                   LOSS_WEIGHT_GIOU=2, AUX_LOSS_WEIGHT=[1.0], SAMPLE_LENGTHS=[2, 3, 4, 5])
+        criterion = build_criterion(cfg)
+        used, kept = [], []
+        orig = QueryUpdater.select_active_tracks
+
+        def spy(self, prev, new, unm, no_augment=False):
+            used.append("_keep_rows" in unm[0].__dict__)
+            out = orig(self, prev, new, unm, no_augment=no_augment)
+            kept.append((len(prev[0]), len(new[0]), len(unm[0]), out[0].ids.clone(), out[0].boxes.detach().clone()))
+            return out
+
+        monkeypatch.setattr(QueryUpdater, "select_active_tracks", spy)
+        model.encode_chunks = "all"
+        loss, _ = clip_forward_backward(model, criterion, batch, torch.device("cpu"), use_dab=True)
+        monkeypatch.setattr(QueryUpdater, "select_active_tracks", orig)
+        assert used == [mode == "1"] * (T - 1)
+        results[mode] = (float(loss), kept, {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+    (l1, k1, g1), (l0, k0, g0) = results["1"], results["0"]
+    assert l1 == l0
+    assert any(len(ids) > n_prev + n_new for n_prev, n_new, _, ids, _ in k1)       # detections above the threshold stayed
+    assert any(len(ids) < n_prev + n_new + n_unm for n_prev, n_new, n_unm, ids, _ in k1)     # ... and some rows went
+    for a, b in zip(k1, k0):
+        assert a[:3] == b[:3] and torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
+    assert g1.keys() == g0.keys() and all(torch.equal(g1[n], g0[n]) for n in g1)

@@ -94,6 +94,10 @@ CONFIGS = [
     dict(fwd_win_margins=0x5432),
     dict(fwd_win_margins=0x7777, fwd_win_rlog=4),
     dict(fwd_win_rlog=5, fwd_win_block=512, fwd_win_margins=0x2222),
+    # round 6: two wavefronts per SIMD at 256 registers, twelve LDS points per wait (measured slower; kept as an option)
+    dict(fwd_win_rlog=4, fwd_win_block=256, fwd_win_wps=2, fwd_win_early=0),
+    dict(fwd_win_rlog=4, fwd_win_block=256, fwd_win_wps=2, fwd_win_early=4),
+    dict(fwd_win_rlog=3, fwd_win_block=256, fwd_win_wps=2, fwd_win_early=4, fwd_win_margins=0x1111),   # ... points leaving their windows
 ]
 
 
@@ -172,8 +176,9 @@ FUSED_PYRAMIDS = [
 
 @pytest.mark.parametrize("case", FUSED_PYRAMIDS, ids=lambda c: f"seed{c[0]}")
 @pytest.mark.parametrize("cfg", [dict(), dict(fwd_win_rlog=3, fwd_win_block=256), dict(fwd_win_l0=0),
-                                 dict(fwd_win_margins=0x1111, fwd_win_block=512), dict(fwd_win_early=0)],
-                         ids=["default", "r3_b256", "all_levels", "m1_b512", "e0"])
+                                 dict(fwd_win_margins=0x1111, fwd_win_block=512), dict(fwd_win_early=0),
+                                 dict(fwd_win_rlog=4, fwd_win_block=256, fwd_win_wps=2, fwd_win_early=4)],
+                         ids=["default", "r3_b256", "all_levels", "m1_b512", "e0", "w2_p12"])
 def test_win_fused_forward_matches_checker(msda, hip_lib, case, cfg):
     seed, N, M, P, shapes, ref_dim = case
     for k, v in cfg.items():

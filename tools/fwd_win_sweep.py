@@ -44,6 +44,13 @@ CONFIGS = [
     ("r6 win l0=2 8x8 256 w3 e4", dict(R3, fwd_win_block=256, fwd_win_l0=2)),
     ("r6 win l0=3 e2", dict(fwd_variant=12, fwd_win_l0=3, fwd_win_early=2)),
     ("r6 win margins 3,3,2,2 (levels 2-3 smaller)", dict(fwd_variant=12, fwd_win_margins=0x2233)),
+    # round 6, late: two wavefronts per SIMD at 256 registers, 12 (6) LDS points per wait ("fwd_win_wps" 2, 256 threads)
+    ("r6w 16x16 256 thr w2 p12 e0", dict(fwd_variant=12, fwd_win_rlog=4, fwd_win_block=256, fwd_win_wps=2, fwd_win_early=0)),
+    ("r6w 16x16 256 thr w2 p12 e4", dict(fwd_variant=12, fwd_win_rlog=4, fwd_win_block=256, fwd_win_wps=2, fwd_win_early=4)),
+    ("r6w 16x8 256 thr w2 p12 e4", dict(R3, fwd_win_rlogx=4, fwd_win_block=256, fwd_win_wps=2, fwd_win_early=4)),
+    ("r6w 16x8 256 thr w2 p12 e0", dict(R3, fwd_win_rlogx=4, fwd_win_block=256, fwd_win_wps=2, fwd_win_early=0)),
+    ("r6w 8x8 256 thr w2 p12 e4", dict(R3, fwd_win_block=256, fwd_win_wps=2, fwd_win_early=4)),
+    ("r6w 16x16 256 thr w4 (4 pts per wait)", dict(fwd_variant=12, fwd_win_rlog=4, fwd_win_block=256, fwd_win_wps=4, fwd_win_early=0)),
 ]
 
 
