@@ -230,41 +230,59 @@ def paired_query_projections(root: nn.Module, named):
     """Order the parameters of ``root`` for the flat argument of a capture so that, for every deformable-attention module,
     ``sampling_offsets.weight`` is directly followed by ``attention_weights.weight`` and the two biases likewise: the
     stacked (offsets; logits) projection the module feeds its one query GEMM with is then a VIEW of the flat tensor, not a
-    concatenation made by every replay (two kernels per layer and frame; the concatenation's gradient was slices anyway).
-    Returns (names, parameters, [(name of sampling_offsets.weight, offset, rows_w, cols, offset_b, rows_b), ...])."""
+    concatenation made by every replay (two kernels per layer and frame).
+    Returns (names, parameters, groups): ``groups`` = [(member names, member shapes, stacked shape or None), ...] in flat
+    order -- the flat tensor is split ONCE, by group; a pair is one piece of that split (``split_parameters``)."""
     from ..modules.ms_deform_attn import MSDeformAttn
     by_name = dict(named)
-    pairs = {}
+    pairs = []
     for mod_name, m in root.named_modules():
-        if isinstance(m, MSDeformAttn):
+        if isinstance(m, MSDeformAttn) and os.environ.get("MEMOTR_QPROJ_VIEW", "1") != "0":
             pre = mod_name + "." if mod_name else ""
             keys = [pre + k for k in ("sampling_offsets.weight", "attention_weights.weight", "sampling_offsets.bias",
                                       "attention_weights.bias")]
-            if all(k in by_name for k in keys) and by_name[keys[0]].dtype == by_name[keys[1]].dtype:
-                pairs[keys[0]] = keys
-    taken = {k for keys in pairs.values() for k in keys}
-    order = [n for n, _ in named if n not in taken]
-    for keys in pairs.values():
-        order += keys
-    names = tuple(order)
+            if all(k in by_name for k in keys) and by_name[keys[0]].dtype == by_name[keys[1]].dtype \
+                    and by_name[keys[0]].shape[1:] == by_name[keys[1]].shape[1:]:
+                pairs.append(keys)
+    taken = {k for keys in pairs for k in keys}
+    groups = [((n,), (tuple(p.shape),), None) for n, p in named if n not in taken]
+    for w0, w1, b0, b1 in pairs:
+        for a, b in ((w0, w1), (b0, b1)):
+            pa, pb = by_name[a], by_name[b]
+            groups.append(((a, b), (tuple(pa.shape), tuple(pb.shape)), (pa.shape[0] + pb.shape[0],) + tuple(pa.shape[1:])))
+    names = tuple(n for g in groups for n in g[0])
     params = tuple(by_name[n] for n in names)
-    offsets, pos = {}, 0
-    for n, p in zip(names, params):
-        offsets[n] = pos
-        pos += p.numel()
-    fused = []
-    for first, keys in pairs.items():
-        w0, w1, b0, b1 = (by_name[k] for k in keys)
-        fused.append((first, offsets[keys[0]], w0.shape[0] + w1.shape[0], w0.shape[1], offsets[keys[2]],
-                      b0.shape[0] + b1.shape[0]))
-    return names, params, fused
+    return names, params, groups
 
 
-def attach_fused_projections(sub: dict, flat: torch.Tensor, fused) -> None:
-    """Tag each module's ``sampling_offsets.weight`` stand-in with the views of ``flat`` that ARE its stacked weight and bias
-    (``MSDeformAttn._fused_query_projection`` picks them up)."""
-    for first, off_w, rows, cols, off_b, rows_b in fused:
-        sub[first]._msda_fused_qproj = (flat.narrow(0, off_w, rows * cols).view(rows, cols), flat.narrow(0, off_b, rows_b))
+def split_parameters(flat: torch.Tensor, groups) -> dict:
+    """{name: view} of the flat parameter tensor for ``torch.func.functional_call``.  ONE split of ``flat`` (its backward:
+    one concatenation); a pair's piece is the module's stacked weight (bias) as it lies, tagged on the
+    ``sampling_offsets`` stand-ins for ``MSDeformAttn._fused_query_projection``.  The pair's members are views of the
+    PIECE, and the fused module does not read them: nothing but the split stands between the flat tensor and the stack.
+    (Round 6 first took the stack as ``flat.narrow(...)``: each narrow's backward is a zero-fill of the WHOLE flat tensor
+    -- 46 MB -- a memcpy node and a full-size add: 12 memcpy nodes and 48 kernels per decoder backward graph, +3 ms per
+    train step for the 0.06 ms the view saved in the forward; tools/qproj_ab.sh, profiles/r06_qproj_ab.txt.)"""
+    def numel(shape):
+        n = 1
+        for d in shape:
+            n *= d
+        return n
+
+    pieces = flat.split([sum(numel(sh) for sh in g[1]) for g in groups])
+    sub, stacks = {}, {}
+    for (names, shapes, stacked), piece in zip(groups, pieces):
+        if stacked is None:
+            sub[names[0]] = piece.view(shapes[0])
+            continue
+        off = 0
+        for n, sh in zip(names, shapes):
+            sub[n] = piece.narrow(0, off, numel(sh)).view(sh)
+            off += numel(sh)
+        stacks[names[0]] = piece.view(stacked)
+    for first in [k for k in stacks if k.endswith("sampling_offsets.weight")]:
+        sub[first]._msda_fused_qproj = (stacks[first], stacks[first[:-len("weight")] + "bias"])
+    return sub
 
 
 class DecoderGraphs(GraphCache):
@@ -344,17 +362,11 @@ class DecoderGraphs(GraphCache):
         if len(named) != sum(1 for _ in loop.named_parameters(remove_duplicate=False)):
             self.failed = True      # a module shared between layers (no box refinement clones): see DecoderLoop
             return None
-        names, params, fused = paired_query_projections(loop, named)
-        sizes = [p.numel() for p in params]
-        views = [p.shape for p in params]
+        names, params, groups = paired_query_projections(loop, named)
         n_user = len(args)
 
         def run(*flat_in):
-            flat_p = flat_in[n_user]
-            pieces = flat_p.split(sizes)
-            sub = {n: w.view(s) for n, w, s in zip(names, pieces, views)}
-            attach_fused_projections(sub, flat_p, fused)
-            return torch.func.functional_call(loop, sub, tuple(flat_in[:n_user]))
+            return torch.func.functional_call(loop, split_parameters(flat_in[n_user], groups), tuple(flat_in[:n_user]))
 
         with torch.no_grad():
             flat = torch.cat([p.reshape(-1) for p in params])

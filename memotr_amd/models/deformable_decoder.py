@@ -223,8 +223,11 @@ class DeformableDecoderLayer(nn.Module):
         nd = self.n_det_queries
         track_tgt = None
         if not merge_det_track:   # early layers see the detect queries only
-            track_tgt = tgt[:, nd:, :]
-            tgt, query_pos = tgt[:, :nd, :], query_pos[:, :nd, :]
+            # (ONE split, not two slices: a slice's backward is a zero-fill of the whole tensor plus a copy -- inside a
+            #  capture a memcpy node, ~27 us of host time per replay, tools/graph_launch_probe.py -- and the two meet
+            #  in an add; the split's backward is one concatenation)
+            tgt, track_tgt = tgt.split((nd, tgt.shape[1] - nd), dim=1)
+            query_pos = query_pos[:, :nd, :]
             reference_points, query_mask = reference_points[:, :nd], query_mask[:, :nd]
             query_mask._no_padding = True             # padding only ever sits behind the track queries
         if self.extra_track_attn:

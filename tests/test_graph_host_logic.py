@@ -162,3 +162,53 @@ def test_sequence_tracker_report_filters_and_converts_like_the_submit_loop():
     assert torch.allclose(out.area, torch.tensor([0.2 * 400 * 0.2 * 200, 0.3 * 400 * 0.3 * 200]))
     empty = st._report(TrackInstances(hidden_dim=8, num_classes=2, use_dab=True), 200, 400)
     assert len(empty) == 0 and empty.boxes.shape == (0, 4)
+
+
+def test_flat_parameters_split_once_with_the_stacked_query_projection_as_one_piece():
+    """models/decoder_graphs.py: the decoder's parameters enter a capture as ONE flat tensor; ``split_parameters`` hands
+    ``functional_call`` a view per parameter and, per deformable-attention module, the stacked (offsets; logits) weight
+    and bias as they lie in the flat tensor.  Nothing but the one split may stand between the flat tensor and a stack: a
+    ``narrow`` of the flat tensor would put a zero-fill of the whole tensor, a copy and a full-size add per use into the
+    captured backward (+3 ms per train step when round 6 did that)."""
+    import torch.nn as nn
+    from memotr_amd.models.decoder_graphs import paired_query_projections, split_parameters
+    from memotr_amd.modules.ms_deform_attn import MSDeformAttn
+
+    class Root(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = MSDeformAttn(d_model=64, n_levels=2, n_heads=4, n_points=2)
+            self.lin = nn.Linear(3, 5)
+            self.b = MSDeformAttn(d_model=64, n_levels=2, n_heads=4, n_points=2)
+
+    torch.manual_seed(0)
+    root = Root()
+    for p in root.parameters():
+        nn.init.normal_(p)
+    named = list(root.named_parameters())
+    names, params, groups = paired_query_projections(root, named)
+    assert sorted(names) == sorted(n for n, _ in named) and sum(len(g[0]) for g in groups) == len(named)
+    flat = torch.cat([p.reshape(-1) for p in params]).detach().requires_grad_(True)
+    sub = split_parameters(flat, groups)
+    for n, p in named:
+        assert torch.equal(sub[n], p), n
+    for mod in ("a", "b"):
+        m = getattr(root, mod)
+        w, b = sub[f"{mod}.sampling_offsets.weight"]._msda_fused_qproj
+        assert torch.equal(w, torch.cat((m.sampling_offsets.weight, m.attention_weights.weight), 0))
+        assert torch.equal(b, torch.cat((m.sampling_offsets.bias, m.attention_weights.bias), 0))
+    w, b = sub["a.sampling_offsets.weight"]._msda_fused_qproj
+    loss = (w * 2).sum() + b.sum() + sub["lin.weight"].sum() * 3
+    # the autograd graph from the stack to the flat tensor: views and the ONE split, no narrow / slice node
+    seen, todo = set(), [loss.grad_fn]
+    while todo:
+        fn = todo.pop()
+        if fn is None or fn in seen:
+            continue
+        seen.add(fn)
+        todo += [f for f, _ in fn.next_functions]
+    kinds = {type(f).__name__ for f in seen}
+    assert not any("Slice" in k or "Narrow" in k for k in kinds), kinds
+    assert sum(1 for f in seen if "Split" in type(f).__name__) == 1, kinds
+    loss.backward()
+    assert float(flat.grad.sum()) == 2 * w.numel() + b.numel() + 3 * root.lin.weight.numel()
