@@ -15,6 +15,7 @@ from __future__ import annotations
 import os
 from typing import Dict, List, Tuple
 
+import numpy as np
 import torch
 import torch.distributed
 import torch.nn.functional as F
@@ -336,7 +337,7 @@ class ClipCriterion:
                 else:
                     qi, tj = self.matcher.solve(cost_h[li][:, free_idx])
                     gj = free_idx[tj]
-                rows_layer[b].append([li] * len(qi))
+                rows_layer[b].append(np.full((len(qi),), li, dtype=np.int64))
                 rows_q[b].append(qi)
                 rows_g[b].append(gj)
                 if li == 0:
@@ -349,31 +350,35 @@ class ClipCriterion:
         for b in range(B):
             tr, gt = tracked_instances[b], gts[b]
             n_tr = len(tr)
-            flat = lambda rows: [x for r in rows for x in r]                       # noqa: E731
             n_main = len(main_q[b][0])
+            mq, mg = (np.asarray(x, dtype=np.int64) for x in main_q[b])
             # detections nobody claimed (the host knows the matched detect queries of the last layer)
-            taken = set(int(q) for q in main_q[b][0])
-            free_list = [q for q in range(n_det_out) if q not in taken]
+            unclaimed = np.ones((n_det_out,), dtype=bool)
+            unclaimed[mq] = False
+            free_np = np.flatnonzero(unclaimed)
             # rows of (carried tracks; new tracks; unclaimed detections) the query updater keeps active: the reference's
             # ``(scores > update_thresh) | (ids >= 0)`` (models/query_updater.py:170-176), from the flags of begin_frame
-            keep_list = None
+            keep_np = None
             if flags_h[b] is not None:
                 fl = flags_h[b]
                 sc, idf, gtf = fl[:nd + n_tr], fl[nd + n_tr:nd + 2 * n_tr], fl[nd + 2 * n_tr:]
-                keep_list = [i for i in range(n_tr) if sc[nd + i] or idf[i]]
-                keep_list += [n_tr + j for j, (q, g) in enumerate(zip(*main_q[b])) if sc[q] or gtf[g]]
-                keep_list += [n_tr + n_main + k for k, q in enumerate(free_list) if sc[q]]
+                keep_np = np.concatenate((np.flatnonzero(sc[nd:nd + n_tr] | idf),
+                                          n_tr + np.flatnonzero(sc[mq] | gtf[mg]),
+                                          n_tr + n_main + np.flatnonzero(sc[free_np])))
             # ONE upload for everything the host found out
-            n_pairs = sum(len(r) for r in rows_q[b])
-            up = upload(flat(rows_layer[b]) + flat(rows_q[b]) + flat(rows_g[b]) + free_list + (keep_list or []),
+            cat = lambda rows: (np.concatenate([np.asarray(r, dtype=np.int64) for r in rows])          # noqa: E731
+                                if rows else np.zeros((0,), dtype=np.int64))
+            lay_np, q_np, g_np = cat(rows_layer[b]), cat(rows_q[b]), cat(rows_g[b])
+            n_pairs = len(q_np)
+            up = upload(np.concatenate((lay_np, q_np, g_np, free_np) + (() if keep_np is None else (keep_np,))),
                         torch.long, dev)
             lay_i, q_i, g_i = up[:n_pairs], up[n_pairs:2 * n_pairs], up[2 * n_pairs:3 * n_pairs]
-            free_q = up[3 * n_pairs:3 * n_pairs + len(free_list)]
-            keep_rows = up[3 * n_pairs + len(free_list):] if keep_list is not None else None
+            free_q = up[3 * n_pairs:3 * n_pairs + len(free_np)]
+            keep_rows = up[3 * n_pairs + len(free_np):] if keep_np is not None else None
             q_idx, gt_idx = q_i[:n_main], g_i[:n_main]                              # layer 0 comes first
 
             nt = TrackInstances(frame_height=tr.frame_height, frame_width=tr.frame_width, hidden_dim=tr.hidden_dim,
-                                num_classes=self.num_classes)
+                                num_classes=self.num_classes, device=dev)
             nt.ids = gt.ids[gt_idx]
             nt.matched_idx = gt_idx
             queries = rows_of(model_outputs["aux_outputs"][-1]["queries"], b, q_idx)
@@ -384,11 +389,12 @@ class ClipCriterion:
             nt.boxes = rows_of(model_outputs["pred_bboxes"], b, q_idx)
             nt.logits = rows_of(model_outputs["pred_logits"], b, q_idx)
             nt.iou = torch.zeros((n_main,), dtype=torch.float, device=dev)
-            nt = nt.to(dev)
+            if not nt.on_device(dev):
+                nt = nt.to(dev)
             per_clip.append({"idx": (lay_i, q_i, g_i), "n_tr": n_tr, "matched_idx": tr.matched_idx if n_tr > 0 else None})
 
             d = TrackInstances(hidden_dim=model_outputs["outputs"].shape[-1],
-                               num_classes=model_outputs["pred_logits"].shape[-1]).to(dev)
+                               num_classes=model_outputs["pred_logits"].shape[-1], device=dev)
             d.ref_pts = rows_of(model_outputs["init_ref_pts"], b, free_q)
             d.output_embed = rows_of(model_outputs["outputs"], b, free_q)
             d.logits = rows_of(model_outputs["pred_logits"], b, free_q)
@@ -404,7 +410,9 @@ class ClipCriterion:
             unmatched.append(d)
 
             # IoU of every track with the ground truth it owns (kept where it owns none)
-            tracked_instances[b] = tr = tr.to(dev)
+            if not tr.on_device(dev):
+                tr = tr.to(dev)
+            tracked_instances[b] = tr
             if len(gt) > 0:
                 iou_of = clip_ops.pair_iou if clip_ops.fused(logits_all, boxes_all, gt.boxes) else clip_ops.pair_iou_reference
                 if n_main > 0:

@@ -20,39 +20,48 @@ _TENSOR_FIELDS = (
 _EMPTY = {}
 
 
-def _empty(shape, dtype=torch.float):
-    """Shared zero-row CPU tensors for the default fields: the container is rebuilt dozens of times per frame and
-    every field is overwritten right away; a tensor with no elements cannot be modified, so sharing is safe."""
-    key = (shape, dtype)
+def _empty(shape, dtype=torch.float, device=None):
+    """Shared zero-row tensors for the default fields (CPU, or ``device``): the container is rebuilt dozens of times per
+    frame and every field is overwritten right away; a tensor with no elements cannot be modified, so sharing is safe."""
+    key = (shape, dtype) if device is None else (shape, dtype, str(device))
     t = _EMPTY.get(key)
     if t is None:
-        t = _EMPTY[key] = torch.zeros(shape, dtype=dtype)
+        t = _EMPTY[key] = torch.zeros(shape, dtype=dtype, device=device)
     return t
 
 
 class TrackInstances:
     def __init__(self, frame_height: float = 1.0, frame_width: float = 1.0, hidden_dim: int = 256,
-                 num_classes: int = 1, use_dab: bool = False):
+                 num_classes: int = 1, use_dab: bool = False, device=None):
+        """``device``: where the (empty) default fields live -- ``TrackInstances(...).to(dev)`` without the fifteen
+        per-field moves (the criterion builds two of these per frame behind the assignment wait)."""
         self.use_dab = use_dab
         self.frame_height = frame_height
         self.frame_width = frame_width
         self.hidden_dim = hidden_dim
         self.num_classes = num_classes
-        self.ref_pts = _empty((0, 4))
-        self.query_embed = _empty((0, hidden_dim if use_dab else 2 * hidden_dim))
-        self.ids = _empty((0,), torch.long)
-        self.boxes = _empty((0, 4))
-        self.labels = _empty((0,), torch.long)
-        self.logits = _empty((0, num_classes))
-        self.matched_idx = _empty((0,), torch.long)
-        self.output_embed = _empty((0, hidden_dim))
-        self.disappear_time = _empty((0,), torch.long)
-        self.scores = _empty((0,))
-        self.area = _empty((0,))
-        self.iou = _empty((0,))
-        self.last_output = _empty((0, hidden_dim))
-        self.long_memory = _empty((0, hidden_dim))
-        self.last_appear_boxes = _empty((0, 4))
+        d = device
+        self.ref_pts = _empty((0, 4), device=d)
+        self.query_embed = _empty((0, hidden_dim if use_dab else 2 * hidden_dim), device=d)
+        self.ids = _empty((0,), torch.long, d)
+        self.boxes = _empty((0, 4), device=d)
+        self.labels = _empty((0,), torch.long, d)
+        self.logits = _empty((0, num_classes), device=d)
+        self.matched_idx = _empty((0,), torch.long, d)
+        self.output_embed = _empty((0, hidden_dim), device=d)
+        self.disappear_time = _empty((0,), torch.long, d)
+        self.scores = _empty((0,), device=d)
+        self.area = _empty((0,), device=d)
+        self.iou = _empty((0,), device=d)
+        self.last_output = _empty((0, hidden_dim), device=d)
+        self.long_memory = _empty((0, hidden_dim), device=d)
+        self.last_appear_boxes = _empty((0, 4), device=d)
+
+    def on_device(self, device) -> bool:
+        """Every tensor field already lives on ``device`` (then ``to(device)`` would only rebuild the container)."""
+        device = torch.device(device)
+        return all((v.device.type == device.type and (device.index is None or v.device.index == device.index))
+                   for v in vars(self).values() if type(v) is torch.Tensor)
 
     def _blank_like(self) -> "TrackInstances":
         return TrackInstances(frame_height=self.frame_height, frame_width=self.frame_width,
@@ -173,7 +182,11 @@ class TrackInstances:
         res = TrackInstances(frame_height=parts[0].frame_height, frame_width=parts[0].frame_width)
         for k, v in vars(parts[0]).items():
             if type(v) is torch.Tensor and k not in names:
-                setattr(res, k, torch.cat(tuple(getattr(t, k) for t in parts)))
+                vals = tuple(getattr(t, k) for t in parts)
+                if all(x.shape[0] == 0 for x in vals) and all(x.device == v.device and x.shape == v.shape for x in vals):
+                    setattr(res, k, v)              # nobody holds a row of it: the concatenation of empties is an empty
+                else:
+                    setattr(res, k, torch.cat(vals))
         res._set_packed(base, names, widths)
         return res
 

@@ -60,6 +60,27 @@ wrap(torch.cuda.CUDAGraph, "replay", "graph replay")
 wrap(torch.cuda.Event, "synchronize", "event wait")
 from memotr_amd.models import matcher as _m  # noqa: E402
 wrap(_m.HungarianMatcher, "solve", "scipy")
+if "--fine" in sys.argv:        # one level further down
+    from memotr_amd.functions import clip_ops as _co  # noqa: E402
+    from memotr_amd.models import criterion as _cr  # noqa: E402
+    from memotr_amd.models.decoder_graphs import DecoderGraphs  # noqa: E402
+    from memotr_amd.models.deformable_decoder import DeformableDecoder  # noqa: E402
+    from memotr_amd.models.deformable_transformer import DeformableTransformer  # noqa: E402
+    from memotr_amd.models.updater_graphs import UpdaterGraphs  # noqa: E402
+    from memotr_amd.structures.track_instances import TrackInstances  # noqa: E402
+    for name in ("get_reference_points", "get_query_embed", "get_query_mask", "_class_head_stack", "set_aux_loss"):
+        wrap(MeMOTR, name)
+    wrap(DeformableTransformer, "decode")
+    wrap(DeformableDecoder, "_forward_graphed")
+    wrap(DecoderGraphs, "run", "DecoderGraphs.run")
+    wrap(DecoderGraphs, "_flat_parameters")
+    wrap(UpdaterGraphs, "run", "UpdaterGraphs.run")
+    wrap(ClipCriterion, "update_tracked_instances")
+    wrap(_cr, "upload")
+    for name in ("to", "__getitem__", "cat_packed"):
+        wrap(TrackInstances, name, "TrackInstances." + name)
+    for name in ("match_cost", "track_ownership", "pair_iou", "focal_loss_per_layer", "focal_labels", "pair_box_loss"):
+        wrap(_co, name, "clip_ops." + name)
 
 for _ in range(2):
     log.clear()
