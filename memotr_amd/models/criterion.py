@@ -406,7 +406,8 @@ class ClipCriterion:
             d.matched_idx = -torch.ones((len(free_q),), dtype=torch.long, device=dev)
             d.iou = torch.zeros((len(free_q),), dtype=torch.float, device=dev)
             if keep_rows is not None:
-                d._keep_rows = keep_rows            # (QueryUpdater.select_active_tracks: index instead of boolean mask)
+                # (QueryUpdater.select_active_tracks: index instead of boolean mask -- valid for THIS threshold only)
+                d._keep_rows = (keep_rows, float(self.keep_threshold))
             unmatched.append(d)
 
             # IoU of every track with the ground truth it owns (kept where it owns none)

@@ -179,8 +179,9 @@ class QueryUpdater(nn.Module):
                 #  them with one gather / read them in place -- structures/track_instances.py: cat_packed)
                 active = (TrackInstances.cat_packed if PACKED_TRACKS else cat)(previous_tracks[b], new_tracks[b],
                                                                                unmatched_dets[b])
-                keep_rows = unmatched_dets[b].__dict__.pop("_keep_rows", None)
-                if keep_rows is not None and self.__dict__.get("_keep_rows_ok", False):
+                keep_rows, keep_thr = unmatched_dets[b].__dict__.pop("_keep_rows", None) or (None, None)
+                if (keep_rows is not None and self.__dict__.get("_keep_rows_ok", False)
+                        and keep_thr == float(self.update_threshold)):
                     # the criterion already knows which rows pass (models/criterion.py: finish_tracks, from flags that
                     # travelled to the host with the matching costs): an index, not a boolean mask -- no nonzero(), no
                     # second stream synchronisation per frame
