@@ -34,7 +34,12 @@ from .graph_cache import MISS_LIMIT, RETRY_AFTER, GraphCache, require_graphs  # 
 from .utils import pos_to_pos_embed
 
 BUCKET = 32
-MAX_GRAPHS = 24          # (frame slots x geometries x buckets) kept alive; least recently used go first
+# (frame slots x geometries x query buckets) kept alive; least recently used go first.  A clip of five frames whose track
+# counts wander over five buckets of 32 is already 25 keys -- one more than round 5's limit of 24, and an LRU cache one
+# entry short of its working set misses on EVERY lookup (a capture costs two warm-up passes and the capture: ~0.1 s).
+# A graph pair holds ~0.25 GB (its static copies of `src`, the flat parameters and the value bank): 48 of them is 12 GB
+# of 288.
+MAX_GRAPHS = int(os.environ.get("MEMOTR_MAX_DECODER_GRAPHS", "48"))
 # (the thrash guard -- MISS_LIMIT / RETRY_AFTER -- and MEMOTR_REQUIRE_GRAPHS live in graph_cache.py)
 
 

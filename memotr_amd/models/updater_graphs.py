@@ -28,7 +28,9 @@ from .decoder_graphs import checked_capture
 from .graph_cache import GraphCache
 
 BUCKET = 16
-MAX_GRAPHS = 24          # (frame slots x clips of the batch x buckets) kept alive; least recently used go first
+# (frame slots x clips of the batch x row buckets) kept alive; least recently used go first -- small graphs (a few MB each);
+# sized so that the working set of a training run (5 slots x up to a dozen buckets of 16 rows) fits
+MAX_GRAPHS = int(os.environ.get("MEMOTR_MAX_UPDATER_GRAPHS", "64"))
 
 
 def enabled() -> bool:

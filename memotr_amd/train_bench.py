@@ -144,5 +144,7 @@ def run_train(args, rank: int, world: int, clip_len: int = None, height: int = 8
 def _graph_stats(model) -> dict:
     g = getattr(model, "module", model).transformer.decoder.graphs()
     e = getattr(model, "module", model).encode_graphs()
+    u = getattr(model, "module", model).query_updater.graphs()
     return {"captures": g.captures, "replays": g.replays, "eager": g.eager, "failed": bool(g.failed),
-            "encode_captures": e.captures, "encode_replays": e.replays, "encode_eager": e.eager}
+            "encode_captures": e.captures, "encode_replays": e.replays, "encode_eager": e.eager,
+            "updater_captures": u.captures, "updater_replays": u.replays, "updater_eager": u.eager}

@@ -11,8 +11,8 @@ fi
 run() { name=$1; shift; t0=$SECONDS; python bench.py "$@" 2> gpurun_out/lines/$name.err | tail -1 > gpurun_out/lines/$name.json; echo "$name: $((SECONDS - t0)) s wall"; cut -c1-160 gpurun_out/lines/$name.json; }
 case "${1:-all}" in
   bdd|all)
-    run ${R}_bench_config5_bdd100k_bf16 --config bdd100k --dtype bf16 --steps 6 --warmup 3 --no-cpu-baseline
-    run ${R}_bench_config5_bdd100k_f32 --config bdd100k --dtype f32 --steps 6 --warmup 3 --no-cpu-baseline
+    run ${R}_bench_config5_bdd100k_bf16 --config bdd100k --dtype bf16 --steps 10 --warmup 14 --no-cpu-baseline
+    run ${R}_bench_config5_bdd100k_f32 --config bdd100k --dtype f32 --steps 10 --warmup 14 --no-cpu-baseline
     du -sh gpurun_out/miopen/db gpurun_out/miopen/cache ;;&
   rest|all)
     run ${R}_bench_config4_mot17_checkpoint --config mot17 --use-checkpoint --steps 8 --warmup 3 --no-cpu-baseline
