@@ -759,3 +759,48 @@ def test_full_size_frame_real_model_default_kernels_vs_oracle_operator(monkeypat
     assert worst < 1e-2, worst
     # what the default path ran: the encoder's self-attention calls are the last operator calls of the backward
     assert "tile_bins" in kernels[0]["backward"], kernels[0]
+
+
+def test_active_track_rows_from_the_host_equal_the_boolean_mask_on_the_kernel_path(monkeypatch):
+    """The GPU side of tests/test_model_golden.py::test_active_track_rows_from_the_host_equal_the_boolean_mask: here the
+    flags are written into the head of the buffer the ownership / cost KERNELS fill (models/criterion.py: begin_frame,
+    the `kernels` branch), the decoder and the updater replay from their hipGraphs; same rows, ids and loss as the
+    boolean mask, with a threshold that keeps some unclaimed detections and drops others."""
+    from memotr_amd.engine import clip_forward_backward
+    from memotr_amd.models.criterion import build as build_criterion
+    from memotr_amd.models.query_updater import QueryUpdater
+    g = load_model_golden("M6_train_step")
+    T = 3
+    batch = {"imgs": [[t(g[f"img{i}"]).cuda() for i in range(T)]],
+             "infos": [[{"ids": t(g[f"gt{i}_ids"]).cuda(), "labels": torch.zeros(6, dtype=torch.long).cuda(),
+                         "boxes": t(g[f"gt{i}_boxes"]).cuda()} for i in range(T)]]}
+    results = {}
+    orig = QueryUpdater.select_active_tracks
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MEMOTR_KEEP_ROWS", mode)
+        model = build_memotr_cuda(g).train()
+        model.query_updater.update_threshold = 0.50915       # scores of this model: 0.5085-0.5093
+        model.encode_chunks = "all"
+        cfg = small_config()
+        cfg.update(MATCH_COST_CLASS=2, MATCH_COST_BBOX=5, MATCH_COST_GIOU=2, LOSS_WEIGHT_FOCAL=2, LOSS_WEIGHT_L1=5,
+                   LOSS_WEIGHT_GIOU=2, AUX_LOSS_WEIGHT=[1.0], SAMPLE_LENGTHS=[2, 3, 4, 5])
+        criterion = build_criterion(cfg)
+        used, kept = [], []
+
+        def spy(self, prev, new, unm, no_augment=False):
+            used.append("_keep_rows" in unm[0].__dict__)
+            out = orig(self, prev, new, unm, no_augment=no_augment)
+            kept.append((len(prev[0]), len(new[0]), len(unm[0]), out[0].ids.clone(), out[0].boxes.detach().clone()))
+            return out
+
+        monkeypatch.setattr(QueryUpdater, "select_active_tracks", spy)
+        loss, _ = clip_forward_backward(model, criterion, batch, torch.device("cuda"))
+        monkeypatch.setattr(QueryUpdater, "select_active_tracks", orig)
+        assert used == [mode == "1"] * (T - 1)
+        results[mode] = (float(loss), kept)
+    (l1, k1), (l0, k0) = results["1"], results["0"]
+    assert any(len(ids) > n_prev + n_new for n_prev, n_new, _, ids, _ in k1)
+    assert any(len(ids) < n_prev + n_new + n_unm for n_prev, n_new, n_unm, ids, _ in k1)
+    for a, b in zip(k1, k0):
+        assert a[:3] == b[:3] and torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
+    np.testing.assert_allclose(l1, l0, rtol=1e-6)       # (float atomics in the operator backward do not touch the loss)
