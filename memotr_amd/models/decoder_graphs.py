@@ -294,7 +294,7 @@ class DecoderGraphs(GraphCache):
     """Cache of captured decoder steps, owned by a ``DeformableDecoder``."""
 
     def __init__(self, decoder):
-        super().__init__("decoder", MAX_GRAPHS)
+        super().__init__("decoder", MAX_GRAPHS, grow_cap=2)
         self.decoder = decoder
 
     def usable(self, output, src) -> bool:

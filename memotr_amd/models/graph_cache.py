@@ -48,9 +48,15 @@ class GraphCache:
     ``failed`` and counted itself in ``captures`` otherwise).  Counters: ``captures`` graphs built, ``replays`` calls
     served from a graph (counted by the owner), ``eager`` eligible calls that ran eagerly."""
 
-    def __init__(self, what: str, max_graphs: int):
+    def __init__(self, what: str, max_graphs: int, grow_cap: int = 1):
+        """``grow_cap`` > 1: when a key that was EVICTED is asked for again the limit doubles, up to ``grow_cap`` times
+        the initial one -- an LRU cache one entry short of its working set misses on every lookup, and a capture costs
+        ~0.1 s; the consecutive-miss guard below does not see that pattern (its misses are interleaved with hits)."""
         self.what = what
         self.max_graphs = max_graphs
+        self._max_cap = max_graphs * max(1, int(grow_cap))
+        self._evicted: "OrderedDict[tuple, bool]" = OrderedDict()
+        self.regrown = 0
         self.slots: "OrderedDict[tuple, object]" = OrderedDict()
         self.failed = False
         self.captures = 0
@@ -72,6 +78,9 @@ class GraphCache:
                 self.eager += 1
                 return None
             self._paused_at, self._misses = None, 0
+        if key in self._evicted and self.max_graphs < self._max_cap:
+            self.max_graphs = min(2 * self.max_graphs, self._max_cap)      # the working set did not fit: make room
+            self.regrown += 1
         self._misses += 1
         if self._misses > MISS_LIMIT and not require_graphs():
             self._paused_at = self.eager
@@ -82,8 +91,12 @@ class GraphCache:
             self.eager += 1
             return None
         self.slots[key] = entry
+        self._evicted.pop(key, None)
         while len(self.slots) > self.max_graphs:
-            self.slots.popitem(last=False)
+            gone, _ = self.slots.popitem(last=False)
+            self._evicted[gone] = True
+            while len(self._evicted) > 8 * self._max_cap:
+                self._evicted.popitem(last=False)
         return entry
 
     def capture_failed(self, exc: Exception):

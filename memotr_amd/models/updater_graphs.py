@@ -56,7 +56,7 @@ class UpdaterGraphs(GraphCache):
     """Cache of captured embedding updates, owned by a ``QueryUpdater``."""
 
     def __init__(self, updater):
-        super().__init__("query updater", MAX_GRAPHS)
+        super().__init__("query updater", MAX_GRAPHS, grow_cap=4)
         self.updater = updater
 
     def usable(self, fields) -> bool:

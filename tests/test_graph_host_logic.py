@@ -212,3 +212,29 @@ def test_flat_parameters_split_once_with_the_stacked_query_projection_as_one_pie
     assert sum(1 for f in seen if "Split" in type(f).__name__) == 1, kinds
     loss.backward()
     assert float(flat.grad.sum()) == 2 * w.numel() + b.numel() + 3 * root.lin.weight.numel()
+
+
+def test_graph_cache_grows_when_an_evicted_key_comes_back(monkeypatch):
+    """models/graph_cache.py: a working set one key larger than the limit would miss on every lookup of a cyclic access
+    pattern (five frame slots x the track-count buckets of a training run); the limit doubles, up to ``grow_cap`` x, the
+    first time an evicted key is asked for again -- and not before."""
+    from memotr_amd.models.graph_cache import GraphCache
+    monkeypatch.setenv("MEMOTR_REQUIRE_GRAPHS", "1")
+    made = []
+
+    def cap(k):
+        made.append(k)
+        return ("graph", k)
+
+    cache = GraphCache("test", 4, grow_cap=2)
+    for rnd in range(3):
+        for k in range(5):                               # a working set of five on a limit of four
+            assert cache.lookup(k, lambda k=k: cap(k)) == ("graph", k)
+    # round 0: five captures, key 0 evicted; round 1: key 0 comes back -> limit 8, captured once more; then all hits
+    assert made == [0, 1, 2, 3, 4, 0] and cache.max_graphs == 8 and cache.regrown == 1 and len(cache.slots) == 5
+    fixed = GraphCache("test", 4)                        # grow_cap 1: the old behaviour
+    n = []
+    for rnd in range(3):
+        for k in range(5):
+            fixed.lookup(k, lambda k=k: n.append(k) or ("graph", k))
+    assert len(n) == 15 and fixed.max_graphs == 4
