@@ -42,6 +42,9 @@ struct WinPlan {
     int steps;                     // ceil(rows / 4)
     int lwin0;                     // first level served from an LDS window
     int rlogx, rlogy;              // log2 of the region width / height on level 0
+    int rsx, rsy;                  // region width / height on level 0 in pixels (1 << rlogx, 1 << rlogy; any size in grid mode)
+    int grid;                      // 1: equal regions of rsy x rsx level-0 pixels, any size (make_win_plan_grid): level l's
+                                   //    pixels go to the region their centre falls into (win_bound)
     int H[kWinMaxL], W[kWinMaxL];
     int qstart[kWinMaxL];          // first query of level l
     int shx[kWinMaxL], shy[kWinMaxL];   // log2 of the region width / height on level l
@@ -83,6 +86,14 @@ struct WinTables {
 // queries and pixels per level below 2^23, row strides below 2^23.
 __device__ __forceinline__ unsigned win_umul24(unsigned a, unsigned b) { return (unsigned)__umul24(a, b); }
 __device__ __forceinline__ int win_mul24(int a, int b) { return __mul24(a, b); }
+
+// Grid mode: first pixel of region r on a level of n pixels, for regions of rs pixels on the finest level (n0 pixels):
+// the pixels whose centre, (y + 0.5) n0 / n in level-0 coordinates, lies at or beyond r rs -- ceil(r rs n / n0 - 1/2).
+// Monotone in r, 0 for r = 0, and r rs itself on the finest level: every pixel of every level has exactly one region.
+__host__ __device__ __forceinline__ int win_bound(int r, int rs, int n, int n0) {
+    const int b = (int)((2 * (long long)r * rs * n + n0 - 1) / (2 * (long long)n0));
+    return b > n ? n : b;
+}
 
 struct WinRow {
     bool ok;
@@ -257,8 +268,8 @@ typedef __attribute__((address_space(3))) void lds_void;
 // Window origin of level l: centred on the region's centre in level-l sampling coordinates plus the mean sampling
 // offset (dx, dy), kept on the level and its one-pixel zero border.
 __device__ __forceinline__ void win_place(WinTables &tb, const WinPlan &pl, int l, int ry, int rx, float dx, float dy) {
-    const float cx = ((float)(rx << pl.rlogx) + 0.5f * (float)(1 << pl.rlogx)) * pl.ratw[0][l] - 0.5f + dx;
-    const float cy = ((float)(ry << pl.rlogy) + 0.5f * (float)(1 << pl.rlogy)) * pl.rath[0][l] - 0.5f + dy;
+    const float cx = ((float)(rx * pl.rsx) + 0.5f * (float)pl.rsx) * pl.ratw[0][l] - 0.5f + dx;
+    const float cy = ((float)(ry * pl.rsy) + 0.5f * (float)pl.rsy) * pl.rath[0][l] - 0.5f + dy;
     const int ww = pl.ww[l], wh = pl.wh[l];
     int ox = (int)floorf(cx - 0.5f * (float)(ww - 1) + 0.5f);
     int oy = (int)floorf(cy - 0.5f * (float)(wh - 1) + 0.5f);
@@ -349,10 +360,16 @@ __global__ __launch_bounds__(WPS == 4 ? 512 : 256, WPS) void msda_fwd_d32_win(co
 #pragma unroll
         for (int i = 0; i < kWinMaxL; ++i) {
             const int sy = pl.shy[i], sx = pl.shx[i];
-            const int y0 = ry << sy, x0 = rx << sx;
+            int y0 = ry << sy, x0 = rx << sx;
             int hv = pl.H[i] - y0, wv = pl.W[i] - x0;
             hv = hv > (1 << sy) ? (1 << sy) : (hv < 0 ? 0 : hv);
             wv = wv > (1 << sx) ? (1 << sx) : (wv < 0 ? 0 : wv);
+            if (pl.grid) {
+                y0 = win_bound(ry, pl.rsy, pl.H[i], pl.H[0]);
+                x0 = win_bound(rx, pl.rsx, pl.W[i], pl.W[0]);
+                hv = (ry + 1 == pl.RY ? pl.H[i] : win_bound(ry + 1, pl.rsy, pl.H[i], pl.H[0])) - y0;
+                wv = (rx + 1 == pl.RX ? pl.W[i] : win_bound(rx + 1, pl.rsx, pl.W[i], pl.W[0])) - x0;
+            }
             if (i >= L) hv = 0;
             if (tid == i) {
                 mine = base;
@@ -898,6 +915,7 @@ inline bool make_win_plan(WinPlan &pl, const int64_t *shapes_host, int N, int S,
     if (lwin0 > L) lwin0 = L;
     memset(&pl, 0, sizeof(pl));
     pl.N = N; pl.S = S; pl.M = M; pl.L = L; pl.P = P; pl.Lq = Lq; pl.lwin0 = lwin0; pl.rlogx = rlogx; pl.rlogy = rlogy;
+    pl.rsx = 1 << rlogx; pl.rsy = 1 << rlogy; pl.grid = 0;
     pl.value_bytes = (unsigned)value_bytes;
     long q = 0;
     int rows = 0, px = 0, RY = 0, RX = 0;
@@ -947,6 +965,102 @@ inline bool make_win_plan(WinPlan &pl, const int64_t *shapes_host, int N, int S,
     pl.RYf = (int)(shapes_host[0] >> rlogy); pl.RXf = (int)(shapes_host[1] >> rlogx);
     if (pl.RYf > RY) pl.RYf = RY;
     if (pl.RXf > RX) pl.RXf = RX;
+    pl.rcpP = (float)(1.0 / (double)P);
+    for (int a = 0; a < kWinMaxL; ++a)
+        for (int c = 0; c < kWinMaxL; ++c) {
+            pl.ratw[a][c] = (float)((double)pl.W[c] / (double)pl.W[a]);
+            pl.rath[a][c] = (float)((double)pl.H[c] / (double)pl.H[a]);
+        }
+    pl.groups = lwin0 < L ? px / gp + 1 : 0;
+    pl.gplog = gplog;
+    const long nb = (long)N * RY * RX * M;
+    if (nb > (1L << 30)) return false;
+    pl.n_blocks = (int)nb;
+    lds = (size_t)pl.groups * 1024 + (size_t)(threads / 64) * 2048 + (size_t)pl.steps * 16;
+    return lds <= 160 * 1024 - 4096;
+}
+
+
+// Grid mode (round 6, late): the finest level is cut into ceil(H0 / rsy) x ceil(W0 / rsx) EQUAL regions of any size, and
+// every coarser pixel goes to the region its centre falls into (win_bound).  Why: the power-of-two regions of an
+// 800 x 1333 image are 77 per head -- 60 whole, 17 partial -- on the 64 workgroup slots of the XCD that head runs on; the
+// partial ones start when a slot frees and pay a whole prologue each, a quarter of the launch at N = 1.  63 equal regions
+// (12 x 24 pixels) are one round.  Same kernel: the per-region tables already hold a rectangle per level.
+// Window of level l: ceil(rs H_l / H_0) pixels + 2 margin + 1 (the misalignment of a region against the coarser pixels is
+// paid out of the margin; results never depend on the windows, only the speed does).
+inline bool make_win_plan_grid(WinPlan &pl, const int64_t *shapes_host, int N, int S, int M, int D, int L, int Lq, int P,
+                               long value_bytes, int rsy, int rsx, int lwin0, const int *margins, int threads,
+                               size_t &lds, int elem_bytes = 4) {
+    const int gplog = elem_bytes == 4 ? 3 : 4, gp = 1 << gplog;
+    if (!shapes_host || D != 32 || L < 1 || L > kWinMaxL || Lq != S || L * P > 16) return false;
+    if (rsy < 1 || rsx < 1 || rsy > 64 || rsx > 64 || threads < 64 || threads > 512 || (threads & 63)) return false;
+    if (lwin0 < 0) lwin0 = 0;
+    if (lwin0 > L) lwin0 = L;
+    memset(&pl, 0, sizeof(pl));
+    pl.N = N; pl.S = S; pl.M = M; pl.L = L; pl.P = P; pl.Lq = Lq; pl.lwin0 = lwin0;
+    pl.rsx = rsx; pl.rsy = rsy; pl.grid = 1; pl.rlogx = pl.rlogy = 0;
+    pl.value_bytes = (unsigned)value_bytes;
+    const long H0 = shapes_host[0], W0 = shapes_host[1];
+    if (H0 <= 0 || W0 <= 0) return false;
+    const int RY = (int)((H0 + rsy - 1) / rsy), RX = (int)((W0 + rsx - 1) / rsx);
+    long q = 0;
+    int px = 0;
+    for (int l = 0; l < kWinMaxL; ++l) {
+        if (l < L) {
+            const long H = shapes_host[2 * l], W = shapes_host[2 * l + 1];
+            if (H <= 0 || W <= 0 || H > 32767 || W > 32767 || W * M >= (1L << 23) || H * W >= (1L << 23)) return false;
+            if (H > H0 || W > W0) return false;            // (a pyramid: no level finer than the first)
+            const int side_y = (int)((rsy * H + H0 - 1) / H0), side_x = (int)((rsx * W + W0 - 1) / W0);
+            int ww = 0, wh = 0;
+            if (l >= lwin0) {
+                int mg = margins ? margins[l] : 3;
+                if (mg < 0) mg = 0;
+                ww = side_x + 2 * mg + 1;
+                wh = side_y + 2 * mg + 1;
+                if (ww > (int)W + 2) ww = (int)W + 2;
+                if (wh > (int)H + 2) wh = (int)H + 2;
+                if (ww < 2) ww = 2;
+                if (wh < 2) wh = 2;
+            }
+            pl.H[l] = (int)H; pl.W[l] = (int)W; pl.qstart[l] = (int)q; pl.shx[l] = 0; pl.shy[l] = 0;
+            pl.rcpH[l] = (float)(1.0 / (double)H); pl.rcpW[l] = (float)(1.0 / (double)W);
+            pl.ww[l] = ww; pl.wh[l] = wh; pl.wbase[l] = px;
+            int magic = 65537;
+            if (ww > 0) {
+                if (ww * wh >= 32768) return false;
+                magic = 65536 / ww + 1;
+                for (int x = 0; x < ww * wh; ++x)
+                    if (((x * magic) >> 16) != x / ww) return false;
+            }
+            pl.wmagic[l] = magic;
+            q += H * W; px += (ww * wh + gp - 1) & ~(gp - 1);
+            if ((ww * wh + gp - 1) / gp > pl.wgroups_max) pl.wgroups_max = (ww * wh + gp - 1) / gp;
+        } else {
+            pl.H[l] = 1; pl.W[l] = 1; pl.qstart[l] = (int)q;
+            pl.rcpH[l] = pl.rcpW[l] = 1.f;
+            pl.ww[l] = 0; pl.wh[l] = 0; pl.wmagic[l] = 65537; pl.wbase[l] = px;
+        }
+    }
+    if (q != S) return false;
+    if ((long)N * Lq * M >= (1L << 24) || (long)M * 32 * elem_bytes >= (1L << 23)) return false;
+    pl.wbase[kWinMaxL] = px;
+    // rows of the largest region (the row table's size); a row of a region must stay below 33 pixels and a level of a
+    // region below 1024 (win_row's division)
+    int rows_max = 0;
+    for (int ry = 0; ry < RY; ++ry)
+        for (int rx = 0; rx < RX; ++rx) {
+            int rows = 0;
+            for (int l = 0; l < L; ++l) {
+                const int hv = (ry + 1 == RY ? pl.H[l] : win_bound(ry + 1, rsy, pl.H[l], pl.H[0])) - win_bound(ry, rsy, pl.H[l], pl.H[0]);
+                const int wv = (rx + 1 == RX ? pl.W[l] : win_bound(rx + 1, rsx, pl.W[l], pl.W[0])) - win_bound(rx, rsx, pl.W[l], pl.W[0]);
+                if (hv < 0 || wv < 0 || wv > 32 || hv * wv >= 1024) return false;
+                rows += hv * wv;
+            }
+            rows_max = rows > rows_max ? rows : rows_max;
+        }
+    if (rows_max < 1) return false;
+    for (int l = 0; l <= kWinMaxL; ++l) pl.row0[l] = 0;      // (per region: the kernel's tables)
+    pl.rows = rows_max; pl.steps = (rows_max + 3) / 4; pl.RY = RY; pl.RX = RX; pl.RYf = RY; pl.RXf = RX;
     pl.rcpP = (float)(1.0 / (double)P);
     for (int a = 0; a < kWinMaxL; ++a)
         for (int c = 0; c < kWinMaxL; ++c) {

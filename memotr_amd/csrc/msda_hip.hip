@@ -49,7 +49,9 @@
 #include <string.h>
 
 #include <atomic>
+#include <mutex>
 #include <type_traits>
+#include <vector>
 
 #include "../../include/msda_hip.h"
 #include "msda_common.h"
@@ -120,6 +122,8 @@ std::atomic<int> opt_fwd_win_l0{1};         // first level served from an LDS wi
 std::atomic<int> opt_fwd_win_margins{0x3333};  // window margin per level, 4 bits each (level 0 in the low nibble)
 std::atomic<int> opt_fwd_win_ablate{0};     // profiling only
 std::atomic<int> opt_fwd_win_place{0};      // 1: measured window placement in every workgroup (rounds 3-4)
+std::atomic<int> opt_fwd_win_grid{1};       // 1: the default shape may become equal regions of any size when that fills the slots in fewer rounds (0: never)
+std::atomic<int> opt_fwd_win_rsy{0}, opt_fwd_win_rsx{0};   // region height / width on level 0 in pixels: grid mode with exactly this size (0: by estimate)
 std::atomic<int> opt_fwd_win_wps{0};        // 3 / 4: force the 168- / 128-register build; 2 (256 threads): the 256-register build
 std::atomic<int> opt_fwd_win_early{9};      // 0 / 2 / 4: level-0 points requested before the LDS phase (else: by register budget)
 constexpr int kWinEarlyW4 = 0;              // ... of the 128-register build (0 and 2 time the same; 0 needs 107 registers, no spill)
@@ -257,6 +261,94 @@ bool make_bins_plan(BinsPlan &bp, const TilePlan &pl, int ni, size_t &lds) {
     o += up16((size_t)(pl.rows + 1) * 4);
     lds = o;
     return lds <= 64 * 1024;
+}
+
+// ---- grid mode of the windowed forward: which region size, if any ----
+// Estimate of a launch in "row units": a workgroup costs kWinPrologueRows + its rows, the workgroups of one XCD (an eighth
+// of the launch: head-major numbering, one contiguous run per XCD) are handed to its 64 slots (32 CUs x two 512-thread
+// workgroups) in dispatch order as slots free up.  The power-of-two plan's partial border regions come last; equal
+// regions all cost the same.  Grid mode is taken when its best size is at least 7 % faster by this estimate AND keeps two
+// workgroups per CU (LDS); the choice is cached per geometry.
+constexpr int kWinPrologueRows = 140;      // (prologue ~ 10 of the 34 us a 340-row workgroup takes under load)
+
+inline double win_makespan(const std::vector<int> &dur_one, long repeats, int slots) {
+    std::vector<double> free_at((size_t)slots, 0.0);      // a binary heap by hand would be faster; this runs once per geometry
+    double end = 0.0;
+    for (long r = 0; r < repeats; ++r)
+        for (int d : dur_one) {
+            size_t k = 0;
+            for (size_t i = 1; i < free_at.size(); ++i)
+                if (free_at[i] < free_at[k]) k = i;
+            free_at[k] += (double)(kWinPrologueRows + d);
+            end = free_at[k] > end ? free_at[k] : end;
+        }
+    return end;
+}
+
+struct WinGridChoice {
+    long key[12];
+    int rsy, rsx;
+};
+
+inline void win_grid_choice(const WinPlan &p2, const int64_t *shapes_host, int N, int S, int M, int D, int L, int Lq, int P,
+                            long value_bytes, int lwin0, const int *margins, int threads, int margin_bits, int &rsy,
+                            int &rsx) {
+    rsy = rsx = 0;
+    if (L < 1 || L > kWinMaxL || (M % 8) != 0) return;
+    static std::mutex mu;
+    static std::vector<WinGridChoice> cache;
+    WinGridChoice c;
+    memset(&c, 0, sizeof(c));
+    for (int l = 0; l < L; ++l) { c.key[2 * l] = shapes_host[2 * l]; c.key[2 * l + 1] = shapes_host[2 * l + 1]; }
+    c.key[8] = N; c.key[9] = M; c.key[10] = ((long)L << 40) | ((long)P << 32) | ((long)lwin0 << 24) | (long)margin_bits;
+    c.key[11] = threads;
+    {
+        std::lock_guard<std::mutex> g(mu);
+        for (const WinGridChoice &e : cache)
+            if (!memcmp(e.key, c.key, sizeof(c.key))) { rsy = e.rsy; rsx = e.rsx; return; }
+    }
+    const int slots = 64;
+    const long per_xcd = (long)N * M / 8;              // (head, image) pairs per XCD
+    // the power-of-two plan in its dispatch order: complete regions, right border column, bottom border row
+    std::vector<int> d2;
+    {
+        auto rows_of = [&](int ry, int rx) {
+            int rows = 0;
+            for (int l = 0; l < L; ++l) {
+                const int sy = p2.shy[l], sx = p2.shx[l];
+                int hv = p2.H[l] - (ry << sy), wv = p2.W[l] - (rx << sx);
+                hv = hv > (1 << sy) ? (1 << sy) : (hv < 0 ? 0 : hv);
+                wv = wv > (1 << sx) ? (1 << sx) : (wv < 0 ? 0 : wv);
+                rows += hv * wv;
+            }
+            return rows;
+        };
+        for (int ry = 0; ry < p2.RYf; ++ry) for (int rx = 0; rx < p2.RXf; ++rx) d2.push_back(rows_of(ry, rx));
+        for (int ry = 0; ry < p2.RYf; ++ry) for (int rx = p2.RXf; rx < p2.RX; ++rx) d2.push_back(rows_of(ry, rx));
+        for (int ry = p2.RYf; ry < p2.RY; ++ry) for (int rx = 0; rx < p2.RX; ++rx) d2.push_back(rows_of(ry, rx));
+    }
+    const double cost2 = win_makespan(d2, per_xcd, slots);
+    double best = cost2 * 0.93;
+    const long H0 = shapes_host[0], W0 = shapes_host[1];
+    for (int ty = 4; ty <= 40; ++ty)
+        for (int tx = 4; tx <= 32; ++tx) {
+            const long nreg = ((H0 + ty - 1) / ty) * ((W0 + tx - 1) / tx);
+            if (nreg * per_xcd < slots / 2) continue;                   // too few workgroups to fill the XCD at all
+            // a lower bound before the plan: all regions at most ty tx (1 + 1/4 + 1/16 + 1/64) rows
+            WinPlan g;
+            size_t glds = 0;
+            if (!make_win_plan_grid(g, shapes_host, N, S, M, D, L, Lq, P, value_bytes, ty, tx, lwin0, margins, threads, glds,
+                                    4))
+                continue;
+            if (glds + 512 > 80 * 1024) continue;                       // two workgroups per CU, as the default shape
+            const long w = nreg * per_xcd;
+            const double cost = (double)((w + slots - 1) / slots) * (double)(kWinPrologueRows + g.rows);
+            if (cost < best) { best = cost; rsy = ty; rsx = tx; }
+        }
+    c.rsy = rsy; c.rsx = rsx;
+    std::lock_guard<std::mutex> g(mu);
+    if (cache.size() >= 64) cache.erase(cache.begin());
+    cache.push_back(c);
 }
 
 // Dynamic LDS above 64 KiB needs an opt-in per kernel; do it once per kernel and device for the full
@@ -601,6 +693,28 @@ int forward_impl(const TV *value, const int64_t *shapes, const int64_t *lstart, 
                 bool planned = make_win_plan(wp, shapes_host, N, S, M, D, L, Lq, P, value_bytes, rlogx, rlogy,
                                              opt_fwd_win_l0.load(), margins, threads, lds, (int)sizeof(TV)) &&
                                !(src.mask != nullptr && wp.wgroups_max > kMaskGroups * (threads / 64));
+                // Equal regions of any size (make_win_plan_grid) where they fill the workgroup slots in fewer rounds than
+                // the power-of-two ones: asked for by size ("fwd_win_rsy" / "fwd_win_rsx"), or chosen by estimate for the
+                // default shape (win_grid_choice, cached per geometry)
+                {
+                    int rsy = opt_fwd_win_rsy.load(), rsx = opt_fwd_win_rsx.load();
+                    if (rsy <= 0 && rsx <= 0 && auto_shape && planned && opt_fwd_win_grid.load() != 0 && sizeof(TV) == 4)
+                        win_grid_choice(wp, shapes_host, N, S, M, D, L, Lq, P, value_bytes, opt_fwd_win_l0.load(), margins,
+                                        threads, mgs, rsy, rsx);
+                    if (rsy > 0 || rsx > 0) {
+                        if (rsy <= 0) rsy = rsx;
+                        if (rsx <= 0) rsx = rsy;
+                        WinPlan gp_;
+                        size_t glds = 0;
+                        if (make_win_plan_grid(gp_, shapes_host, N, S, M, D, L, Lq, P, value_bytes, rsy, rsx,
+                                               opt_fwd_win_l0.load(), margins, threads, glds, (int)sizeof(TV)) &&
+                            !(src.mask != nullptr && gp_.wgroups_max > kMaskGroups * (threads / 64))) {
+                            wp = gp_;
+                            lds = glds;
+                            planned = true;
+                        }
+                    }
+                }
                 if (!planned && auto_shape) {
                     threads = 256;
                     planned = make_win_plan(wp, shapes_host, N, S, M, D, L, Lq, P, value_bytes, 3, 3,
@@ -1521,6 +1635,9 @@ static std::atomic<int> *find_opt(const char *key) {
     if (!strcmp(key, "fwd_win_ablate")) return &opt_fwd_win_ablate;
     if (!strcmp(key, "fwd_win_place")) return &opt_fwd_win_place;
     if (!strcmp(key, "fwd_win_wps")) return &opt_fwd_win_wps;
+    if (!strcmp(key, "fwd_win_grid")) return &opt_fwd_win_grid;
+    if (!strcmp(key, "fwd_win_rsy")) return &opt_fwd_win_rsy;
+    if (!strcmp(key, "fwd_win_rsx")) return &opt_fwd_win_rsx;
     if (!strcmp(key, "fwd_win_early")) return &opt_fwd_win_early;
     return nullptr;
 }

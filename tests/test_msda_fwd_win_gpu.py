@@ -20,7 +20,7 @@ from fused_helpers import expected, make_case
 pytestmark = pytest.mark.gpu
 
 WIN_DEFAULTS = dict(fwd_win_rlog=0, fwd_win_rlogx=0, fwd_win_block=0, fwd_win_l0=1, fwd_win_margins=0x3333, fwd_win_early=9,
-                    fwd_win_wps=0)
+                    fwd_win_wps=0, fwd_win_grid=1, fwd_win_rsy=0, fwd_win_rsx=0)
 
 
 @pytest.fixture(scope="module")
@@ -98,6 +98,15 @@ CONFIGS = [
     dict(fwd_win_rlog=4, fwd_win_block=256, fwd_win_wps=2, fwd_win_early=0),
     dict(fwd_win_rlog=4, fwd_win_block=256, fwd_win_wps=2, fwd_win_early=4),
     dict(fwd_win_rlog=3, fwd_win_block=256, fwd_win_wps=2, fwd_win_early=4, fwd_win_margins=0x1111),   # ... points leaving their windows
+    # round 6, late: equal regions of any size (grid mode); the regions of a coarser level are whatever pixels' centres
+    # fall into a region -- odd sizes, sizes that divide nothing, one region per image, the estimate switched off
+    dict(fwd_win_rsy=12, fwd_win_rsx=24),
+    dict(fwd_win_rsy=13, fwd_win_rsx=21, fwd_win_margins=0x2333),
+    dict(fwd_win_rsy=7, fwd_win_rsx=9),
+    dict(fwd_win_rsy=17, fwd_win_rsx=17, fwd_win_margins=0x2222),
+    dict(fwd_win_rsy=5, fwd_win_rsx=32, fwd_win_block=256),
+    dict(fwd_win_rsy=25, fwd_win_rsx=11, fwd_win_margins=0x1111),
+    dict(fwd_win_grid=0),
 ]
 
 
@@ -177,8 +186,9 @@ FUSED_PYRAMIDS = [
 @pytest.mark.parametrize("case", FUSED_PYRAMIDS, ids=lambda c: f"seed{c[0]}")
 @pytest.mark.parametrize("cfg", [dict(), dict(fwd_win_rlog=3, fwd_win_block=256), dict(fwd_win_l0=0),
                                  dict(fwd_win_margins=0x1111, fwd_win_block=512), dict(fwd_win_early=0),
-                                 dict(fwd_win_rlog=4, fwd_win_block=256, fwd_win_wps=2, fwd_win_early=4)],
-                         ids=["default", "r3_b256", "all_levels", "m1_b512", "e0", "w2_p12"])
+                                 dict(fwd_win_rlog=4, fwd_win_block=256, fwd_win_wps=2, fwd_win_early=4),
+                                 dict(fwd_win_rsy=6, fwd_win_rsx=10), dict(fwd_win_grid=0)],
+                         ids=["default", "r3_b256", "all_levels", "m1_b512", "e0", "w2_p12", "grid6x10", "no_grid"])
 def test_win_fused_forward_matches_checker(msda, hip_lib, case, cfg):
     seed, N, M, P, shapes, ref_dim = case
     for k, v in cfg.items():

@@ -16,7 +16,7 @@ from memotr_amd import _lib  # noqa: E402
 from memotr_amd.synth import make_inputs  # noqa: E402
 
 DEFAULTS = dict(fwd_variant=0, fwd_win_rlog=0, fwd_win_rlogx=0, fwd_win_block=0, fwd_win_l0=1,
-                fwd_win_margins=0x3333, fwd_head_major=0, fwd_win_early=9, fwd_win_wps=0, fwd_win_place=0,
+                fwd_win_margins=0x3333, fwd_head_major=0, fwd_win_early=9, fwd_win_wps=0, fwd_win_place=0, fwd_win_grid=1, fwd_win_rsy=0, fwd_win_rsx=0,
                 sel_level=-1, auto_select=1)
 
 R3 = dict(fwd_variant=12, fwd_win_rlog=3)
@@ -51,6 +51,17 @@ CONFIGS = [
     ("r6w 16x8 256 thr w2 p12 e0", dict(R3, fwd_win_rlogx=4, fwd_win_block=256, fwd_win_wps=2, fwd_win_early=0)),
     ("r6w 8x8 256 thr w2 p12 e4", dict(R3, fwd_win_block=256, fwd_win_wps=2, fwd_win_early=4)),
     ("r6w 16x16 256 thr w4 (4 pts per wait)", dict(fwd_variant=12, fwd_win_rlog=4, fwd_win_block=256, fwd_win_wps=4, fwd_win_early=0)),
+    # round 6, last: equal regions of any size ("grid"): one round of workgroups per image at N = 1
+    ("r6g power-of-two regions only (grid=0)", dict(fwd_variant=12, fwd_win_grid=0)),
+    ("r6g grid by estimate (default)", dict(fwd_variant=12)),
+    ("r6g grid 12x24", dict(fwd_variant=12, fwd_win_rsy=12, fwd_win_rsx=24)),
+    ("r6g grid 15x19", dict(fwd_variant=12, fwd_win_rsy=15, fwd_win_rsx=19)),
+    ("r6g grid 13x21 m2333", dict(fwd_variant=12, fwd_win_rsy=13, fwd_win_rsx=21, fwd_win_margins=0x2333)),
+    ("r6g grid 13x21 m2233", dict(fwd_variant=12, fwd_win_rsy=13, fwd_win_rsx=21, fwd_win_margins=0x2233)),
+    ("r6g grid 17x17 m2333", dict(fwd_variant=12, fwd_win_rsy=17, fwd_win_rsx=17, fwd_win_margins=0x2333)),
+    ("r6g grid 20x14", dict(fwd_variant=12, fwd_win_rsy=20, fwd_win_rsx=14)),
+    ("r6g grid 10x28", dict(fwd_variant=12, fwd_win_rsy=10, fwd_win_rsx=28)),
+    ("r6g grid 12x24 e2", dict(fwd_variant=12, fwd_win_rsy=12, fwd_win_rsx=24, fwd_win_early=2)),
 ]
 
 
