@@ -316,7 +316,11 @@ int msda_fused_points_f32(const int64_t *shapes_dev, const float *proj, int proj
  *       finest level and threads per workgroup; 0 = auto: 16 x 16 pixels, 512 threads), "fwd_win_margins" (per level as
  *       0xL3L2L1L0), "fwd_win_l0" (first windowed level), "fwd_win_bf16" (1: bf16 rows take the
  *       windowed forward too; measured slower than the gather kernel, default 0), "fwd_win_early" / "fwd_win_wps" (level-0 rows requested
- *       ahead, register budget), "fwd_win_place" (1 = every workgroup measures its window placement, rounds 3-4;
+ *       ahead, register budget; "fwd_win_wps" 2 with 256 threads: the 256-register build, twelve LDS points per wait),
+ *       "fwd_win_grid" (1, default: the default shape becomes equal regions of any size when a per-XCD slot estimate
+ *       says they fill the workgroup slots in fewer rounds than the power-of-two regions; 0: never),
+ *       "fwd_win_rsy" / "fwd_win_rsx" (region height / width on the finest level in pixels: grid mode with exactly that
+ *       size), "fwd_win_place" (1 = every workgroup measures its window placement, rounds 3-4;
  *       0 = from the call site's running means), profiling switches; tools/fwd_win_sweep.py lists them;
  *       "fwd_head_major" (head-major block numbering of the gather
  *       kernel), "bwd_rows" / "bwd_rows_block" (the 32-lanes-per-row backward of decoder-shaped calls), "bwd_soft" (1: the one-kernel fused backward when the forward's output is given; 0: the side kernels), "bwd_sorted" (1: selector
