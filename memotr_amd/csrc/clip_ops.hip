@@ -935,7 +935,10 @@ typedef float lb_f32x16 __attribute__((ext_vector_type(16)));
 // One workgroup's tile.  GX: C = G' W (A rows are rows of G: one 16-byte load per lane and chunk when OUT % 4 == 0);
 // else C = G'^T X (A columns are rows of G: coalesced dwords).  LB_U chunks of 8 k are requested before the first MFMA
 // of the group -- without that every chunk waits a memory round trip and the kernel takes 40 us at K = 1024.
-constexpr int LB_U = 4;
+#ifndef MSDA_LB_U
+#define MSDA_LB_U 4
+#endif
+constexpr int LB_U = MSDA_LB_U;
 
 template <bool GX, bool RELU>
 __device__ __forceinline__ void linear_bwd_tile(const float *__restrict__ g, const float *__restrict__ y,
